@@ -1,0 +1,177 @@
+/*
+ * bnmtf_hip.h -- C ABI of libbnmtf_hip.so: the MI355X (gfx950) implementation of
+ * the Gibbs / VB inference hot path of ThomasBrouwer/BNMTF.
+ *
+ * The reference has no FFI layer: its boundary is the duck-typed Python class
+ * contract of code/models/{bnmf_gibbs,bnmtf_gibbs,bnmf_vb}_optimised.py.  Each
+ * entry point below names the reference method(s) it replaces (file:line,
+ * relative to the reference checkout).  bnmtf_amd/*.py binds these with ctypes
+ * and reproduces the class surface; INTEGRATION.md shows the stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no exceptions; every function returns 0 on success or a negative
+ *     BNMTF_E* code; bnmtf_last_error() gives the message (thread-local).
+ *   - host pointers are caller-owned, C-contiguous (row-major) and only touched
+ *     during the call; every call is synchronous at return.
+ *   - factor matrices cross the boundary as double (what the reference's
+ *     attributes hold); the device computes the O(I*J*K) contractions in fp32
+ *     (f32 MFMA) and every reduction that feeds tau / metrics in fp64.
+ *   - one host thread per handle; a handle owns its device buffers and stream.
+ *   - multi-GPU = one process (and one handle) per GPU, rows of R split over
+ *     `world` ranks for the U/F sweep, columns for the V/G sweep, freshly drawn
+ *     factor blocks exchanged with an RCCL all-gather.
+ */
+#ifndef BNMTF_HIP_H
+#define BNMTF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BNMTF_OK 0
+#define BNMTF_EINVAL (-1)   /* bad argument / unsupported shape */
+#define BNMTF_EHIP (-2)     /* HIP runtime error */
+#define BNMTF_ENOMEM (-3)
+#define BNMTF_ECOMM (-4)    /* RCCL error */
+#define BNMTF_ESTATE (-5)   /* call order (e.g. run before set_state) */
+
+#define BNMTF_MAX_RANK 64   /* K and L <= 64 (one wave lane per latent factor) */
+
+typedef struct bnmtf_model* bnmtf_handle;
+
+/* update rule applied to each conditional: Gibbs draw (the path), or the
+ * deterministic mode max(0,mu) = the ICM update of nmf_icm.py:124-134, which
+ * shares all tau/mu kernels and serves as an exact end-to-end parity harness. */
+#define BNMTF_UPDATE_DRAW 0
+#define BNMTF_UPDATE_MODE 1
+
+typedef struct bnmtf_problem {
+  int32_t I, J;              /* shape of R */
+  int32_t K;                 /* latent factors (rows factor U / F) */
+  int32_t L;                 /* 0: BNMF  R ~ U.V^T ;  >0: BNMTF  R ~ F.S.G^T */
+  const float* R;            /* I x J, full matrix; entries with M==0 are kept only for predict() */
+  const uint8_t* M;          /* I x J, 1 = observed, 0 = missing */
+  const double* lambda_rows; /* I x K   lambdaU / lambdaF */
+  const double* lambda_cols; /* J x K (lambdaV) or J x L (lambdaG) */
+  const double* lambda_S;    /* K x L, BNMTF only (else NULL) */
+  double alpha, beta;        /* Gamma prior of tau */
+  uint64_t seed;             /* Philox key */
+  int32_t device;            /* HIP device ordinal */
+  int32_t rank, world;       /* this process' shard; world == 1: single GPU */
+  const uint8_t* comm_id;    /* 128-byte id from bnmtf_comm_unique_id (world > 1) */
+} bnmtf_problem;
+
+/* ---- library ---------------------------------------------------------- */
+int bnmtf_version(void);
+const char* bnmtf_last_error(void);
+int bnmtf_device_count(int* count);
+/* rank 0 makes the id, the host code ships it to the other ranks */
+int bnmtf_comm_unique_id(uint8_t out[128]);
+
+/* ---- life cycle: bnmf_gibbs_optimised.__init__ (bnmf_gibbs_optimised.py:54-78),
+ *      bnmtf_gibbs_optimised.__init__ (bnmtf_gibbs_optimised.py:56-84).  Shape /
+ *      empty-row assertions stay in the Python class (exact messages); create
+ *      re-checks them and fails with BNMTF_EINVAL. ---------------------- */
+int bnmtf_create(const bnmtf_problem* p, bnmtf_handle* out);
+int bnmtf_destroy(bnmtf_handle h);
+int bnmtf_sync(bnmtf_handle h);
+
+/* size_Omega and the per-row / per-column observed counts (bit-exact integers;
+ * size_Omega = M.sum(), bnmf_gibbs_optimised.py:65; counts :83-84).
+ * row/col may be NULL. */
+int bnmtf_omega_counts(bnmtf_handle h, uint64_t* total, uint32_t* row, uint32_t* col);
+
+/* Gibbs iteration counter = RNG counter word 2 (continues across run calls). */
+int bnmtf_set_iteration(bnmtf_handle h, uint64_t it);
+int bnmtf_get_iteration(bnmtf_handle h, uint64_t* it);
+
+/* ---- BNMF Gibbs state: attributes U, V, tau (bnmf_gibbs_optimised.py:102-117) */
+int bnmf_set_state(bnmtf_handle h, const double* U, const double* V, double tau);
+int bnmf_get_state(bnmtf_handle h, double* U, double* V, double* tau);
+
+/* tauU(k)/muU(tauUk,k) (which=0, :167-171) and tauV(k)/muV (which=1, :173-177) for
+ * the current state, through the same kernels the sampler uses.  numer_out is
+ * (-lambda[:,k] + tau * sum(...)), so that mu = numer / tau_k as the reference
+ * divides by the caller-supplied tauUk; tau_out is tauU(k). Length I (or J). */
+int bnmf_cond_params(bnmtf_handle h, int which, int k, double* numer_out, double* tau_out);
+
+/* beta_s() (:164-165) for the current state: beta + 0.5 * masked SSE */
+int bnmtf_beta_s(bnmtf_handle h, double* out);
+
+/* run(iterations) (:121-157): n_iter full sweeps (U columns, V columns, tau draw,
+ * metrics on the training mask).  Outputs, each may be NULL:
+ *   U_out [n_iter][I][K], V_out [n_iter][J][K]   (all_U / all_V, fp32 samples)
+ *   tau_out [n_iter]                             (all_tau)
+ *   perf_out [n_iter][3]  MSE, R^2, Rp           (all_performances)
+ *   times_out [n_iter]    cumulative seconds     (all_times)           */
+int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* V_out,
+                   double* tau_out, double* perf_out, double* times_out);
+
+/* ---- BNMTF Gibbs (bnmtf_gibbs_optimised.py) ---------------------------- */
+int bnmtf_set_state(bnmtf_handle h, const double* F, const double* S, const double* G, double tau);
+int bnmtf_get_state(bnmtf_handle h, double* F, double* S, double* G, double* tau);
+/* which = 0: tauF(k)/muF (:195-199), length I; 1: tauS(k,l)/muS (:201-205), length 1;
+ * 2: tauG(l)/muG (:207-211), length J (k ignored). */
+int bnmtf_cond_params(bnmtf_handle h, int which, int k, int l, double* numer_out, double* tau_out);
+/* run(iterations) (:138-180): F columns, S row-major, G columns, tau. */
+int bnmtf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* F_out, float* S_out, float* G_out,
+                    double* tau_out, double* perf_out, double* times_out);
+
+/* ---- BNMF VB (bnmf_vb_optimised.py) ------------------------------------ */
+/* all eight q-parameter matrices + exptau; any pointer may be NULL (left as is) */
+int bnmf_vb_set_state(bnmtf_handle h, const double* muU, const double* tauU, const double* expU, const double* varU,
+                      const double* muV, const double* tauV, const double* expV, const double* varV, double exptau);
+int bnmf_vb_get_state(bnmtf_handle h, double* muU, double* tauU, double* expU, double* varU,
+                      double* muV, double* tauV, double* expV, double* varV);
+/* update_U(k)+update_exp_U(k) (which=0, :189-191,199-204) or update_V/update_exp_V
+ * (which=1, :193-195,206-211) for one column; moments=0 skips the update_exp part. */
+int bnmf_vb_update(bnmtf_handle h, int which, int k, int moments);
+/* exp_square_diff() (:185-187) */
+int bnmf_vb_exp_square_diff(bnmtf_handle h, double* out);
+/* run(iterations) (:121-153).  exptau_out[n_iter] (all_exp_tau), perf_out[n_iter][3],
+ * elbo_terms_out[n_iter][4] = {exp_square_diff, sum log(0.5 erfc(-muU sqrt(tauU/2))),
+ * same for V, beta_s} -- the O(I*J) / O((I+J)K) pieces of elbo() (:163-177) that live
+ * on the device; the host finishes the scalar algebra. times_out[n_iter]. */
+int bnmf_vb_run(bnmtf_handle h, int n_iter, double* exptau_out, double* perf_out,
+                double* elbo_terms_out, double* times_out);
+
+/* ---- metrics: predict()/predict_while_running()/quality('MSE')/log_likelihood
+ *      (:191-223,247-251).  Six fp64 sums over mask Mp (I x J bytes; NULL = the
+ *      training mask): n, sum R, sum R^2, sum P, sum P^2, sum R*P with
+ *      P = A.B^T (S == NULL, A: I x K, B: J x K) or A.S.B^T (S: K x L, B: J x L).
+ *      A == NULL uses the handle's current state. */
+int bnmtf_metric_sums(bnmtf_handle h, const uint8_t* Mp, const double* A, const double* S,
+                      const double* B, double sums_out[6]);
+
+/* ---- distributions (stand-alone hooks; code/models/distributions/) ----- */
+/* TN_vector_draw (truncated_normal_vector.py:37-50): out[e] ~ TN(mu[e],tau[e]) on
+ * [0,inf); RNG counter (elem0+e, col, it, STREAM_HOOK). */
+int bnmtf_tn_sample(const double* mu, const double* tau, size_t n, uint64_t seed, uint64_t it,
+                    uint32_t col, uint32_t elem0, int device, double* out);
+/* TN_vector_expectation / TN_vector_variance (:53-73) */
+int bnmtf_tn_moments(const double* mu, const double* tau, size_t n, int device,
+                     double* exp_out, double* var_out);
+/* gamma_draw (gamma.py:11-14), shape alpha, rate beta */
+int bnmtf_gamma_sample(double alpha, double beta, uint64_t seed, uint64_t it, int device, double* out);
+
+/* ---- measurement aids (bench.py) --------------------------------------- */
+#define BNMTF_KERNEL_GEMM_ROWS 0   /* P  = R~ . V      (U/F step numerators)        */
+#define BNMTF_KERNEL_GEMM_COLS 1   /* Pv = R~^T . U    ("the U^T.R step")          */
+#define BNMTF_KERNEL_SWEEP_ROWS 2
+#define BNMTF_KERNEL_SWEEP_COLS 3
+#define BNMTF_KERNEL_COUNT 8
+/* when enabled, run() brackets each launch of the listed kernels with hipEvents
+ * on the handle's stream; totals are read back with bnmtf_kernel_stats. */
+int bnmtf_set_profiling(bnmtf_handle h, int enable);
+int bnmtf_kernel_stats(bnmtf_handle h, int kernel, double* total_ms, uint64_t* launches);
+/* geometry of the last create: padded shapes, split factor, slot counts (for DESIGN/bench) */
+int bnmtf_describe(bnmtf_handle h, char* buf, size_t buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BNMTF_HIP_H */

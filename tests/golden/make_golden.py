@@ -1,0 +1,306 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference).  The reference is
+Python-2 source, so a throw-away copy is converted with lib2to3 under
+/tmp/oracle (never inside this repo, never shipped to the GPU box) and
+imported from there -- recipe of SURVEY.md Appendix B.  What is committed is
+DATA ONLY: inputs and the reference's outputs for them.
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+"""
+import contextlib
+import io
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+TMP = "/tmp/oracle"
+
+
+def import_reference():
+    if not os.path.isdir(os.path.join(TMP, "BNMTF")):
+        os.makedirs(TMP, exist_ok=True)
+        shutil.copytree(REF, os.path.join(TMP, "BNMTF"))
+        subprocess.run("chmod -R u+w %s/BNMTF" % TMP, shell=True, check=True)
+        subprocess.run([sys.executable, "-m", "lib2to3", "-w", "-n",
+                        TMP + "/BNMTF/code", TMP + "/BNMTF/tests", TMP + "/BNMTF/data_toy"],
+                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    sys.path.insert(0, TMP)
+    import matplotlib
+    matplotlib.use("Agg")
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()):
+        yield
+
+
+def rand_mask(rs, I, J, frac):
+    while True:
+        M = (rs.rand(I, J) >= frac).astype(float)
+        if M.sum(axis=0).min() > 0 and M.sum(axis=1).min() > 0:
+            return M
+
+
+def bnmf_cases():
+    rs = np.random.RandomState(12345)
+    cases = {}
+    # the reference's own 5x3 known-answer matrix (tests/code/test_bnmf_gibbs_optimised.py:144-153)
+    I, J, K = 5, 3, 2
+    R = np.ones((I, J)); M = np.ones((I, J)); M[0, 0] = M[2, 2] = M[3, 1] = 0
+    cases["t5x3"] = dict(R=R, M=M, K=K, alpha=3.0, beta=1.0, lambdaU=2 * np.ones((I, K)), lambdaV=3 * np.ones((J, K)))
+    # toy data set (config 1)
+    R = np.loadtxt(REF + "/data_toy/bnmf/R.txt"); M = np.loadtxt(REF + "/data_toy/bnmf/M.txt")
+    I, J = R.shape; K = 10
+    cases["toy"] = dict(R=R, M=M, K=K, alpha=1.0, beta=1.0, lambdaU=0.1 * np.ones((I, K)), lambdaV=0.1 * np.ones((J, K)))
+    # ragged random case, non-constant lambdas
+    I, J, K = 37, 29, 6
+    R = rs.exponential(1.0, (I, K)) @ rs.exponential(1.0, (J, K)).T + rs.normal(0, 1, (I, J))
+    M = rand_mask(rs, I, J, 0.2)
+    cases["r37x29"] = dict(R=R, M=M, K=K, alpha=2.0, beta=0.5, lambdaU=rs.uniform(0.05, 2.0, (I, K)), lambdaV=rs.uniform(0.05, 2.0, (J, K)))
+    # heavily masked case (60 % missing)
+    I, J, K = 40, 33, 5
+    R = rs.exponential(1.0, (I, K)) @ rs.exponential(1.0, (J, K)).T + rs.normal(0, 1, (I, J))
+    M = rand_mask(rs, I, J, 0.6)
+    cases["r40x33"] = dict(R=R, M=M, K=K, alpha=1.0, beta=1.0, lambdaU=0.3 * np.ones((I, K)), lambdaV=0.7 * np.ones((J, K)))
+    return cases, rs
+
+
+def make_bnmf_cond():
+    from BNMTF.code.models.bnmf_gibbs_optimised import bnmf_gibbs_optimised
+    cases, rs = bnmf_cases()
+    out = {}
+    for name, c in cases.items():
+        pri = dict(alpha=c["alpha"], beta=c["beta"], lambdaU=c["lambdaU"], lambdaV=c["lambdaV"])
+        b = bnmf_gibbs_optimised(c["R"], c["M"], c["K"], pri)
+        I, J, K = b.I, b.J, b.K
+        if name == "t5x3":
+            b.initialise("exp"); b.tau = 3.0
+        else:
+            b.U = rs.exponential(1.0, (I, K)); b.V = rs.exponential(1.0, (J, K)); b.tau = float(rs.gamma(2.0, 0.5))
+        for k_, v in c.items():
+            out["%s/%s" % (name, k_)] = np.asarray(v)
+        out[name + "/U"], out[name + "/V"], out[name + "/tau"] = b.U.copy(), b.V.copy(), np.float64(b.tau)
+        tU = np.array([b.tauU(k) for k in range(K)]); mU = np.array([b.muU(tU[k], k) for k in range(K)])
+        tV = np.array([b.tauV(k) for k in range(K)]); mV = np.array([b.muV(tV[k], k) for k in range(K)])
+        out[name + "/tauU"], out[name + "/muU"], out[name + "/tauV"], out[name + "/muV"] = tU, mU, tV, mV
+        out[name + "/alpha_s"], out[name + "/beta_s"] = np.float64(b.alpha_s()), np.float64(b.beta_s())
+        p = b.predict_while_running()
+        out[name + "/perf"] = np.array([p["MSE"], p["R^2"], p["Rp"]])
+        out[name + "/size_Omega"] = np.int64(b.size_Omega)
+        out[name + "/row_counts"] = b.M.sum(axis=1).astype(np.int64)
+        out[name + "/col_counts"] = b.M.sum(axis=0).astype(np.int64)
+        # post-run API on a hand-made sample list (mirrors tests :240-360)
+        n = 10
+        b.all_U = [rs.exponential(1.0, (I, K)) for _ in range(n)]
+        b.all_V = [rs.exponential(1.0, (J, K)) for _ in range(n)]
+        b.all_tau = [float(rs.gamma(2.0, 0.5)) for _ in range(n)]
+        out[name + "/all_U"], out[name + "/all_V"], out[name + "/all_tau"] = np.array(b.all_U), np.array(b.all_V), np.array(b.all_tau)
+        eU, eV, et = b.approx_expectation(2, 3)
+        out[name + "/expU"], out[name + "/expV"], out[name + "/exptau"] = eU, eV, np.float64(et)
+        Mt = rand_mask(rs, I, J, 0.7) if I > 5 else np.array([[0, 0, 1], [0, 1, 0], [0, 0, 0], [1, 1, 0], [0, 0, 1]], dtype=float)
+        pp = b.predict(Mt, 2, 3)
+        out[name + "/M_test"] = Mt
+        out[name + "/predict"] = np.array([pp["MSE"], pp["R^2"], pp["Rp"]])
+        out[name + "/quality"] = np.array([b.quality(m, 2, 3) for m in ["loglikelihood", "BIC", "AIC", "MSE", "ELBO"]])
+    np.savez_compressed(os.path.join(HERE, "bnmf_gibbs_cond.npz"), **out)
+
+
+def make_bnmtf_cond():
+    from BNMTF.code.models.bnmtf_gibbs_optimised import bnmtf_gibbs_optimised
+    rs = np.random.RandomState(777)
+    cases = {}
+    I, J, K, L = 5, 3, 2, 4   # tests/code/test_bnmtf_gibbs_optimised.py known-answer shape
+    R = np.ones((I, J)); M = np.ones((I, J)); M[0, 0] = M[2, 2] = M[3, 1] = 0
+    cases["t5x3"] = dict(R=R, M=M, K=K, L=L, alpha=3.0, beta=1.0, lambdaF=2 * np.ones((I, K)), lambdaS=3 * np.ones((K, L)), lambdaG=5 * np.ones((J, L)))
+    R = np.loadtxt(REF + "/data_toy/bnmtf/R.txt"); M = np.loadtxt(REF + "/data_toy/bnmtf/M.txt")
+    I, J = R.shape; K = L = 5
+    cases["toy"] = dict(R=R, M=M, K=K, L=L, alpha=1.0, beta=1.0, lambdaF=0.1 * np.ones((I, K)), lambdaS=0.1 * np.ones((K, L)), lambdaG=0.1 * np.ones((J, L)))
+    I, J, K, L = 37, 29, 4, 3
+    R = rs.exponential(1.0, (I, K)) @ rs.exponential(1.0, (K, L)) @ rs.exponential(1.0, (J, L)).T + rs.normal(0, 1, (I, J))
+    M = rand_mask(rs, I, J, 0.25)
+    cases["r37x29"] = dict(R=R, M=M, K=K, L=L, alpha=2.0, beta=0.5, lambdaF=rs.uniform(0.05, 2, (I, K)), lambdaS=rs.uniform(0.05, 2, (K, L)), lambdaG=rs.uniform(0.05, 2, (J, L)))
+    out = {}
+    for name, c in cases.items():
+        pri = dict(alpha=c["alpha"], beta=c["beta"], lambdaF=c["lambdaF"], lambdaS=c["lambdaS"], lambdaG=c["lambdaG"])
+        b = bnmtf_gibbs_optimised(c["R"], c["M"], c["K"], c["L"], pri)
+        I, J, K, L = b.I, b.J, b.K, b.L
+        if name == "t5x3":
+            b.initialise("exp", "exp"); b.tau = 3.0
+        else:
+            b.F = rs.exponential(1.0, (I, K)); b.S = rs.exponential(1.0, (K, L)); b.G = rs.exponential(1.0, (J, L))
+            b.tau = float(rs.gamma(2.0, 0.5))
+        for k_, v in c.items():
+            out["%s/%s" % (name, k_)] = np.asarray(v)
+        out[name + "/F"], out[name + "/S"], out[name + "/G"], out[name + "/tau"] = b.F.copy(), b.S.copy(), b.G.copy(), np.float64(b.tau)
+        tF = np.array([b.tauF(k) for k in range(K)]); mF = np.array([b.muF(tF[k], k) for k in range(K)])
+        tS = np.array([[b.tauS(k, l) for l in range(L)] for k in range(K)])
+        mS = np.array([[b.muS(tS[k, l], k, l) for l in range(L)] for k in range(K)])
+        tG = np.array([b.tauG(l) for l in range(L)]); mG = np.array([b.muG(tG[l], l) for l in range(L)])
+        out[name + "/tauF"], out[name + "/muF"] = tF, mF
+        out[name + "/tauS"], out[name + "/muS"] = tS, mS
+        out[name + "/tauG"], out[name + "/muG"] = tG, mG
+        out[name + "/alpha_s"], out[name + "/beta_s"] = np.float64(b.alpha_s()), np.float64(b.beta_s())
+        p = b.predict_while_running()
+        out[name + "/perf"] = np.array([p["MSE"], p["R^2"], p["Rp"]])
+        out[name + "/size_Omega"] = np.int64(b.size_Omega)
+        n = 10
+        b.all_F = [rs.exponential(1.0, (I, K)) for _ in range(n)]
+        b.all_S = [rs.exponential(1.0, (K, L)) for _ in range(n)]
+        b.all_G = [rs.exponential(1.0, (J, L)) for _ in range(n)]
+        b.all_tau = [float(rs.gamma(2.0, 0.5)) for _ in range(n)]
+        out[name + "/all_F"], out[name + "/all_S"], out[name + "/all_G"], out[name + "/all_tau"] = \
+            np.array(b.all_F), np.array(b.all_S), np.array(b.all_G), np.array(b.all_tau)
+        Mt = rand_mask(rs, I, J, 0.7) if I > 5 else np.array([[0, 0, 1], [0, 1, 0], [0, 0, 0], [1, 1, 0], [0, 0, 1]], dtype=float)
+        pp = b.predict(Mt, 2, 3)
+        out[name + "/M_test"] = Mt
+        out[name + "/predict"] = np.array([pp["MSE"], pp["R^2"], pp["Rp"]])
+        out[name + "/quality"] = np.array([b.quality(m, 2, 3) for m in ["loglikelihood", "BIC", "AIC", "MSE", "ELBO"]])
+    np.savez_compressed(os.path.join(HERE, "bnmtf_gibbs_cond.npz"), **out)
+
+
+def make_vb():
+    from BNMTF.code.models.bnmf_vb_optimised import bnmf_vb_optimised
+    out = {}
+    R = np.loadtxt(REF + "/data_toy/bnmf/R.txt"); M = np.loadtxt(REF + "/data_toy/bnmf/M.txt")
+    I, J = R.shape; K = 10
+    pri = dict(alpha=1.0, beta=1.0, lambdaU=0.1 * np.ones((I, K)), lambdaV=0.1 * np.ones((J, K)))
+    b = bnmf_vb_optimised(R, M, K, pri)
+    b.initialise("exp")
+    out["toy/init_exptau"] = np.float64(b.exptau); out["toy/init_expU"] = b.expU.copy(); out["toy/init_varU"] = b.varU.copy()
+    out["toy/init_esd"] = np.float64(b.exp_square_diff())
+    mse, exptau, elbo = [], [], []
+    for it in range(20):
+        with quiet():
+            b.run(1)
+        mse.append(b.all_performances["MSE"][0]); exptau.append(b.exptau); elbo.append(b.elbo())
+        if it + 1 in (1, 2, 20):
+            for nm in ["expU", "expV", "varU", "varV", "muU", "muV", "tauU", "tauV"]:
+                out["toy/it%d/%s" % (it + 1, nm)] = getattr(b, nm).copy()
+    out["toy/mse"], out["toy/exptau"], out["toy/elbo"] = np.array(mse), np.array(exptau), np.array(elbo)
+    p = b.predict(M)
+    out["toy/final_perf"] = np.array([p["MSE"], p["R^2"], p["Rp"]])
+    out["toy/quality"] = np.array([b.quality(m) for m in ["loglikelihood", "BIC", "AIC", "MSE", "ELBO"]])
+    # ragged random case with non-trivial tauUV init and one update of each kind
+    rs = np.random.RandomState(4242)
+    I, J, K = 31, 23, 4
+    R = rs.exponential(1.0, (I, K)) @ rs.exponential(1.0, (J, K)).T + rs.normal(0, 1, (I, J))
+    Mr = rand_mask(rs, I, J, 0.3)
+    lU, lV = rs.uniform(0.1, 2, (I, K)), rs.uniform(0.1, 2, (J, K))
+    b = bnmf_vb_optimised(R, Mr, K, dict(alpha=2.0, beta=0.5, lambdaU=lU, lambdaV=lV))
+    b.initialise("exp", {"tauU": rs.uniform(0.5, 3, (I, K)), "tauV": rs.uniform(0.5, 3, (J, K))})
+    out["r31x23/R"], out["r31x23/M"], out["r31x23/lambdaU"], out["r31x23/lambdaV"] = R, Mr, lU, lV
+    out["r31x23/tauU0"], out["r31x23/tauV0"] = b.tauU.copy(), b.tauV.copy()
+    mse, exptau, elbo = [], [], []
+    for it in range(10):
+        with quiet():
+            b.run(1)
+        mse.append(b.all_performances["MSE"][0]); exptau.append(b.exptau); elbo.append(b.elbo())
+    out["r31x23/mse"], out["r31x23/exptau"], out["r31x23/elbo"] = np.array(mse), np.array(exptau), np.array(elbo)
+    for nm in ["expU", "expV", "varU", "varV", "muU", "muV", "tauU", "tauV"]:
+        out["r31x23/it10/%s" % nm] = getattr(b, nm).copy()
+    np.savez_compressed(os.path.join(HERE, "bnmf_vb.npz"), **out)
+
+
+def make_tn():
+    from BNMTF.code.models.distributions.truncated_normal_vector import TN_vector_draw, TN_vector_expectation, TN_vector_variance
+    from BNMTF.code.models.distributions.gamma import gamma_expectation, gamma_expectation_log, gamma_mode
+    out = {}
+    mus = np.array([-60., -31., -30.5, -29.5, -10., -3., -1., -0.3, 0., 0.2, 1., 4., 25., -1., 1e-3, -1e3, 5.0, -0.5])
+    taus = np.array([1., 1., 1., 1., 1., 1., 2000., 1., 1., 3., 3., 0.25, 1., 0.01, 1e6, 1e-4, 0.0, 1e-12])
+    G1, G2 = np.meshgrid(np.linspace(-45, 12, 58), np.array([0.05, 0.5, 1.0, 7.0, 400.0]))
+    mus = np.concatenate([mus, G1.ravel()]); taus = np.concatenate([taus, G2.ravel()])
+    with np.errstate(all="ignore"):
+        out["mom/mu"], out["mom/tau"] = mus, taus
+        out["mom/exp"] = np.array(TN_vector_expectation(mus, taus), dtype=float)
+        out["mom/var"] = np.array(TN_vector_variance(mus, taus), dtype=float)
+    out["gamma/ab"] = np.array([[2.0, 3.0], [3600.5, 1234.25], [1.0, 1e-3], [7.5e6, 3.1e7]])
+    out["gamma/exp"] = np.array([gamma_expectation(a, b) for a, b in out["gamma/ab"]])
+    out["gamma/explog"] = np.array([gamma_expectation_log(a, b) for a, b in out["gamma/ab"]])
+    out["gamma/mode"] = np.array([gamma_mode(a, b) for a, b in out["gamma/ab"]])
+    # distribution of the reference sampler: quantiles of n draws per (a = -mu*sqrt(tau)) regime
+    n = 200000
+    probs = np.concatenate([[0.0005, 0.001, 0.005], np.linspace(0.01, 0.99, 99), [0.995, 0.999, 0.9995]])
+    pairs = []
+    for a in [-10., -2.5, -1., 0., 0.2, 0.3, 1., 3., 3.6, 8., 40.]:
+        for tau in [1.0, 37.0]:
+            pairs.append((-a / np.sqrt(tau), tau))
+    np.random.seed(2024)
+    q, mom = [], []
+    for mu, tau in pairs:
+        d = np.array(TN_vector_draw(np.full(n, mu), np.full(n, tau)), dtype=float)
+        q.append(np.quantile(d, probs)); mom.append([d.mean(), d.var()])
+    out["draw/pairs"], out["draw/probs"], out["draw/quantiles"], out["draw/moments"], out["draw/n"] = \
+        np.array(pairs), probs, np.array(q), np.array(mom), np.int64(n)
+    np.savez_compressed(os.path.join(HERE, "distributions.npz"), **out)
+
+
+def make_trajectories():
+    """Seeded reference Gibbs runs on the toy sets: per-iteration MSE for 10 seeds."""
+    from BNMTF.code.models.bnmf_gibbs_optimised import bnmf_gibbs_optimised
+    from BNMTF.code.models.bnmtf_gibbs_optimised import bnmtf_gibbs_optimised
+    import random
+    out = {}
+    R = np.loadtxt(REF + "/data_toy/bnmf/R.txt"); M = np.loadtxt(REF + "/data_toy/bnmf/M.txt")
+    I, J = R.shape; K = 10
+    pri = dict(alpha=1.0, beta=1.0, lambdaU=0.1 * np.ones((I, K)), lambdaV=0.1 * np.ones((J, K)))
+    rs = np.random.RandomState(99)
+    Mtest = (rs.rand(I, J) < 0.5).astype(float) * (1 - M)      # held-out = half of the unobserved entries
+    Rtrue = np.loadtxt(REF + "/data_toy/bnmf/R_true.txt")
+    mse, tau, held, init_mse = [], [], [], []
+    for s in range(10):
+        np.random.seed(s); random.seed(s)
+        b = bnmf_gibbs_optimised(R, M, K, pri)
+        b.initialise("random")
+        if s == 0:
+            out["bnmf/U0_seed0"], out["bnmf/V0_seed0"], out["bnmf/tau0_seed0"] = b.U.copy(), b.V.copy(), np.float64(b.tau)
+        with quiet():
+            b.run(200)
+        mse.append(b.all_performances["MSE"]); tau.append(b.all_tau.copy())
+        eU, eV, _ = b.approx_expectation(100, 2)
+        held.append(((1 - M) * (Rtrue - eU @ eV.T) ** 2).sum() / (1 - M).sum())
+    out["bnmf/mse"], out["bnmf/tau"], out["bnmf/heldout_mse_vs_Rtrue"] = np.array(mse), np.array(tau), np.array(held)
+    R = np.loadtxt(REF + "/data_toy/bnmtf/R.txt"); M = np.loadtxt(REF + "/data_toy/bnmtf/M.txt")
+    I, J = R.shape; K = L = 5
+    pri = dict(alpha=1.0, beta=1.0, lambdaF=0.1 * np.ones((I, K)), lambdaS=0.1 * np.ones((K, L)), lambdaG=0.1 * np.ones((J, L)))
+    mse, tau = [], []
+    for s in range(6):
+        np.random.seed(s); random.seed(s)
+        b = bnmtf_gibbs_optimised(R, M, K, L, pri)
+        b.initialise("random", "random")
+        with quiet():
+            b.run(200)
+        mse.append(b.all_performances["MSE"]); tau.append(b.all_tau.copy())
+    out["bnmtf/mse"], out["bnmtf/tau"] = np.array(mse), np.array(tau)
+    np.savez_compressed(os.path.join(HERE, "gibbs_trajectories.npz"), **out)
+
+
+def make_toy_data():
+    """The reference's toy inputs (data files its own tests/experiments hold) as one fixture."""
+    out = {}
+    for m in ["R", "M", "U", "V", "R_true"]:
+        out["bnmf/" + m] = np.loadtxt(REF + "/data_toy/bnmf/%s.txt" % m)
+    for m in ["R", "M", "F", "S", "G", "R_true"]:
+        out["bnmtf/" + m] = np.loadtxt(REF + "/data_toy/bnmtf/%s.txt" % m)
+    np.savez_compressed(os.path.join(HERE, "toy_data.npz"), **out)
+
+
+if __name__ == "__main__":
+    import_reference()
+    which = sys.argv[1:] or ["toy", "bnmf", "bnmtf", "vb", "tn", "traj"]
+    if "toy" in which: make_toy_data()
+    if "bnmf" in which: make_bnmf_cond()
+    if "bnmtf" in which: make_bnmtf_cond()
+    if "vb" in which: make_vb()
+    if "tn" in which: make_tn()
+    if "traj" in which: make_trajectories()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))
