@@ -216,25 +216,61 @@ def test_philox_known_answers():
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
 
 
+def _tn_exact(mu, tau):
+    from scipy import stats
+    sd = 1.0 / math.sqrt(tau)
+    return stats.truncnorm(-mu / sd, np.inf, loc=mu, scale=sd)
+
+
 def test_tn_sampler_matches_reference_distribution(golden):
     """The new sampler against quantiles of 2e5 draws of the reference's
-    TN_vector_draw per (mu,tau): empirical CDF of 2e5 oracle draws evaluated at
-    the reference's quantiles must agree with the nominal probabilities
-    (two-sample band, 4.5 sigma) -- covers all three rtnorm regimes."""
+    TN_vector_draw per (mu,tau) pair, all three rtnorm regimes
+    (a = -mu*sqrt(tau) in {-10,-2.5,-1,0,.2,.3,1,3,3.6,8,40}, tau in {1,37}).
+
+    Finding pinned here: the reference's vendored table sampler (rtnorm.py:128-217)
+    is itself off the exact truncated normal near its right-tail cell
+    (x ~ 3.2..3.49 sigma): tiny for a in [0,1] (about 5e-4 of mass missing beyond
+    3.2 sigma) and gross for a in (2.9, 3.4867) (CDF error up to 0.12 at a = 3).
+    The new sampler follows the exact distribution the reference documents
+    (truncated_normal_vector.py:1-5); it is compared with the reference's
+    quantiles wherever the reference agrees with the exact CDF, and with the
+    exact CDF everywhere."""
     g = golden("distributions.npz").case("draw")
-    n = 200000
+    n = 200000; nref = int(g["n"]); p = g["probs"]
+    n_ref_ok = 0
     for (mu, tau), q, mom in zip(g["pairs"], g["quantiles"], g["moments"]):
         x = rng.tn_draw(np.full(n, mu), np.full(n, tau), np.arange(n), 3, 11, rng.STREAM_HOOK, 2718)
         assert (x >= 0).all()
-        p = g["probs"]
-        emp = np.searchsorted(np.sort(x), q, side="right") / float(n)
-        band = 4.5 * np.sqrt(p * (1 - p) * (1. / n + 1. / int(g["n"]))) + 2.0 / n
-        assert (np.abs(emp - p) <= band).all(), (mu, tau, np.abs(emp - p).max())
-        sd = math.sqrt(mom[1])
-        assert abs(x.mean() - mom[0]) < 6 * sd * math.sqrt(2. / n)
+        d = _tn_exact(mu, tau)
+        xs = np.sort(x)
+        # (1) exact CDF, every pair: Kolmogorov distance below the 1e-6-level critical value
+        ks = np.abs(d.cdf(xs) - (np.arange(n) + 0.5) / n).max()
+        assert ks < 2.7 / math.sqrt(n), (mu, tau, ks)
+        # (2) reference quantiles, where the reference itself is on the exact CDF
+        ref_dev = np.abs(d.cdf(q) - p)
+        ref_ok = ref_dev <= 4.5 * np.sqrt(p * (1 - p) / nref) + 1.0 / nref
+        emp = np.searchsorted(xs, q, side="right") / float(n)
+        band = 4.5 * np.sqrt(p * (1 - p) * (1. / n + 1. / nref)) + 2.0 / n
+        assert (np.abs(emp - p)[ref_ok] <= band[ref_ok]).all(), (mu, tau)
+        a = -mu * math.sqrt(tau)
+        if abs(a - 3.0) < 1e-9:
+            assert ref_dev.max() > 0.05      # the reference's own deviation, documented above
+        else:
+            assert ref_ok.sum() >= len(p) - 3, (mu, tau, ref_ok.sum())
+            n_ref_ok += 1
+            sd = math.sqrt(mom[1])
+            assert abs(x.mean() - mom[0]) < 6 * sd * math.sqrt(2. / n)
+    assert n_ref_ok == 20
     # guards of truncated_normal_vector.py:41-45
     x = rng.tn_draw([1.0, 0.32, np.nan], [3.0, 0.0, 1.0], [0, 1, 2], 0, 0, rng.STREAM_HOOK, 1)
     assert x[0] >= 0 and x[1] == 0.0 and x[2] == 0.0
+
+
+def test_gamma_sampler_distribution():
+    from scipy import stats
+    for shape, rate in [(30.0, 2.0), (0.5, 2.0), (3.6e3, 1.2e3)]:
+        g = np.array([rng.gamma_draw(shape, rate, i, 7) for i in range(4000)])
+        assert stats.kstest(g, stats.gamma(shape, scale=1.0 / rate).cdf).pvalue > 1e-4
 
 
 def test_gibbs_toy_trajectory_within_reference_bands(golden):
