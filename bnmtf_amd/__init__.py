@@ -1,0 +1,9 @@
+"""bnmtf_amd -- MI355X-native Gibbs / VB inference for Bayesian non-negative matrix
+(tri-)factorisation, behind the class API of ThomasBrouwer/BNMTF.
+
+Python host code + ctypes -> libbnmtf_hip.so (hand-written HIP for gfx950).  There is
+no CPU fallback: every model method that computes goes through the library."""
+from ._lib import BnmtfError, device_count, lib, LIB_PATH, EXPORTS
+from .bnmf_gibbs import bnmf_gibbs_optimised, bnmf_gibbs
+
+__all__ = ["bnmf_gibbs_optimised", "bnmf_gibbs", "device_count", "BnmtfError", "lib", "LIB_PATH", "EXPORTS"]

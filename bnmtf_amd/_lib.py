@@ -1,0 +1,98 @@
+"""ctypes binding of libbnmtf_hip.so (include/bnmtf_hip.h).  No PyTorch, no fallback:
+if the HIP library is missing or a call fails, an exception is raised."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbnmtf_hip.so")
+
+KERNEL_GEMM_ROWS, KERNEL_GEMM_COLS, KERNEL_SWEEP_ROWS, KERNEL_SWEEP_COLS = 0, 1, 2, 3
+UPDATE_DRAW, UPDATE_MODE = 0, 1
+
+
+class BnmtfError(RuntimeError):
+    pass
+
+
+class Problem(C.Structure):
+    _fields_ = [("I", C.c_int32), ("J", C.c_int32), ("K", C.c_int32), ("L", C.c_int32),
+                ("R", C.c_void_p), ("M", C.c_void_p),
+                ("lambda_rows", C.c_void_p), ("lambda_cols", C.c_void_p), ("lambda_S", C.c_void_p),
+                ("alpha", C.c_double), ("beta", C.c_double), ("seed", C.c_uint64),
+                ("device", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32),
+                ("comm_id", C.c_void_p)]
+
+
+_P = C.c_void_p
+_SIGS = {
+    "bnmtf_version": ([], C.c_int),
+    "bnmtf_last_error": ([], C.c_char_p),
+    "bnmtf_device_count": ([C.POINTER(C.c_int)], C.c_int),
+    "bnmtf_comm_unique_id": ([_P], C.c_int),
+    "bnmtf_create": ([C.POINTER(Problem), C.POINTER(_P)], C.c_int),
+    "bnmtf_destroy": ([_P], C.c_int),
+    "bnmtf_sync": ([_P], C.c_int),
+    "bnmtf_omega_counts": ([_P, C.POINTER(C.c_uint64), _P, _P], C.c_int),
+    "bnmtf_set_iteration": ([_P, C.c_uint64], C.c_int),
+    "bnmtf_get_iteration": ([_P, C.POINTER(C.c_uint64)], C.c_int),
+    "bnmf_set_state": ([_P, _P, _P, C.c_double], C.c_int),
+    "bnmf_get_state": ([_P, _P, _P, C.POINTER(C.c_double)], C.c_int),
+    "bnmf_cond_params": ([_P, C.c_int, C.c_int, _P, _P], C.c_int),
+    "bnmtf_beta_s": ([_P, C.POINTER(C.c_double)], C.c_int),
+    "bnmf_gibbs_run": ([_P, C.c_int, C.c_int, _P, _P, _P, _P, _P], C.c_int),
+    "bnmtf_set_state": ([_P, _P, _P, _P, C.c_double], C.c_int),
+    "bnmtf_get_state": ([_P, _P, _P, _P, C.POINTER(C.c_double)], C.c_int),
+    "bnmtf_cond_params": ([_P, C.c_int, C.c_int, C.c_int, _P, _P], C.c_int),
+    "bnmtf_gibbs_run": ([_P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P], C.c_int),
+    "bnmf_vb_set_state": ([_P] + [_P] * 8 + [C.c_double], C.c_int),
+    "bnmf_vb_get_state": ([_P] + [_P] * 8, C.c_int),
+    "bnmf_vb_update": ([_P, C.c_int, C.c_int, C.c_int], C.c_int),
+    "bnmf_vb_exp_square_diff": ([_P, C.POINTER(C.c_double)], C.c_int),
+    "bnmf_vb_run": ([_P, C.c_int, _P, _P, _P, _P], C.c_int),
+    "bnmtf_metric_sums": ([_P, _P, _P, _P, _P, _P], C.c_int),
+    "bnmtf_tn_sample": ([_P, _P, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, _P], C.c_int),
+    "bnmtf_tn_moments": ([_P, _P, C.c_size_t, C.c_int, _P, _P], C.c_int),
+    "bnmtf_gamma_sample": ([C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_double)], C.c_int),
+    "bnmtf_set_profiling": ([_P, C.c_int], C.c_int),
+    "bnmtf_kernel_stats": ([_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)], C.c_int),
+    "bnmtf_describe": ([_P, C.c_char_p, C.c_size_t], C.c_int),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises BnmtfError when it has not been built (no CPU fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BnmtfError("HIP library %s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "or `make -C bnmtf_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+        l = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (args, res) in _SIGS.items():
+            f = getattr(l, name)
+            f.argtypes, f.restype = args, res
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise BnmtfError("libbnmtf_hip error %d: %s" % (rc, lib().bnmtf_last_error().decode("utf-8", "replace")))
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().bnmtf_device_count(C.byref(n)))
+    return n.value

@@ -1,0 +1,162 @@
+"""Drop-in for code/models/bnmf_gibbs_optimised.py (class bnmf_gibbs_optimised):
+Gibbs sampler for Bayesian non-negative matrix factorisation R ~ U.V^T, with the
+per-iteration work done by libbnmtf_hip.so on an MI355X.
+
+    BNMF = bnmf_gibbs_optimised(R, M, K, priors)
+    BNMF.initialise(init)          # 'random' | 'exp'
+    BNMF.run(iterations)           # -> (all_U, all_V, all_tau)
+    BNMF.approx_expectation(burn_in, thinning); BNMF.predict(M_pred, burn_in, thinning)
+    BNMF.quality(metric, burn_in, thinning)
+
+Same constructor arguments, attributes (R, M, I, J, K, size_Omega, alpha, beta,
+lambdaU, lambdaV, U, V, tau, all_U, all_V, all_tau, all_times, all_performances),
+methods and assertion messages as the reference.  Build-only extras are
+keyword-only: seed (Philox key; default drawn from numpy.random so that
+numpy.random.seed() makes runs reproducible, as in the reference), device,
+verbose, rank/world/comm_id (row/column sharding over several GPUs).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from ._base import DeviceModel, broadcast_lambda, check_R_M, metrics_from_sums
+
+
+class bnmf_gibbs_optimised(DeviceModel):
+    def __init__(self, R, M, K, priors, *, seed=None, device=0, verbose=True, rank=0, world=1, comm_id=None):
+        self.R = np.array(R, dtype=float)
+        self.M = np.array(M, dtype=float)
+        self.K = K
+        check_R_M(self.R, self.M)
+        (self.I, self.J) = self.R.shape
+        self.size_Omega = self.M.sum()
+        self.alpha, self.beta = float(priors['alpha']), float(priors['beta'])
+        self.lambdaU = broadcast_lambda(priors['lambdaU'], (self.I, self.K), "lambdaU")
+        self.lambdaV = broadcast_lambda(priors['lambdaV'], (self.J, self.K), "lambdaV")
+        self.verbose = verbose
+        self._init_device(seed, device, rank, world, comm_id)
+
+    def _lambda_arrays(self):
+        return self.lambdaU, self.lambdaV, None
+
+    # Initialise and run the sampler (bnmf_gibbs_optimised.py:94-96)
+    def train(self, init, iterations):
+        self.initialise(init=init)
+        return self.run(iterations)
+
+    def initialise(self, init='random'):
+        """:100-117.  'random' consumes numpy.random.exponential in (i,k) row-major order,
+        i.e. the same values as the reference's scalar loop for the same numpy seed."""
+        assert init in ['random', 'exp'], "Unknown initialisation option: %s. Should be 'random' or 'exp'." % init
+        if init == 'random':
+            self.U = np.random.exponential(scale=1.0 / self.lambdaU)
+            self.V = np.random.exponential(scale=1.0 / self.lambdaV)
+        else:
+            self.U = 1.0 / self.lambdaU
+            self.V = 1.0 / self.lambdaV
+        self.tau = self.alpha_s() / self.beta_s()
+
+    def _push(self, tau=None):
+        tau = getattr(self, "tau", 1.0) if tau is None else tau
+        _lib.check(_lib.lib().bnmf_set_state(self._handle(), _lib.ptr(_lib.f64(self.U)), _lib.ptr(_lib.f64(self.V)), float(tau)))
+
+    def _pull(self):
+        U = np.zeros((self.I, self.K)); V = np.zeros((self.J, self.K)); tau = C.c_double()
+        _lib.check(_lib.lib().bnmf_get_state(self._handle(), _lib.ptr(U), _lib.ptr(V), C.byref(tau)))
+        self.U, self.V, self.tau = U, V, tau.value
+
+    def run(self, iterations, update='draw', store_samples=True):
+        """:121-157.  One device call runs all iterations; samples, tau, metrics and
+        cumulative times come back afterwards.  store_samples=False skips the all_U/all_V
+        hand-off (device-resident benchmark mode); update='mode' runs the ICM harness."""
+        it = int(iterations)
+        self._push()
+        U_out = np.zeros((it, self.I, self.K), dtype=np.float32) if store_samples else None
+        V_out = np.zeros((it, self.J, self.K), dtype=np.float32) if store_samples else None
+        taus = np.zeros(it); perf = np.zeros((it, 3)); times = np.zeros(it)
+        _lib.check(_lib.lib().bnmf_gibbs_run(self._handle(), it, _lib.UPDATE_MODE if update == 'mode' else _lib.UPDATE_DRAW,
+                                             _lib.ptr(U_out), _lib.ptr(V_out), _lib.ptr(taus), _lib.ptr(perf), _lib.ptr(times)))
+        self._pull()
+        self.all_U = U_out.astype(np.float64) if store_samples else np.zeros((0, self.I, self.K))
+        self.all_V = V_out.astype(np.float64) if store_samples else np.zeros((0, self.J, self.K))
+        self.all_tau = taus
+        self.all_times = list(times)
+        self.all_performances = {'MSE': list(perf[:, 0]), 'R^2': list(perf[:, 1]), 'Rp': list(perf[:, 2])}
+        if self.verbose:
+            for i in range(it):
+                print("Iteration %s. MSE: %s. R^2: %s. Rp: %s." % (i + 1, perf[i, 0], perf[i, 1], perf[i, 2]))
+        return (self.all_U, self.all_V, self.all_tau)
+
+    # Parameters of the conditional posteriors (:161-177), evaluated on the device
+    def alpha_s(self):
+        return self.alpha + self.size_Omega / 2.0
+
+    def beta_s(self):
+        self._push()
+        out = C.c_double()
+        _lib.check(_lib.lib().bnmtf_beta_s(self._handle(), C.byref(out)))
+        return out.value
+
+    def _cond(self, which, k):
+        self._push()
+        n = self.I if which == 0 else self.J
+        numer = np.zeros(n); tauk = np.zeros(n)
+        _lib.check(_lib.lib().bnmf_cond_params(self._handle(), which, int(k), _lib.ptr(numer), _lib.ptr(tauk)))
+        return numer, tauk
+
+    def tauU(self, k):
+        return self._cond(0, k)[1]
+
+    def muU(self, tauUk, k):
+        return 1. / np.asarray(tauUk, dtype=float) * self._cond(0, k)[0]
+
+    def tauV(self, k):
+        return self._cond(1, k)[1]
+
+    def muV(self, tauVk, k):
+        return 1. / np.asarray(tauVk, dtype=float) * self._cond(1, k)[0]
+
+    # Posterior means from the stored samples (:182-187); host fp64, accepts lists
+    def approx_expectation(self, burn_in, thinning):
+        indices = range(burn_in, len(self.all_U), thinning)
+        exp_U = np.array([self.all_U[i] for i in indices]).sum(axis=0) / float(len(indices))
+        exp_V = np.array([self.all_V[i] for i in indices]).sum(axis=0) / float(len(indices))
+        exp_tau = sum([self.all_tau[i] for i in indices]) / float(len(indices))
+        return (exp_U, exp_V, exp_tau)
+
+    def predict(self, M_pred, burn_in, thinning):
+        """:191-197 (the I x J x K product and the masked sums run on the device in fp64)."""
+        (exp_U, exp_V, _) = self.approx_expectation(burn_in, thinning)
+        return metrics_from_sums(self._metric_sums(M_pred, exp_U, None, exp_V))
+
+    def predict_while_running(self):
+        """:199-204."""
+        return metrics_from_sums(self._metric_sums(None, self.U, None, self.V))
+
+    def quality(self, metric, burn_in, thinning):
+        """:227-245."""
+        assert metric in ['loglikelihood', 'BIC', 'AIC', 'MSE', 'ELBO'], 'Unrecognised metric for model quality: %s.' % metric
+        (expU, expV, exptau) = self.approx_expectation(burn_in, thinning)
+        log_likelihood = self.log_likelihood(expU, expV, exptau)
+        if metric == 'loglikelihood':
+            return log_likelihood
+        elif metric == 'BIC':
+            return - 2 * log_likelihood + (self.I * self.K + self.J * self.K) * math.log(self.size_Omega)
+        elif metric == 'AIC':
+            return - 2 * log_likelihood + 2 * (self.I * self.K + self.J * self.K)
+        elif metric == 'MSE':
+            return metrics_from_sums(self._metric_sums(None, expU, None, expV))['MSE']
+        elif metric == 'ELBO':
+            return 0.
+
+    def log_likelihood(self, expU, expV, exptau):
+        """:247-251."""
+        s = self._metric_sums(None, expU, None, expV)
+        sse = s[2] - 2.0 * s[5] + s[4]
+        explogtau = math.log(exptau)
+        return self.size_Omega / 2. * (explogtau - math.log(2 * math.pi)) - exptau / 2. * sse
+
+
+bnmf_gibbs = bnmf_gibbs_optimised

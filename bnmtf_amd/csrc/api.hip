@@ -1,0 +1,570 @@
+// C ABI of libbnmtf_hip.so (include/bnmtf_hip.h): model construction (host-side
+// layout of the masked matrix for the two sweep directions), state hand-off, the
+// Gibbs / VB drivers that enqueue the kernels on the handle's stream.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "model.h"
+#include "comm.h"
+
+namespace bnmtf {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+template <typename T>
+static int dalloc(T** p, size_t count, bool zero = true) {
+  if (count == 0) count = 1;
+  HIPCHK(hipMalloc((void**)p, count * sizeof(T)));
+  if (zero) { HIPCHK(hipMemset(*p, 0, count * sizeof(T))); HIPCHK(hipDeviceSynchronize()); }
+  return BNMTF_OK;
+}
+template <typename T>
+static void dfree(T*& p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+// ------------------------------------------------------------------ layout
+// Fill one direction.  get(u, r) returns (observed, value) of unit u (global) at
+// inner index r.
+template <typename Get>
+static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const double* lambda, Get get) {
+  d.nglob = nglob; d.m = m; d.W = W; d.KP = W <= 32 ? 32 : 64;
+  d.n0 = (int)(((int64_t)nglob * rank) / world);
+  d.n = (int)(((int64_t)nglob * (rank + 1)) / world) - d.n0;
+  d.n_pad = round_up(std::max(d.n, 1), 128);
+  // split of the inner dimension: aim at >= 2 blocks per CU, >= 64 inner rows per wave
+  const int tiles = d.n_pad / 128;
+  int split = std::max(1, 512 / tiles);
+  const int max_split = std::max(1, m / (4 * 64));
+  d.split = std::min(split, max_split);
+  d.ipw = round_up((m + d.split * 4 - 1) / (d.split * 4), 16);
+  d.inner_pad = d.split * 4 * d.ipw;
+
+  std::vector<float> big((size_t)d.inner_pad * d.n_pad, 0.0f);
+  std::vector<uint32_t> ptr(d.n + 1, 0), idx;
+  d.obs_count.assign(nglob, 0);
+  d.nmiss = 0;
+  idx.reserve((size_t)d.n * 64);
+  std::vector<uint32_t> miss;
+  for (int ul = 0; ul < d.n; ++ul) {
+    const int u = d.n0 + ul;
+    miss.clear();
+    for (int r = 0; r < m; ++r) {
+      float v;
+      if (get(u, r, &v)) big[(size_t)r * d.n_pad + ul] = v;
+      else miss.push_back((uint32_t)r);
+    }
+    d.nmiss += miss.size();
+    const size_t slots = (miss.size() + 63) / 64 * 64;
+    ptr[ul + 1] = ptr[ul] + (uint32_t)slots;
+    for (size_t e = 0; e < slots; ++e) idx.push_back(e < miss.size() ? miss[e] : (uint32_t)m);  // m = zero sentinel
+  }
+  d.nslots = idx.size();
+
+  CHK(dalloc(&d.big, big.size(), false));
+  HIPCHK(hipMemcpy(d.big, big.data(), big.size() * sizeof(float), hipMemcpyHostToDevice));
+  CHK(dalloc(&d.slabs, (size_t)d.split * d.n_pad * d.KP));
+  CHK(dalloc(&d.slot_ptr, ptr.size(), false));
+  HIPCHK(hipMemcpy(d.slot_ptr, ptr.data(), ptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  CHK(dalloc(&d.idx, idx.size(), false));
+  if (!idx.empty()) HIPCHK(hipMemcpy(d.idx, idx.data(), idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  CHK(dalloc(&d.q, idx.size()));
+  std::vector<float> lam((size_t)std::max(d.n, 1) * d.KP, 0.0f);
+  for (int ul = 0; ul < d.n; ++ul)
+    for (int k = 0; k < W; ++k) lam[(size_t)ul * d.KP + k] = (float)lambda[(size_t)(d.n0 + ul) * W + k];
+  CHK(dalloc(&d.lambda, lam.size(), false));
+  HIPCHK(hipMemcpy(d.lambda, lam.data(), lam.size() * sizeof(float), hipMemcpyHostToDevice));
+  CHK(dalloc(&d.C64, (size_t)64 * 64));
+  CHK(dalloc(&d.C32, (size_t)64 * 64));
+  CHK(dalloc(&d.colsum, 64));
+  CHK(dalloc(&d.colsum2, 64));
+  CHK(dalloc(&d.numer, (size_t)std::max(d.n, 1)));
+  CHK(dalloc(&d.taup, (size_t)std::max(d.n, 1)));
+  return BNMTF_OK;
+}
+
+static int alloc_factor(Dir& d, int other_inner_pad) {
+  d.xrows = std::max(d.nglob + 1, other_inner_pad);
+  d.ldT = round_up(d.nglob + 1, 64);
+  CHK(dalloc(&d.X, (size_t)d.xrows * d.KP));
+  CHK(dalloc(&d.XT, (size_t)d.KP * d.ldT));
+  return BNMTF_OK;
+}
+
+static void free_dir(Dir& d) {
+  dfree(d.big); dfree(d.slabs); dfree(d.lambda); dfree(d.slot_ptr); dfree(d.idx); dfree(d.q);
+  dfree(d.X); dfree(d.XT); dfree(d.C64); dfree(d.C32); dfree(d.colsum); dfree(d.colsum2);
+  dfree(d.mu); dfree(d.tauq); dfree(d.var); dfree(d.S2); dfree(d.S2T); dfree(d.numer); dfree(d.taup);
+}
+
+// ---------------------------------------------------------------- profiling
+struct ScopedKernelTimer {
+  bnmtf_model* h; int id; hipEvent_t a = nullptr, b = nullptr;
+  ScopedKernelTimer(bnmtf_model* h_, int id_) : h(h_), id(id_) {
+    if (!h->profiling) return;
+    auto get = [&]() {
+      hipEvent_t e;
+      if (!h->event_pool.empty()) { e = h->event_pool.back(); h->event_pool.pop_back(); }
+      else (void)hipEventCreate(&e);
+      return e;
+    };
+    a = get(); b = get();
+    (void)hipEventRecord(a, h->stream);
+  }
+  ~ScopedKernelTimer() {
+    if (!h->profiling) return;
+    (void)hipEventRecord(b, h->stream);
+    h->pending_events.push_back({id, {a, b}});
+  }
+};
+static void drain_events(bnmtf_model* h) {
+  for (auto& pe : h->pending_events) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pe.second.first, pe.second.second) == hipSuccess) {
+      h->kernel_ms[pe.first] += ms;
+      h->kernel_launches[pe.first] += 1;
+    }
+    h->event_pool.push_back(pe.second.first);
+    h->event_pool.push_back(pe.second.second);
+  }
+  h->pending_events.clear();
+}
+
+// ------------------------------------------------------------- step pieces
+static void enqueue_gemm(bnmtf_model* h, Dir& d, const Dir& other, int kid) {
+  ScopedKernelTimer t(h, kid);
+  GemmArgs g;
+  g.big = d.big; g.ld = d.n_pad; g.X = other.X; g.slabs = d.slabs;
+  g.n_pad = d.n_pad; g.split = d.split; g.inner_per_wave = d.ipw;
+  launch_gemm(g, d.KP, h->stream);
+}
+static void enqueue_gram(bnmtf_model* h, Dir& d, bool vb = false) {
+  GramArgs g;
+  g.X = d.X; g.S2 = vb ? d.S2 : nullptr; g.rows = d.nglob; g.KP = d.KP;
+  g.C64 = d.C64; g.C32 = d.C32; g.colsum = d.colsum; g.colsum2 = vb ? d.colsum2 : nullptr;
+  launch_gram(g, h->stream);
+}
+static SweepArgs sweep_args(bnmtf_model* h, Dir& d, const Dir& other, int mode, uint32_t stream_id) {
+  SweepArgs s;
+  memset(&s, 0, sizeof(s));
+  s.n = d.n; s.n0 = d.n0; s.K = d.W; s.KP = d.KP; s.mode = mode; s.cond_k = -1;
+  s.slabs = d.slabs; s.split = d.split; s.n_pad = d.n_pad; s.lambda = d.lambda;
+  s.Xself = d.X; s.XselfT = d.XT; s.ldT_self = d.ldT;
+  s.XoT = other.XT; s.ldT_o = other.ldT; s.C32 = other.C32;
+  s.slot_ptr = d.slot_ptr; s.idx = d.idx; s.q = d.q;
+  s.tau = h->tau_f;
+  s.key0 = (uint32_t)h->seed; s.key1 = (uint32_t)(h->seed >> 32); s.it = (uint32_t)h->iteration; s.stream = stream_id;
+  s.acc = nullptr;
+  s.numer_out = d.numer; s.tau_out = d.taup;
+  s.mu_self = d.mu; s.tau_self = d.tauq; s.var_self = d.var; s.S2self = d.S2; s.S2selfT = d.S2T;
+  s.S2oT = other.S2T; s.colsum2_o = other.colsum2;
+  return s;
+}
+
+static int upload_factor(bnmtf_model* h, Dir& d, const double* src) {
+  std::vector<float> tmp((size_t)d.nglob * d.KP, 0.0f);
+  for (int r = 0; r < d.nglob; ++r)
+    for (int k = 0; k < d.W; ++k) tmp[(size_t)r * d.KP + k] = (float)src[(size_t)r * d.W + k];
+  HIPCHK(hipMemcpyAsync(d.X, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  launch_transpose(d.X, d.nglob, d.KP, d.XT, d.ldT, h->stream);
+  return BNMTF_OK;
+}
+static int download_matrix(bnmtf_model* h, const float* dev, int rows, int W, int KP, double* dst) {
+  std::vector<float> tmp((size_t)rows * KP);
+  HIPCHK(hipMemcpyAsync(tmp.data(), dev, tmp.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int r = 0; r < rows; ++r)
+    for (int k = 0; k < W; ++k) dst[(size_t)r * W + k] = (double)tmp[(size_t)r * KP + k];
+  return BNMTF_OK;
+}
+static int set_tau(bnmtf_model* h, double tau) {
+  const float tf = (float)tau;
+  HIPCHK(hipMemcpyAsync(h->tau_d, &tau, sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->tau_f, &tf, sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return BNMTF_OK;
+}
+
+static int ensure_rec(bnmtf_model* h, size_t n) {
+  if (h->rec_cap >= n) return BNMTF_OK;
+  dfree(h->rec);
+  CHK(dalloc(&h->rec, n * 5));
+  h->rec_cap = n;
+  return BNMTF_OK;
+}
+
+}  // namespace bnmtf
+
+using namespace bnmtf;
+
+// ======================================================================= C ABI
+extern "C" {
+
+int bnmtf_version(void) { return 100; }
+const char* bnmtf_last_error(void) { return g_err; }
+
+int bnmtf_device_count(int* count) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { n = 0; (void)hipGetLastError(); }
+  *count = n;
+  return BNMTF_OK;
+}
+
+int bnmtf_comm_unique_id(uint8_t out[128]) { return comm_unique_id(out); }
+
+int bnmtf_create(const bnmtf_problem* p, bnmtf_handle* out) {
+  *out = nullptr;
+  if (!p || !p->R || !p->M || !p->lambda_rows || !p->lambda_cols) { set_error("bnmtf_create: null argument"); return BNMTF_EINVAL; }
+  if (p->I < 1 || p->J < 1 || p->K < 1 || p->K > BNMTF_MAX_RANK || p->L < 0 || p->L > BNMTF_MAX_RANK) {
+    set_error("bnmtf_create: unsupported shape I=%d J=%d K=%d L=%d (1 <= K,L <= %d)", p->I, p->J, p->K, p->L, BNMTF_MAX_RANK);
+    return BNMTF_EINVAL;
+  }
+  if (p->L > 0 && !p->lambda_S) { set_error("bnmtf_create: lambda_S required when L > 0"); return BNMTF_EINVAL; }
+  if (p->world < 1 || p->rank < 0 || p->rank >= p->world) { set_error("bnmtf_create: bad rank/world %d/%d", p->rank, p->world); return BNMTF_EINVAL; }
+  if (p->world > 1 && !p->comm_id) { set_error("bnmtf_create: comm_id required when world > 1"); return BNMTF_EINVAL; }
+  if (p->world > p->I || p->world > p->J) { set_error("bnmtf_create: world %d larger than a matrix dimension", p->world); return BNMTF_EINVAL; }
+  HIPCHK(hipSetDevice(p->device));
+
+  bnmtf_model* h = new bnmtf_model();
+  h->I = p->I; h->J = p->J; h->K = p->K; h->L = p->L;
+  h->alpha = p->alpha; h->beta = p->beta; h->seed = p->seed;
+  h->device = p->device; h->rank = p->rank; h->world = p->world;
+  const int I = p->I, J = p->J;
+  const float* R = p->R; const uint8_t* M = p->M;
+
+  auto fail = [&](int rc) { bnmtf_destroy(h); return rc; };
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(BNMTF_EHIP); }
+
+  // observed counts, training-mask constants (fp64) and the empty row/column check
+  std::vector<uint32_t> rc(I, 0), cc(J, 0);
+  double n_obs = 0, sR = 0, sR2 = 0;
+  for (int i = 0; i < I; ++i)
+    for (int j = 0; j < J; ++j)
+      if (M[(size_t)i * J + j]) {
+        const double r = (double)R[(size_t)i * J + j];
+        rc[i]++; cc[j]++; n_obs += 1.0; sR += r; sR2 += r * r;
+      }
+  for (int i = 0; i < I; ++i) if (!rc[i]) { set_error("Fully unobserved row in R, row %d.", i); return fail(BNMTF_EINVAL); }
+  for (int j = 0; j < J; ++j) if (!cc[j]) { set_error("Fully unobserved column in R, column %d.", j); return fail(BNMTF_EINVAL); }
+  h->n_obs = n_obs; h->sumR = sR; h->sumR2 = sR2;
+
+  const int Wr = p->K, Wc = p->L > 0 ? p->L : p->K;
+  int rcode = build_dir(h->rows, I, J, Wr, p->rank, p->world, p->lambda_rows,
+                        [&](int i, int j, float* v) { *v = R[(size_t)i * J + j]; return M[(size_t)i * J + j] != 0; });
+  if (rcode) return fail(rcode);
+  rcode = build_dir(h->cols, J, I, Wc, p->rank, p->world, p->lambda_cols,
+                    [&](int j, int i, float* v) { *v = R[(size_t)i * J + j]; return M[(size_t)i * J + j] != 0; });
+  if (rcode) return fail(rcode);
+  h->rows.obs_count = rc; h->cols.obs_count = cc;
+  if ((rcode = alloc_factor(h->rows, h->cols.inner_pad))) return fail(rcode);
+  if ((rcode = alloc_factor(h->cols, h->rows.inner_pad))) return fail(rcode);
+
+  if ((rcode = dalloc(&h->Rfull, (size_t)I * J, false))) return fail(rcode);
+  if (hipMemcpy(h->Rfull, R, (size_t)I * J * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { set_error("copy R failed"); return fail(BNMTF_EHIP); }
+  if ((rcode = dalloc(&h->Mtrain, (size_t)I * J, false))) return fail(rcode);
+  if (hipMemcpy(h->Mtrain, M, (size_t)I * J, hipMemcpyHostToDevice) != hipSuccess) { set_error("copy M failed"); return fail(BNMTF_EHIP); }
+  if ((rcode = dalloc(&h->Ad, (size_t)I * 64))) return fail(rcode);
+  if ((rcode = dalloc(&h->Bd, (size_t)J * 64))) return fail(rcode);
+  if ((rcode = dalloc(&h->out6, 8))) return fail(rcode);
+  if ((rcode = dalloc(&h->tau_d, 1))) return fail(rcode);
+  if ((rcode = dalloc(&h->tau_f, 1))) return fail(rcode);
+  if ((rcode = dalloc(&h->acc, 4))) return fail(rcode);
+  if (p->L > 0 && (rcode = dalloc(&h->S, (size_t)p->K * p->L))) return fail(rcode);
+
+  if (p->world > 1) {
+    if ((rcode = comm_create(&h->comm, p->comm_id, p->rank, p->world, h->stream))) return fail(rcode);
+  }
+
+  char buf[512];
+  snprintf(buf, sizeof(buf),
+           "I=%d J=%d K=%d L=%d rank=%d/%d rows[n=%d n_pad=%d split=%d ipw=%d inner_pad=%d nmiss=%zu nslots=%zu] "
+           "cols[n=%d n_pad=%d split=%d ipw=%d inner_pad=%d nmiss=%zu nslots=%zu] n_obs=%.0f",
+           I, J, p->K, p->L, p->rank, p->world, h->rows.n, h->rows.n_pad, h->rows.split, h->rows.ipw, h->rows.inner_pad,
+           h->rows.nmiss, h->rows.nslots, h->cols.n, h->cols.n_pad, h->cols.split, h->cols.ipw, h->cols.inner_pad,
+           h->cols.nmiss, h->cols.nslots, n_obs);
+  h->description = buf;
+  *out = h;
+  return BNMTF_OK;
+}
+
+int bnmtf_destroy(bnmtf_handle h) {
+  if (!h) return BNMTF_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->comm) comm_destroy(h->comm);
+  free_dir(h->rows); free_dir(h->cols);
+  dfree(h->Rfull); dfree(h->Mtrain); dfree(h->Mscratch); dfree(h->Ad); dfree(h->Bd); dfree(h->out6);
+  dfree(h->tau_d); dfree(h->tau_f); dfree(h->acc); dfree(h->rec); dfree(h->S);
+  for (auto& pe : h->pending_events) { (void)hipEventDestroy(pe.second.first); (void)hipEventDestroy(pe.second.second); }
+  for (auto e : h->event_pool) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return BNMTF_OK;
+}
+
+int bnmtf_sync(bnmtf_handle h) {
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return BNMTF_OK;
+}
+
+int bnmtf_omega_counts(bnmtf_handle h, uint64_t* total, uint32_t* row, uint32_t* col) {
+  if (total) *total = (uint64_t)h->n_obs;
+  if (row) memcpy(row, h->rows.obs_count.data(), sizeof(uint32_t) * h->I);
+  if (col) memcpy(col, h->cols.obs_count.data(), sizeof(uint32_t) * h->J);
+  return BNMTF_OK;
+}
+
+int bnmtf_set_iteration(bnmtf_handle h, uint64_t it) { h->iteration = it; return BNMTF_OK; }
+int bnmtf_get_iteration(bnmtf_handle h, uint64_t* it) { *it = h->iteration; return BNMTF_OK; }
+
+int bnmtf_set_profiling(bnmtf_handle h, int enable) {
+  h->profiling = enable != 0;
+  for (int i = 0; i < BNMTF_KERNEL_COUNT; ++i) { h->kernel_ms[i] = 0; h->kernel_launches[i] = 0; }
+  return BNMTF_OK;
+}
+int bnmtf_kernel_stats(bnmtf_handle h, int kernel, double* total_ms, uint64_t* launches) {
+  if (kernel < 0 || kernel >= BNMTF_KERNEL_COUNT) { set_error("bad kernel id"); return BNMTF_EINVAL; }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  drain_events(h);
+  *total_ms = h->kernel_ms[kernel]; *launches = h->kernel_launches[kernel];
+  return BNMTF_OK;
+}
+int bnmtf_describe(bnmtf_handle h, char* buf, size_t buflen) {
+  snprintf(buf, buflen, "%s", h->description.c_str());
+  return BNMTF_OK;
+}
+
+// ------------------------------------------------------------------ BNMF Gibbs
+int bnmf_set_state(bnmtf_handle h, const double* U, const double* V, double tau) {
+  if (h->L != 0) { set_error("bnmf_set_state on a BNMTF handle"); return BNMTF_ESTATE; }
+  HIPCHK(hipSetDevice(h->device));
+  CHK(upload_factor(h, h->rows, U));
+  CHK(upload_factor(h, h->cols, V));
+  enqueue_gram(h, h->rows);
+  enqueue_gram(h, h->cols);
+  CHK(set_tau(h, tau));
+  h->have_state = true;
+  return BNMTF_OK;
+}
+
+int bnmf_get_state(bnmtf_handle h, double* U, double* V, double* tau) {
+  if (!h->have_state) { set_error("no state set"); return BNMTF_ESTATE; }
+  HIPCHK(hipSetDevice(h->device));
+  if (U) CHK(download_matrix(h, h->rows.X, h->I, h->rows.W, h->rows.KP, U));
+  if (V) CHK(download_matrix(h, h->cols.X, h->J, h->cols.W, h->cols.KP, V));
+  if (tau) {
+    HIPCHK(hipMemcpyAsync(tau, h->tau_d, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  return BNMTF_OK;
+}
+
+int bnmf_cond_params(bnmtf_handle h, int which, int k, double* numer_out, double* tau_out) {
+  if (!h->have_state) { set_error("no state set"); return BNMTF_ESTATE; }
+  if (h->world != 1) { set_error("cond_params is a single-GPU test hook"); return BNMTF_EINVAL; }
+  Dir& d = which == 0 ? h->rows : h->cols;
+  Dir& o = which == 0 ? h->cols : h->rows;
+  if (k < 0 || k >= d.W) { set_error("column %d out of range", k); return BNMTF_EINVAL; }
+  HIPCHK(hipSetDevice(h->device));
+  enqueue_gemm(h, d, o, which == 0 ? BNMTF_KERNEL_GEMM_ROWS : BNMTF_KERNEL_GEMM_COLS);
+  SweepArgs s = sweep_args(h, d, o, kSweepDraw, which == 0 ? kStreamRows : kStreamCols);
+  s.cond_k = k;
+  launch_sweep(s, h->stream);
+  HIPCHK(hipMemcpyAsync(numer_out, d.numer, sizeof(double) * d.n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(tau_out, d.taup, sizeof(double) * d.n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
+  return BNMTF_OK;
+}
+
+int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* V_out,
+                   double* tau_out, double* perf_out, double* times_out) {
+  if (h->L != 0) { set_error("bnmf_gibbs_run on a BNMTF handle"); return BNMTF_ESTATE; }
+  if (!h->have_state) { set_error("bnmf_gibbs_run before bnmf_set_state"); return BNMTF_ESTATE; }
+  if (n_iter < 0) { set_error("negative iteration count"); return BNMTF_EINVAL; }
+  if (n_iter == 0) return BNMTF_OK;
+  HIPCHK(hipSetDevice(h->device));
+  CHK(ensure_rec(h, (size_t)n_iter));
+  const int mode = update == BNMTF_UPDATE_MODE ? kSweepMode : kSweepDraw;
+  Dir& r = h->rows; Dir& c = h->cols;
+  std::vector<hipEvent_t> ev(times_out ? n_iter + 1 : 0);
+  for (auto& e : ev) HIPCHK(hipEventCreate(&e));
+  if (times_out) HIPCHK(hipEventRecord(ev[0], h->stream));
+
+  for (int it = 0; it < n_iter; ++it) {
+    // ---- U columns: P = R~ . V, then the K sequential row-wise updates
+    enqueue_gemm(h, r, c, BNMTF_KERNEL_GEMM_ROWS);
+    {
+      ScopedKernelTimer t(h, BNMTF_KERNEL_SWEEP_ROWS);
+      SweepArgs s = sweep_args(h, r, c, mode, kStreamRows);
+      launch_sweep(s, h->stream);
+    }
+    if (h->comm) CHK(comm_allgather_factor(h->comm, r.X, r.KP, r.nglob, h->world, h->stream, r.XT, r.ldT));
+    enqueue_gram(h, r);
+    // ---- V columns: Pv = R~^T . U
+    enqueue_gemm(h, c, r, BNMTF_KERNEL_GEMM_COLS);
+    HIPCHK(hipMemsetAsync(h->acc, 0, 4 * sizeof(double), h->stream));
+    {
+      ScopedKernelTimer t(h, BNMTF_KERNEL_SWEEP_COLS);
+      SweepArgs s = sweep_args(h, c, r, mode, kStreamCols);
+      s.acc = h->acc;
+      launch_sweep(s, h->stream);
+    }
+    if (h->comm) {
+      CHK(comm_allgather_factor(h->comm, c.X, c.KP, c.nglob, h->world, h->stream, c.XT, c.ldT));
+      CHK(comm_allreduce_sum(h->comm, h->acc, 4, h->stream));
+    }
+    enqueue_gram(h, c);
+    // ---- tau and the metrics of this sample
+    FinishArgs f;
+    f.Cr64 = r.C64; f.Cc64 = c.C64; f.sr = r.colsum; f.sc = c.colsum; f.KP = r.KP;
+    f.acc = h->acc; f.n_obs = h->n_obs; f.sumR = h->sumR; f.sumR2 = h->sumR2;
+    f.alpha = h->alpha; f.beta = h->beta; f.update = update;
+    f.key0 = (uint32_t)h->seed; f.key1 = (uint32_t)(h->seed >> 32); f.it = (uint32_t)h->iteration;
+    f.tau_d = h->tau_d; f.tau_f = h->tau_f; f.rec = h->rec + (size_t)it * 5;
+    launch_finish(f, h->stream);
+    // ---- sample hand-off (all_U[it], all_V[it])
+    if (U_out) HIPCHK(hipMemcpy2DAsync(U_out + (size_t)it * h->I * r.W, r.W * sizeof(float), r.X, r.KP * sizeof(float),
+                                       r.W * sizeof(float), h->I, hipMemcpyDeviceToHost, h->stream));
+    if (V_out) HIPCHK(hipMemcpy2DAsync(V_out + (size_t)it * h->J * c.W, c.W * sizeof(float), c.X, c.KP * sizeof(float),
+                                       c.W * sizeof(float), h->J, hipMemcpyDeviceToHost, h->stream));
+    if (times_out) HIPCHK(hipEventRecord(ev[it + 1], h->stream));
+    h->iteration++;
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
+  drain_events(h);
+  std::vector<double> rec((size_t)n_iter * 5);
+  HIPCHK(hipMemcpy(rec.data(), h->rec, rec.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (int it = 0; it < n_iter; ++it) {
+    if (tau_out) tau_out[it] = rec[(size_t)it * 5];
+    if (perf_out) for (int m = 0; m < 3; ++m) perf_out[(size_t)it * 3 + m] = rec[(size_t)it * 5 + 1 + m];
+    if (times_out) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, ev[0], ev[it + 1]);
+      times_out[it] = (double)ms * 1e-3;
+    }
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return BNMTF_OK;
+}
+
+// ---------------------------------------------------------------------- metrics
+int bnmtf_metric_sums(bnmtf_handle h, const uint8_t* Mp, const double* A, const double* S, const double* B,
+                      double sums_out[6]) {
+  HIPCHK(hipSetDevice(h->device));
+  const int I = h->I, J = h->J;
+  std::vector<double> a_own, b_own, as;
+  int Kc;  // contraction width of the two-factor product handed to the kernel
+  if (!A) {
+    if (!h->have_state) { set_error("no state set"); return BNMTF_ESTATE; }
+    a_own.resize((size_t)I * h->rows.W); b_own.resize((size_t)J * h->cols.W);
+    CHK(download_matrix(h, h->rows.X, I, h->rows.W, h->rows.KP, a_own.data()));
+    CHK(download_matrix(h, h->cols.X, J, h->cols.W, h->cols.KP, b_own.data()));
+    A = a_own.data(); B = b_own.data();
+    if (h->L > 0) {
+      as.resize((size_t)h->K * h->L);
+      std::vector<float> sf((size_t)h->K * h->L);
+      HIPCHK(hipMemcpy(sf.data(), h->S, sf.size() * sizeof(float), hipMemcpyDeviceToHost));
+      for (size_t t = 0; t < sf.size(); ++t) as[t] = sf[t];
+      S = as.data();
+    }
+  }
+  std::vector<double> AS;
+  if (S) {   // A.S  (I x L), then a plain two-factor product with B (J x L)
+    const int K = h->K, L = h->L;
+    AS.assign((size_t)I * L, 0.0);
+    for (int i = 0; i < I; ++i)
+      for (int k = 0; k < K; ++k) {
+        const double aik = A[(size_t)i * K + k];
+        for (int l = 0; l < L; ++l) AS[(size_t)i * L + l] += aik * S[(size_t)k * L + l];
+      }
+    A = AS.data(); Kc = L;
+  } else {
+    Kc = h->L > 0 ? h->L : h->K;
+    if (h->L > 0) { set_error("bnmtf_metric_sums: S required for a BNMTF handle"); return BNMTF_EINVAL; }
+  }
+  HIPCHK(hipMemcpyAsync(h->Ad, A, sizeof(double) * (size_t)I * Kc, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->Bd, B, sizeof(double) * (size_t)J * Kc, hipMemcpyHostToDevice, h->stream));
+  const uint8_t* mask = h->Mtrain;
+  if (Mp) {
+    if (!h->Mscratch) CHK(dalloc(&h->Mscratch, (size_t)I * J, false));
+    HIPCHK(hipMemcpyAsync(h->Mscratch, Mp, (size_t)I * J, hipMemcpyHostToDevice, h->stream));
+    mask = h->Mscratch;
+  }
+  MetricArgs m;
+  m.R = h->Rfull; m.Mp = mask; m.I = I; m.J = J; m.A = h->Ad; m.B = h->Bd; m.K = Kc; m.out6 = h->out6;
+  launch_metric_sums(m, h->stream);
+  HIPCHK(hipMemcpyAsync(sums_out, h->out6, 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
+  return BNMTF_OK;
+}
+
+int bnmtf_beta_s(bnmtf_handle h, double* out) {
+  double s[6];
+  CHK(bnmtf_metric_sums(h, nullptr, nullptr, nullptr, nullptr, s));
+  *out = h->beta + 0.5 * (s[2] - 2.0 * s[5] + s[4]);
+  return BNMTF_OK;
+}
+
+// ---------------------------------------------------------------- distributions
+int bnmtf_tn_sample(const double* mu, const double* tau, size_t n, uint64_t seed, uint64_t it, uint32_t col,
+                    uint32_t elem0, int device, double* out) {
+  if (n == 0) return BNMTF_OK;
+  HIPCHK(hipSetDevice(device));
+  double *dm = nullptr, *dt = nullptr, *dout = nullptr;
+  CHK(dalloc(&dm, n, false)); CHK(dalloc(&dt, n, false)); CHK(dalloc(&dout, n, false));
+  HIPCHK(hipMemcpy(dm, mu, n * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dt, tau, n * sizeof(double), hipMemcpyHostToDevice));
+  launch_tn_sample(dm, dt, n, seed, (uint32_t)it, col, elem0, dout, nullptr);
+  HIPCHK(hipMemcpy(out, dout, n * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipGetLastError());
+  dfree(dm); dfree(dt); dfree(dout);
+  return BNMTF_OK;
+}
+
+int bnmtf_tn_moments(const double* mu, const double* tau, size_t n, int device, double* exp_out, double* var_out) {
+  if (n == 0) return BNMTF_OK;
+  HIPCHK(hipSetDevice(device));
+  double *dm = nullptr, *dt = nullptr, *de = nullptr, *dv = nullptr;
+  CHK(dalloc(&dm, n, false)); CHK(dalloc(&dt, n, false)); CHK(dalloc(&de, n, false)); CHK(dalloc(&dv, n, false));
+  HIPCHK(hipMemcpy(dm, mu, n * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dt, tau, n * sizeof(double), hipMemcpyHostToDevice));
+  launch_tn_moments(dm, dt, n, de, dv, nullptr);
+  HIPCHK(hipMemcpy(exp_out, de, n * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(var_out, dv, n * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipGetLastError());
+  dfree(dm); dfree(dt); dfree(de); dfree(dv);
+  return BNMTF_OK;
+}
+
+int bnmtf_gamma_sample(double alpha, double beta, uint64_t seed, uint64_t it, int device, double* out) {
+  HIPCHK(hipSetDevice(device));
+  double* d = nullptr;
+  CHK(dalloc(&d, 1));
+  launch_gamma_sample(alpha, beta, seed, (uint32_t)it, d, nullptr);
+  HIPCHK(hipMemcpy(out, d, sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipGetLastError());
+  dfree(d);
+  return BNMTF_OK;
+}
+
+}  // extern "C"

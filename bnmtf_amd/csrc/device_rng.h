@@ -1,0 +1,125 @@
+// Device-side statement of oracle/rng.py: Philox-4x32-10 and the
+// first-accepted-candidate TN(mu,tau) / Gamma samplers.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels.h"
+
+namespace bnmtf {
+
+constexpr float kTnA0 = 0.25f;
+constexpr float kTwoPi = 6.283185307179586f;
+
+struct U4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                             uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return U4{c0, c1, c2, c3};
+}
+
+// uint32 -> (0,1), 24 significant bits: identical value in fp32 and fp64
+__device__ __forceinline__ float u24(uint32_t r) { return ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+__device__ __forceinline__ double u32d(uint32_t r) { return ((double)r + 0.5) * (1.0 / 4294967296.0); }
+
+// Per-draw constants of TN(mu, tau_p) on [0,inf): a = -mu*sqrt(tau_p).
+struct TnParams {
+  float mu, rt;      // mean, sqrt(precision)
+  float a, d, lam;   // lower bound (standardised), lam - a, Robert rate
+  bool live, tail;
+};
+
+__device__ __forceinline__ TnParams tn_params(float mu, float tau_p) {
+  TnParams p;
+  p.live = tau_p > 0.0f;
+  p.rt = sqrtf(p.live ? tau_p : 1.0f);
+  p.mu = mu;
+  p.a = -mu * p.rt;
+  p.live = p.live && isfinite(p.a);
+  p.d = 2.0f / (sqrtf(p.a * p.a + 4.0f) + p.a);
+  p.lam = p.a + p.d;
+  p.tail = p.a >= kTnA0;
+  return p;
+}
+
+// Candidate number `cand` of the draw identified by (elem, col, it, stream).
+// Returns acceptance; *x receives the candidate value.
+__device__ __forceinline__ bool tn_candidate(const TnParams& p, uint32_t elem, uint32_t col, uint32_t it,
+                                             uint32_t stream, uint32_t cand, uint32_t k0, uint32_t k1, float* x) {
+  const U4 r = philox4x32_10(elem, col, it, stream + 16u * cand, k0, k1);
+  const float u1 = u24(r.x), u2 = u24(r.y);
+  const float nl = -logf(u1);
+  bool acc;
+  if (p.tail) {
+    const float e = nl / p.lam;
+    const float t = e - p.d;
+    acc = u2 <= expf(-0.5f * t * t);
+    *x = e / p.rt;
+  } else {
+    const float z = sqrtf(2.0f * nl) * cosf(kTwoPi * u2);
+    acc = z >= p.a;
+    *x = p.mu + z / p.rt;
+  }
+  return acc;
+}
+
+__device__ __forceinline__ float tn_guard(float x) { return (isfinite(x) && x >= 0.0f) ? x : 0.0f; }
+
+// Serial form (one thread per draw): used by the stand-alone hook and the S sweep.
+__device__ __forceinline__ float tn_draw_serial(float mu, float tau_p, uint32_t elem, uint32_t col, uint32_t it,
+                                                uint32_t stream, uint32_t k0, uint32_t k1) {
+  const TnParams p = tn_params(mu, tau_p);
+  if (!p.live) return 0.0f;
+  float x = 0.0f;
+  for (uint32_t c = 0; c < 4096u; ++c)
+    if (tn_candidate(p, elem, col, it, stream, c, k0, k1, &x)) return tn_guard(x);
+  return 0.0f;
+}
+
+// Gamma(shape, rate) by Marsaglia-Tsang in fp64 (one thread).
+__device__ inline double gamma_draw_serial(double shape, double rate, uint32_t it, uint32_t stream,
+                                           uint32_t k0, uint32_t k1) {
+  const bool boost = shape < 1.0;
+  const double a = boost ? shape + 1.0 : shape;
+  const double d = a - 1.0 / 3.0;
+  const double c = 1.0 / sqrt(9.0 * d);
+  for (uint32_t cand = 0; cand < 4096u; ++cand) {
+    const U4 r = philox4x32_10(0u, 0u, it, stream + 16u * cand, k0, k1);
+    const double u1 = u32d(r.x), u2 = u32d(r.y), u3 = u32d(r.z), u4 = u32d(r.w);
+    const double x = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+    double v = 1.0 + c * x;
+    if (v <= 0.0) continue;
+    v = v * v * v;
+    if (log(u3) < 0.5 * x * x + d - d * v + d * log(v)) {
+      double g = d * v;
+      if (boost) g *= pow(u4, 1.0 / shape);
+      return g / rate;
+    }
+  }
+  return shape / rate;
+}
+
+// TN moments in fp64, as truncated_normal_vector.py:53-73 (incl. the exponential
+// fall-back for mu < -30 sigma and the negative / non-finite -> 0 guard).
+__device__ inline void tn_moments(double mu, double tau_p, double* e_out, double* v_out) {
+  const double sig = 1.0 / sqrt(tau_p);
+  const double x = -mu / sig;
+  const double pdf = 0.3989422804014327 * exp(-0.5 * x * x);
+  const double lam = pdf / (0.5 * erfc(x * 0.7071067811865476));
+  double e = mu + sig * lam;
+  double v = sig * sig * (1.0 - lam * (lam - x));
+  if (mu < -30.0 * sig) {
+    e = 1.0 / (fabs(mu) * tau_p);
+    v = e * e;
+  }
+  *e_out = (isfinite(e) && e >= 0.0) ? e : 0.0;
+  *v_out = (isfinite(v) && v >= 0.0) ? v : 0.0;
+}
+
+}  // namespace bnmtf

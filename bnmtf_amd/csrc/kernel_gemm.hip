@@ -1,0 +1,115 @@
+// K1/K2: the masked contractions  P = R~ . V  and  Pv = R~^T . U  ("the U^T.R step").
+//
+// Both are the same skinny product  out[n][KP] = sum_r big[r][n] * X[r][KP]  with
+// n, r ~ 8192 and KP = 32/64: every element of `big` (the 256 MiB operand) is used
+// by exactly one wave, so it is streamed HBM -> VGPR directly in MFMA B-fragment
+// shape (no LDS round trip; see cdna_hip_programming.md "GEMV / operand streamed once"),
+// while the small factor X is the A operand.
+//
+// v_mfma_f32_32x32x2_f32:  D[i][j] += sum_{k<2} A[i][k] B[k][j]
+//   A: lane l holds A[i = l&31][k = l>>5]   -> X[r + (l>>5)][mt*32 + (l&31)]      (coalesced 128 B)
+//   B: lane l holds B[k = l>>5][j = l&31]   -> big[r + (l>>5)][col0 + 4*(l&31) + t] (one dwordx4 = 4 tiles)
+//   D: reg g, lane l -> i = (g&3) + 8*(g>>2) + 4*(l>>5), j = l&31
+// One dwordx4 per lane per r-pair gives the B fragments of four 32-column tiles whose
+// columns interleave with stride 4, so each wave-instruction reads two fully used
+// 512 B row segments.  A wave owns 128 output columns x KP and a private slice of the
+// inner dimension; the four waves of a block reduce through LDS and the block writes
+// one partial slab, which the sweep kernel sums in its prologue.
+#include "kernels.h"
+
+namespace bnmtf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int MT>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
+  constexpr int KP = MT * 32;
+  constexpr int NACC = MT * 4 * 16;            // accumulator floats per lane
+  __shared__ float red[2][NACC * 64];          // 2 x 32 KiB (MT=2)
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, c = lane & 31;
+  const int col0 = blockIdx.x * 128;
+  const int s = blockIdx.y;
+  const int ipw = a.inner_per_wave;
+  const size_t r0 = (size_t)(s * 4 + wave) * ipw + h;
+
+  const float* bp = a.big + r0 * (size_t)a.ld + col0 + 4 * c;
+  const float* xp = a.X + r0 * KP + c;
+  const size_t bstep = 2 * (size_t)a.ld;
+
+  f32x16 acc[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[mt][t][g] = 0.0f;
+
+  constexpr int U = 8;                          // r-pairs in flight per wave
+  for (int kk = 0; kk < ipw; kk += 2 * U) {
+    f32x4 b[U];
+    float av[U][MT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      b[u] = *reinterpret_cast<const f32x4*>(bp + u * bstep);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) av[u][mt] = xp[u * 2 * KP + mt * 32];
+    }
+    bp += U * bstep;
+    xp += U * 2 * KP;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][mt], b[u][t], acc[mt][t], 0, 0, 0);
+  }
+
+  // cross-wave tree reduction through LDS: (2,3) -> (0,1), then 1 -> 0
+  auto put = [&](float* dst) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) dst[((mt * 4 + t) * 16 + g) * 64 + lane] = acc[mt][t][g];
+  };
+  auto add = [&](const float* src) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[mt][t][g] += src[((mt * 4 + t) * 16 + g) * 64 + lane];
+  };
+  if (wave >= 2) put(red[wave - 2]);
+  __syncthreads();
+  if (wave < 2) add(red[wave]);
+  __syncthreads();
+  if (wave == 1) put(red[0]);
+  __syncthreads();
+  if (wave == 0) {
+    add(red[0]);
+    float* out = a.slabs + ((size_t)s * a.n_pad + col0) * KP;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          f32x4 v = {acc[mt][t][4 * g4], acc[mt][t][4 * g4 + 1], acc[mt][t][4 * g4 + 2], acc[mt][t][4 * g4 + 3]};
+          *reinterpret_cast<f32x4*>(out + (size_t)(4 * c + t) * KP + mt * 32 + 8 * g4 + 4 * h) = v;
+        }
+  }
+}
+
+void launch_gemm(const GemmArgs& a, int KP, hipStream_t st) {
+  dim3 grid(a.n_pad / 128, a.split), block(256);
+  if (KP == 32) hipLaunchKernelGGL(gemm_kernel<1>, grid, block, 0, st, a);
+  else          hipLaunchKernelGGL(gemm_kernel<2>, grid, block, 0, st, a);
+}
+
+}  // namespace bnmtf

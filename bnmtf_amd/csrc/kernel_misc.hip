@@ -1,0 +1,181 @@
+// Small kernels around the two hot ones: Gram matrices, end-of-iteration scalar
+// work (masked SSE from Gram identities, tau draw, metrics), direct fp64 metric
+// sums for predict(), layout helpers and the stand-alone distribution hooks.
+#include "kernels.h"
+#include "device_rng.h"
+
+namespace bnmtf {
+
+// ---------------------------------------------------------------------------
+// Gram: C = X^T X in fp64.  Block = 256 threads, 128 rows per block staged in LDS;
+// thread t owns entries (a, b) with a*KP+b = t + 256*m.  fp64 atomics merge blocks.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
+  __shared__ float tile[128 * 64];
+  const int KP = a.KP;
+  const int r0 = blockIdx.x * 128;
+  const int nr = min(128, a.rows - r0);
+  for (int t = threadIdx.x; t < nr * KP; t += 256) tile[t] = a.X[(size_t)r0 * KP + t];
+  __syncthreads();
+  const int npairs = KP * KP;
+  for (int pidx = threadIdx.x; pidx < npairs; pidx += 256) {
+    const int ia = pidx / KP, ib = pidx % KP;
+    if (ib < ia) continue;                       // symmetric: compute upper triangle
+    double s = 0.0;
+    for (int r = 0; r < nr; ++r) s = fma((double)tile[r * KP + ia], (double)tile[r * KP + ib], s);
+    atomicAdd(a.C64 + pidx, s);
+    if (ib != ia) atomicAdd(a.C64 + ib * KP + ia, s);
+  }
+  if ((int)threadIdx.x < KP) {
+    double s = 0.0;
+    for (int r = 0; r < nr; ++r) s += (double)tile[r * KP + threadIdx.x];
+    atomicAdd(a.colsum + threadIdx.x, s);
+    if (a.S2) {
+      double s2 = 0.0;
+      for (int r = 0; r < nr; ++r) s2 += (double)a.S2[(size_t)(r0 + r) * KP + threadIdx.x];
+      atomicAdd(a.colsum2 + threadIdx.x, s2);
+    }
+  }
+}
+__global__ void gram_finish_kernel(const double* C64, float* C32, int n) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) C32[t] = (float)C64[t];
+}
+void launch_gram(const GramArgs& a, hipStream_t st) {
+  (void)hipMemsetAsync(a.C64, 0, sizeof(double) * a.KP * a.KP, st);
+  (void)hipMemsetAsync(a.colsum, 0, sizeof(double) * a.KP, st);
+  if (a.colsum2) (void)hipMemsetAsync(a.colsum2, 0, sizeof(double) * a.KP, st);
+  hipLaunchKernelGGL(gram_kernel, dim3((a.rows + 127) / 128), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(gram_finish_kernel, dim3((a.KP * a.KP + 255) / 256), dim3(256), 0, st, a.C64, a.C32, a.KP * a.KP);
+}
+
+// ---------------------------------------------------------------------------
+// end of iteration (bnmf_gibbs_optimised.py:144 tau draw, :199-223 metrics):
+//   sum_Omega Rp^2 = <U^T U, V^T V> - sum_miss q^2 ;  sum_Omega Rp = (1^T U).(1^T V) - sum_miss q
+//   sum_Omega R Rp = sum (Pv o V)   (Pv = R~^T U only holds observed entries)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
+  __shared__ double red[256];
+  const int KP = a.KP;
+  double s = 0.0;
+  for (int t = threadIdx.x; t < KP * KP; t += 256) s = fma(a.Cr64[t], a.Cc64[t], s);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w >= 1; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double dot = red[0];
+    double sp1 = 0.0;
+    for (int t = 0; t < KP; ++t) sp1 = fma(a.sr[t], a.sc[t], sp1);
+    const double srp = a.acc[0], sp = sp1 - a.acc[1], spp = dot - a.acc[2];
+    const double n = a.n_obs;
+    const double sse = a.sumR2 - 2.0 * srp + spp;
+    const double alpha_s = a.alpha + 0.5 * n, beta_s = a.beta + 0.5 * sse;
+    double tau;
+    if (a.update == 0) tau = gamma_draw_serial(alpha_s, beta_s, a.it, kStreamTau, a.key0, a.key1);
+    else tau = alpha_s / beta_s;
+    *a.tau_d = tau;
+    *a.tau_f = (float)tau;
+    const double ss_tot = a.sumR2 - a.sumR * a.sumR / n;
+    const double cov = srp - a.sumR * sp / n;
+    const double vp = spp - sp * sp / n;
+    a.rec[0] = tau;
+    a.rec[1] = sse / n;
+    a.rec[2] = ss_tot != 0.0 ? 1.0 - sse / ss_tot : __longlong_as_double(0x7ff0000000000000LL);
+    a.rec[3] = cov / (sqrt(ss_tot) * sqrt(vp));
+    a.rec[4] = sse;
+  }
+}
+void launch_finish(const FinishArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, a);
+}
+
+// ---------------------------------------------------------------------------
+// direct masked metric sums, fp64 arithmetic (predict(), beta_s(), validation).
+// Block (32 x 8) covers a 32 x 32 tile of R; A/B tiles in LDS as double.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void metric_kernel(MetricArgs a) {
+  __shared__ double At[32 * 65], Bt[32 * 65];
+  __shared__ double red[6][256];
+  const int K = a.K;
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  const int tid = threadIdx.y * 32 + threadIdx.x;
+  for (int t = tid; t < 32 * K; t += 256) {
+    const int r = t / K, k = t % K;
+    At[r * 65 + k] = (i0 + r < a.I) ? a.A[(size_t)(i0 + r) * K + k] : 0.0;
+    Bt[r * 65 + k] = (j0 + r < a.J) ? a.B[(size_t)(j0 + r) * K + k] : 0.0;
+  }
+  __syncthreads();
+  double s[6] = {0, 0, 0, 0, 0, 0};
+  const int j = j0 + threadIdx.x;
+  for (int rr = 0; rr < 4; ++rr) {
+    const int il = threadIdx.y + 8 * rr, i = i0 + il;
+    if (i < a.I && j < a.J && a.Mp[(size_t)i * a.J + j]) {
+      double pr = 0.0;
+      for (int k = 0; k < K; ++k) pr = fma(At[il * 65 + k], Bt[threadIdx.x * 65 + k], pr);
+      const double r = (double)a.R[(size_t)i * a.J + j];
+      s[0] += 1.0; s[1] += r; s[2] += r * r; s[3] += pr; s[4] += pr * pr; s[5] += r * pr;
+    }
+  }
+  for (int m = 0; m < 6; ++m) red[m][tid] = s[m];
+  __syncthreads();
+  for (int w = 128; w >= 1; w >>= 1) {
+    if (tid < w) for (int m = 0; m < 6; ++m) red[m][tid] += red[m][tid + w];
+    __syncthreads();
+  }
+  if (tid < 6) atomicAdd(a.out6 + tid, red[tid][0]);
+}
+void launch_metric_sums(const MetricArgs& a, hipStream_t st) {
+  (void)hipMemsetAsync(a.out6, 0, 6 * sizeof(double), st);
+  dim3 grid((a.J + 31) / 32, (a.I + 31) / 32), block(32, 8);
+  hipLaunchKernelGGL(metric_kernel, grid, block, 0, st, a);
+}
+
+// ---------------------------------------------------------------------------
+__global__ void transpose_kernel(const float* X, int rows, int KP, float* XT, int ldT) {
+  __shared__ float t[64][65];
+  const int r0 = blockIdx.x * 64;
+  for (int e = threadIdx.x; e < 64 * KP; e += 256) {
+    const int r = e / KP, k = e % KP;
+    t[r][k] = (r0 + r < rows) ? X[(size_t)(r0 + r) * KP + k] : 0.f;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * KP; e += 256) {
+    const int k = e / 64, r = e % 64;
+    if (r0 + r < rows) XT[(size_t)k * ldT + r0 + r] = t[r][k];
+  }
+}
+void launch_transpose(const float* X, int rows, int KP, float* XT, int ldT, hipStream_t st) {
+  hipLaunchKernelGGL(transpose_kernel, dim3((rows + 63) / 64), dim3(256), 0, st, X, rows, KP, XT, ldT);
+}
+
+// ---------------------------------------------------------------------------
+__global__ void tn_sample_kernel(const double* mu, const double* tau, size_t n, uint32_t k0, uint32_t k1,
+                                 uint32_t it, uint32_t col, uint32_t elem0, double* out) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  out[e] = (double)tn_draw_serial((float)mu[e], (float)tau[e], elem0 + (uint32_t)e, col, it, kStreamHook, k0, k1);
+}
+void launch_tn_sample(const double* mu, const double* tau, size_t n, uint64_t seed, uint32_t it, uint32_t col,
+                      uint32_t elem0, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(tn_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mu, tau, n,
+                     (uint32_t)seed, (uint32_t)(seed >> 32), it, col, elem0, out);
+}
+__global__ void tn_moments_kernel(const double* mu, const double* tau, size_t n, double* e, double* v) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  tn_moments(mu[t], tau[t], e + t, v + t);
+}
+void launch_tn_moments(const double* mu, const double* tau, size_t n, double* e, double* v, hipStream_t st) {
+  hipLaunchKernelGGL(tn_moments_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mu, tau, n, e, v);
+}
+__global__ void gamma_sample_kernel(double alpha, double beta, uint32_t k0, uint32_t k1, uint32_t it, double* out) {
+  *out = gamma_draw_serial(alpha, beta, it, kStreamTau, k0, k1);
+}
+void launch_gamma_sample(double alpha, double beta, uint64_t seed, uint32_t it, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(gamma_sample_kernel, dim3(1), dim3(1), 0, st, alpha, beta, (uint32_t)seed, (uint32_t)(seed >> 32), it, out);
+}
+
+}  // namespace bnmtf

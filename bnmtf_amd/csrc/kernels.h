@@ -1,0 +1,101 @@
+// Kernel launch interface shared by api.hip and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bnmtf {
+
+// RNG stream ids (counter word 3, low 4 bits) -- same numbers as oracle/rng.py
+constexpr uint32_t kStreamRows = 0, kStreamCols = 1, kStreamS = 2, kStreamTau = 3, kStreamHook = 8;
+
+// ---------------------------------------------------------------------------
+// K1/K2: masked contraction  out[n][KP] = sum_inner big[inner][n] * X[inner][KP]
+//   big  : R~ shard stored so that the OUTPUT index is the contiguous one
+//          (rows step:  big[j][i] = R~[i][j];   cols step: big[i][j] = R~[i][j])
+//   X    : the other factor, row-major, padded rows are zero
+//   slabs: [split][n_pad][KP] partial sums, summed by the consumer (sweep prologue)
+// ---------------------------------------------------------------------------
+struct GemmArgs {
+  const float* big; int ld;          // leading dimension of big (= n_pad)
+  const float* X;                    // [inner_pad][KP]
+  float* slabs;                      // [split][n_pad][KP]
+  int n_pad, split, inner_per_wave;  // inner range of wave w in split s: [(s*4+w)*ipw, +ipw)
+};
+void launch_gemm(const GemmArgs& a, int KP, hipStream_t st);
+
+// ---------------------------------------------------------------------------
+// Gram: C[a][b] = sum_r X[r][a] X[r][b] (fp64 accumulate), colsum[a] = sum_r X[r][a]
+//   also for VB: colsum2[a] = sum_r S2[r][a] when S2 != nullptr
+// ---------------------------------------------------------------------------
+struct GramArgs {
+  const float* X; const float* S2; int rows, KP;
+  double* C64; float* C32; double* colsum; double* colsum2;
+};
+void launch_gram(const GramArgs& a, hipStream_t st);
+
+// ---------------------------------------------------------------------------
+// K3: sequential-k conditional update of one factor (one half sweep)
+// ---------------------------------------------------------------------------
+enum SweepMode { kSweepDraw = 0, kSweepMode = 1, kSweepVB = 2 };
+
+struct SweepArgs {
+  int n, n0;                 // local units, global index of the first
+  int K, KP;                 // true and padded width
+  int mode;                  // SweepMode
+  int cond_k;                // >= 0: only evaluate column cond_k, write numer/tau, change nothing
+  // numerators
+  const float* slabs; int split, n_pad;
+  const float* lambda;       // [n][KP] local
+  // own factor (global, row-major [*][KP]) and its transposed copy [KP][ldT]
+  float* Xself; float* XselfT; int ldT_self;
+  // other factor, transposed [KP][ldT_o]; index m_sentinel reads 0
+  const float* XoT; int ldT_o;
+  const float* C32;          // Gram of other factor [KP][KP]
+  // missing-entry slots (64 per unit row-step)
+  const uint32_t* slot_ptr; const uint32_t* idx; float* q;
+  // precision
+  const float* tau;          // device scalar
+  // RNG
+  uint32_t key0, key1, it, stream;
+  // outputs
+  double* acc;               // [0] += sum P.X', [1] += sum_miss q, [2] += sum_miss q^2 (may be null)
+  double* numer_out; double* tau_out;   // cond mode, length n
+  // VB extras (mode == kSweepVB)
+  float* mu_self; float* tau_self; float* var_self; float* S2self; float* S2selfT;
+  const float* S2oT; const double* colsum2_o;   // other's var+exp^2 (transposed) and its column sums
+};
+void launch_sweep(const SweepArgs& a, hipStream_t st);
+
+// ---------------------------------------------------------------------------
+// end of iteration: masked SSE from Gram identities, tau draw, metrics record
+// ---------------------------------------------------------------------------
+struct FinishArgs {
+  const double* Cr64; const double* Cc64; const double* sr; const double* sc; int KP;
+  const double* acc;          // [3]
+  double n_obs, sumR, sumR2;  // over the training mask
+  double alpha, beta;
+  int update;                 // 0 draw, 1 mode (tau = alpha_s/beta_s)
+  uint32_t key0, key1, it;
+  double* tau_d; float* tau_f;
+  double* rec;                // [5]: tau, MSE, R2, Rp, SSE  (slot of this iteration)
+};
+void launch_finish(const FinishArgs& a, hipStream_t st);
+
+// ---------------------------------------------------------------------------
+// direct masked metric sums in fp64 (predict / validation path)
+// ---------------------------------------------------------------------------
+struct MetricArgs {
+  const float* R; const uint8_t* Mp; int I, J;
+  const double* A; const double* B; int K;     // A [I][K], B [J][K]
+  double* out6;
+};
+void launch_metric_sums(const MetricArgs& a, hipStream_t st);
+
+// small helpers
+void launch_transpose(const float* X, int rows, int KP, float* XT, int ldT, hipStream_t st);
+void launch_tn_sample(const double* mu, const double* tau, size_t n, uint64_t seed, uint32_t it, uint32_t col,
+                      uint32_t elem0, double* out, hipStream_t st);
+void launch_tn_moments(const double* mu, const double* tau, size_t n, double* e, double* v, hipStream_t st);
+void launch_gamma_sample(double alpha, double beta, uint64_t seed, uint32_t it, double* out, hipStream_t st);
+
+}  // namespace bnmtf

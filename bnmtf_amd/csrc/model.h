@@ -1,0 +1,90 @@
+// Host-side model object behind the opaque bnmtf_handle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/bnmtf_hip.h"
+#include "kernels.h"
+
+namespace bnmtf {
+
+void set_error(const char* fmt, ...);
+
+#define HIPCHK(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      ::bnmtf::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return BNMTF_EHIP;                                                                      \
+    }                                                                                         \
+  } while (0)
+
+#define CHK(expr)                  \
+  do {                             \
+    int rc_ = (expr);              \
+    if (rc_ != BNMTF_OK) return rc_; \
+  } while (0)
+
+// One sweep direction: "rows" updates U / F (units = rows of R, inner = columns),
+// "cols" updates V / G.  Everything a half sweep touches lives here.
+struct Dir {
+  // geometry
+  int nglob = 0;        // units in the whole problem (I or J)
+  int n = 0, n0 = 0;    // this rank's units [n0, n0+n)
+  int m = 0;            // inner extent = nglob of the other direction
+  int W = 0, KP = 0;    // factor width (K or L) and its padding (32 / 64)
+  int n_pad = 0, split = 1, ipw = 0, inner_pad = 0;
+  // device data
+  float* big = nullptr;        // [inner_pad][n_pad]  masked R shard, output index contiguous
+  float* slabs = nullptr;      // [split][n_pad][KP]
+  float* lambda = nullptr;     // [n][KP]
+  uint32_t* slot_ptr = nullptr;
+  uint32_t* idx = nullptr;
+  float* q = nullptr;
+  size_t nslots = 0, nmiss = 0;
+  // this direction's factor, replicated on every rank
+  float* X = nullptr;  int xrows = 0;   // [xrows][KP] row major (GEMM A operand of the other direction)
+  float* XT = nullptr; int ldT = 0;     // [KP][ldT]  (gather source of the other direction)
+  double* C64 = nullptr; float* C32 = nullptr; double* colsum = nullptr;   // Gram of X
+  // VB only
+  float *mu = nullptr, *tauq = nullptr, *var = nullptr, *S2 = nullptr, *S2T = nullptr;
+  double* colsum2 = nullptr;
+  // cond-params scratch
+  double *numer = nullptr, *taup = nullptr;
+  std::vector<uint32_t> obs_count;      // host, all nglob units
+};
+
+struct Comm;   // RCCL wrapper (comm.cpp)
+
+}  // namespace bnmtf
+
+struct bnmtf_model {
+  int I = 0, J = 0, K = 0, L = 0;
+  double alpha = 0, beta = 0;
+  uint64_t seed = 0, iteration = 0;
+  int device = 0, rank = 0, world = 1;
+  hipStream_t stream = nullptr;
+  bnmtf::Dir rows, cols;
+  // full-matrix copies for predict()/validation
+  float* Rfull = nullptr; uint8_t* Mtrain = nullptr; uint8_t* Mscratch = nullptr;
+  double *Ad = nullptr, *Bd = nullptr, *out6 = nullptr;
+  // scalars
+  double n_obs = 0, sumR = 0, sumR2 = 0;
+  double* tau_d = nullptr; float* tau_f = nullptr;
+  double* acc = nullptr;     // [4]
+  double* rec = nullptr; size_t rec_cap = 0;
+  bool have_state = false;
+  // BNMTF extras
+  float* S = nullptr;            // [K][L] on device (row major, unpadded)
+  // profiling
+  bool profiling = false;
+  double kernel_ms[BNMTF_KERNEL_COUNT] = {0};
+  uint64_t kernel_launches[BNMTF_KERNEL_COUNT] = {0};
+  std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending_events;
+  std::vector<hipEvent_t> event_pool;
+  bnmtf::Comm* comm = nullptr;
+  std::string description;
+};

@@ -3,9 +3,9 @@
  * the Gibbs / VB inference hot path of ThomasBrouwer/BNMTF.
  *
  * The reference has no FFI layer: its boundary is the duck-typed Python class
- * contract of code/models/{bnmf_gibbs,bnmtf_gibbs,bnmf_vb}_optimised.py.  Each
- * entry point below names the reference method(s) it replaces (file:line,
- * relative to the reference checkout).  bnmtf_amd/*.py binds these with ctypes
+ * contract of code/models/ bnmf_gibbs_optimised.py, bnmtf_gibbs_optimised.py, bnmf_vb_optimised.py.
+ * Each entry point below names the reference method(s) it replaces (file:line,
+ * relative to the reference checkout).  The Python package bnmtf_amd binds these with ctypes
  * and reproduces the class surface; INTEGRATION.md shows the stub a reference
  * maintainer would add.
  *
