@@ -210,8 +210,9 @@ def test_large_shape_properties():
         np.testing.assert_allclose(b.tauV(k), tV, rtol=5e-6)
         sc = _mu_scale(o.M, o.R, o.U, o.V, o.tau, k, False) / tV
         assert (np.abs(b.muV(tV, k) - o.muV(tV, k)) <= 2e-5 * sc).all()
-    b.run(25)
+    b.run(150)
     mse = b.all_performances['MSE']
+    print('MSE trajectory', [round(float(m), 3) for m in mse[::10]])
     assert mse[0] > 10 * mse[-1] and 0.8 < mse[-1] < 1.3
     p = b.predict_while_running()
     assert abs(p["MSE"] - mse[-1]) < 5e-5 * mse[-1]
