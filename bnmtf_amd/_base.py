@@ -128,6 +128,10 @@ class DeviceModel(object):
     def set_profiling(self, enable=True):
         _lib.check(_lib.lib().bnmtf_set_profiling(self._handle(), int(bool(enable))))
 
+    def set_sweep_path(self, fast=True):
+        """fast=False forces the generic sweep kernel (test hook; results are the same)."""
+        _lib.check(_lib.lib().bnmtf_set_sweep_path(self._handle(), int(bool(fast))))
+
     def kernel_stats(self, kernel):
         ms = C.c_double(); n = C.c_uint64()
         _lib.check(_lib.lib().bnmtf_kernel_stats(self._handle(), int(kernel), C.byref(ms), C.byref(n)))

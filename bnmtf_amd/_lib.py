@@ -56,6 +56,7 @@ _SIGS = {
     "bnmtf_tn_moments": ([_P, _P, C.c_size_t, C.c_int, _P, _P], C.c_int),
     "bnmtf_gamma_sample": ([C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_double)], C.c_int),
     "bnmtf_set_profiling": ([_P, C.c_int], C.c_int),
+    "bnmtf_set_sweep_path": ([_P, C.c_int], C.c_int),
     "bnmtf_kernel_stats": ([_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)], C.c_int),
     "bnmtf_describe": ([_P, C.c_char_p, C.c_size_t], C.c_int),
 }

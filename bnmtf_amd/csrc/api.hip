@@ -75,6 +75,72 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
   }
   d.nslots = idx.size();
 
+  // fast layout: a unit owns a 32-lane half wave; lane r holds the entries with j mod 32 == r
+  // (bank-conflict-free LDS gathers), padded to the fullest residue class; units sorted by
+  // slot count so that the two halves of a wave and the waves of a block are balanced.
+  d.mz = round_up(m, 32);
+  d.pw = round_up(d.mz + 32, 256);
+  {
+    std::vector<std::vector<uint32_t>> res((size_t)d.n * 32);
+    std::vector<int> Eu(d.n, 0);
+    for (int ul = 0; ul < d.n; ++ul) {
+      for (uint32_t t = ptr[ul]; t < ptr[ul + 1]; ++t) {
+        const uint32_t j = idx[t];
+        if (j < (uint32_t)m) res[(size_t)ul * 32 + (j & 31)].push_back(j);
+      }
+      for (int r = 0; r < 32; ++r) Eu[ul] = std::max(Eu[ul], (int)res[(size_t)ul * 32 + r].size());
+    }
+    std::vector<int> order(d.n);
+    for (int i = 0; i < d.n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return Eu[x] > Eu[y]; });
+    d.f_npairs = (d.n + 1) / 2;
+    std::vector<int> umap((size_t)d.f_npairs * 2, -1);
+    std::vector<uint32_t> pE(d.f_npairs), pB(d.f_npairs);
+    size_t rows_total = 0;
+    d.f_emax = 0;
+    for (int pi = 0; pi < d.f_npairs; ++pi) {
+      int e = 0;
+      for (int hh = 0; hh < 2; ++hh) {
+        const int pos = 2 * pi + hh;
+        if (pos < d.n) { umap[pos] = order[pos]; e = std::max(e, Eu[order[pos]]); }
+      }
+      pE[pi] = (uint32_t)e; pB[pi] = (uint32_t)rows_total; rows_total += e;
+      d.f_emax = std::max(d.f_emax, e);
+    }
+    std::vector<uint32_t> off(std::max<size_t>(rows_total, 1) * 64);
+    for (int pi = 0; pi < d.f_npairs; ++pi)
+      for (int hh = 0; hh < 2; ++hh) {
+        const int ul = umap[2 * pi + hh];
+        for (uint32_t sidx = 0; sidx < pE[pi]; ++sidx)
+          for (int r = 0; r < 32; ++r) {
+            uint32_t v = (uint32_t)(d.mz + r);
+            if (ul >= 0) { const auto& lst = res[(size_t)ul * 32 + r]; if (sidx < lst.size()) v = lst[sidx]; }
+            off[((size_t)pB[pi] + sidx) * 64 + hh * 32 + r] = v;
+          }
+      }
+    d.f_slots = rows_total;
+    CHK(dalloc(&d.f_unit_map, umap.size(), false));
+    HIPCHK(hipMemcpy(d.f_unit_map, umap.data(), umap.size() * sizeof(int), hipMemcpyHostToDevice));
+    CHK(dalloc(&d.f_pair_E, pE.size(), false));
+    HIPCHK(hipMemcpy(d.f_pair_E, pE.data(), pE.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    CHK(dalloc(&d.f_pair_base, pB.size(), false));
+    HIPCHK(hipMemcpy(d.f_pair_base, pB.data(), pB.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    CHK(dalloc(&d.f_off, off.size(), false));
+    HIPCHK(hipMemcpy(d.f_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    // blocks (8 pairs) whose fullest pair exceeds kFastMaxSlots are left to the generic kernel
+    {
+      std::vector<int> gen;
+      for (int b0 = 0; b0 < d.f_npairs; b0 += 8)
+        if ((int)pE[b0] > kFastMaxSlots)
+          for (int t = 2 * b0; t < std::min(2 * (b0 + 8), 2 * d.f_npairs); ++t) if (umap[t] >= 0) gen.push_back(umap[t]);
+      d.f_gen_count = (int)gen.size();
+      CHK(dalloc(&d.f_gen_units, std::max<size_t>(gen.size(), 1), false));
+      if (!gen.empty()) HIPCHK(hipMemcpy(d.f_gen_units, gen.data(), gen.size() * sizeof(int), hipMemcpyHostToDevice));
+      d.stats_blocks = std::max((d.f_npairs + 7) / 8, 1);
+    }
+    CHK(dalloc(&d.stats, (size_t)d.stats_blocks * 4));
+  }
+
   CHK(dalloc(&d.big, big.size(), false));
   HIPCHK(hipMemcpy(d.big, big.data(), big.size() * sizeof(float), hipMemcpyHostToDevice));
   CHK(dalloc(&d.slabs, (size_t)d.split * d.n_pad * d.KP));
@@ -99,15 +165,22 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
 
 static int alloc_factor(Dir& d, int other_inner_pad) {
   d.xrows = std::max(d.nglob + 1, other_inner_pad);
-  d.ldT = round_up(d.nglob + 1, 64);
+  d.ldT = round_up(round_up(d.nglob, 32) + 32, 256);   // = the other direction's panel size pw; zero beyond nglob
   CHK(dalloc(&d.X, (size_t)d.xrows * d.KP));
   CHK(dalloc(&d.XT, (size_t)d.KP * d.ldT));
+  CHK(dalloc(&d.XT2, (size_t)d.KP * d.ldT));
+  const int nb = post_blocks(d.nglob);
+  CHK(dalloc(&d.Cpart, (size_t)nb * d.KP * d.KP));
+  CHK(dalloc(&d.spart, (size_t)nb * d.KP));
+  CHK(dalloc(&d.s2part, (size_t)nb * d.KP));
   return BNMTF_OK;
 }
 
 static void free_dir(Dir& d) {
   dfree(d.big); dfree(d.slabs); dfree(d.lambda); dfree(d.slot_ptr); dfree(d.idx); dfree(d.q);
   dfree(d.X); dfree(d.XT); dfree(d.C64); dfree(d.C32); dfree(d.colsum); dfree(d.colsum2);
+  dfree(d.XT2); dfree(d.Cpart); dfree(d.spart); dfree(d.s2part); dfree(d.f_unit_map); dfree(d.f_pair_E);
+  dfree(d.f_pair_base); dfree(d.f_off); dfree(d.stats); dfree(d.f_gen_units);
   dfree(d.mu); dfree(d.tauq); dfree(d.var); dfree(d.S2); dfree(d.S2T); dfree(d.numer); dfree(d.taup);
 }
 
@@ -152,18 +225,40 @@ static void enqueue_gemm(bnmtf_model* h, Dir& d, const Dir& other, int kid) {
   g.n_pad = d.n_pad; g.split = d.split; g.inner_per_wave = d.ipw;
   launch_gemm(g, d.KP, h->stream);
 }
-static void enqueue_gram(bnmtf_model* h, Dir& d, bool vb = false) {
-  GramArgs g;
-  g.X = d.X; g.S2 = vb ? d.S2 : nullptr; g.rows = d.nglob; g.KP = d.KP;
-  g.C64 = d.C64; g.C32 = d.C32; g.colsum = d.colsum; g.colsum2 = vb ? d.colsum2 : nullptr;
-  launch_gram(g, h->stream);
+// relayout (XT, XT2) + Gram of a factor that was just written
+static void enqueue_post(bnmtf_model* h, Dir& d, bool vb = false) {
+  PostArgs g;
+  memset(&g, 0, sizeof(g));
+  g.X = d.X; g.rows = d.nglob; g.KP = d.KP; g.XT = d.XT; g.ldT = d.ldT; g.XT2 = d.XT2; g.ld2 = d.ldT;
+  g.Cpart = d.Cpart; g.spart = d.spart; g.C64 = d.C64; g.C32 = d.C32; g.colsum = d.colsum;
+  if (vb) { g.S2 = d.S2; g.S2T = d.S2T; g.s2part = d.s2part; g.colsum2 = d.colsum2; }
+  launch_post(g, h->stream);
+}
+static void enqueue_sweep(bnmtf_model* h, Dir& d, const Dir& other, SweepArgs& s, bool want_stats) {
+  s.unit_list = nullptr;
+  h->last_sweep_fast = false;
+  if (h->use_fast && s.cond_k < 0 && s.mode != kSweepVB && sweep_fast_supported(d.KP, d.pw)) {
+    FastArgs f;
+    f.unit_map = d.f_unit_map; f.pair_E = d.f_pair_E; f.pair_base = d.f_pair_base; f.off = d.f_off;
+    f.npairs = d.f_npairs; f.mz = d.mz; f.pw = d.pw;
+    f.XoT = other.XT; f.ldT_o = other.ldT; f.XoT2 = other.XT2; f.ld2_o = other.ldT;
+    f.stats = want_stats ? d.stats : nullptr;
+    SweepArgs s2 = s;
+    s2.acc = nullptr;
+    launch_sweep_fast(s2, f, h->stream);
+    h->last_sweep_fast = true;
+    if (d.f_gen_count == 0) return;
+    s.unit_list = d.f_gen_units;           // the few units with more than kFastMaxSlots slots per lane
+    s.n = d.f_gen_count;
+  }
+  launch_sweep(s, h->stream);
 }
 static SweepArgs sweep_args(bnmtf_model* h, Dir& d, const Dir& other, int mode, uint32_t stream_id) {
   SweepArgs s;
   memset(&s, 0, sizeof(s));
   s.n = d.n; s.n0 = d.n0; s.K = d.W; s.KP = d.KP; s.mode = mode; s.cond_k = -1;
   s.slabs = d.slabs; s.split = d.split; s.n_pad = d.n_pad; s.lambda = d.lambda;
-  s.Xself = d.X; s.XselfT = d.XT; s.ldT_self = d.ldT;
+  s.Xself = d.X; s.XselfT = nullptr; s.ldT_self = d.ldT;
   s.XoT = other.XT; s.ldT_o = other.ldT; s.C32 = other.C32;
   s.slot_ptr = d.slot_ptr; s.idx = d.idx; s.q = d.q;
   s.tau = h->tau_f;
@@ -181,7 +276,7 @@ static int upload_factor(bnmtf_model* h, Dir& d, const double* src) {
     for (int k = 0; k < d.W; ++k) tmp[(size_t)r * d.KP + k] = (float)src[(size_t)r * d.W + k];
   HIPCHK(hipMemcpyAsync(d.X, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  launch_transpose(d.X, d.nglob, d.KP, d.XT, d.ldT, h->stream);
+  enqueue_post(h, d);
   return BNMTF_OK;
 }
 static int download_matrix(bnmtf_model* h, const float* dev, int rows, int W, int KP, double* dst) {
@@ -339,6 +434,7 @@ int bnmtf_set_profiling(bnmtf_handle h, int enable) {
   for (int i = 0; i < BNMTF_KERNEL_COUNT; ++i) { h->kernel_ms[i] = 0; h->kernel_launches[i] = 0; }
   return BNMTF_OK;
 }
+int bnmtf_set_sweep_path(bnmtf_handle h, int fast) { h->use_fast = fast != 0; return BNMTF_OK; }
 int bnmtf_kernel_stats(bnmtf_handle h, int kernel, double* total_ms, uint64_t* launches) {
   if (kernel < 0 || kernel >= BNMTF_KERNEL_COUNT) { set_error("bad kernel id"); return BNMTF_EINVAL; }
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -357,8 +453,6 @@ int bnmf_set_state(bnmtf_handle h, const double* U, const double* V, double tau)
   HIPCHK(hipSetDevice(h->device));
   CHK(upload_factor(h, h->rows, U));
   CHK(upload_factor(h, h->cols, V));
-  enqueue_gram(h, h->rows);
-  enqueue_gram(h, h->cols);
   CHK(set_tau(h, tau));
   h->have_state = true;
   return BNMTF_OK;
@@ -386,7 +480,7 @@ int bnmf_cond_params(bnmtf_handle h, int which, int k, double* numer_out, double
   enqueue_gemm(h, d, o, which == 0 ? BNMTF_KERNEL_GEMM_ROWS : BNMTF_KERNEL_GEMM_COLS);
   SweepArgs s = sweep_args(h, d, o, kSweepDraw, which == 0 ? kStreamRows : kStreamCols);
   s.cond_k = k;
-  launch_sweep(s, h->stream);
+  enqueue_sweep(h, d, o, s, false);
   HIPCHK(hipMemcpyAsync(numer_out, d.numer, sizeof(double) * d.n, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipMemcpyAsync(tau_out, d.taup, sizeof(double) * d.n, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -414,10 +508,10 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
     {
       ScopedKernelTimer t(h, BNMTF_KERNEL_SWEEP_ROWS);
       SweepArgs s = sweep_args(h, r, c, mode, kStreamRows);
-      launch_sweep(s, h->stream);
+      enqueue_sweep(h, r, c, s, false);
     }
-    if (h->comm) CHK(comm_allgather_factor(h->comm, r.X, r.KP, r.nglob, h->world, h->stream, r.XT, r.ldT));
-    enqueue_gram(h, r);
+    if (h->comm) CHK(comm_allgather_factor(h->comm, r.X, r.KP, r.nglob, h->world, h->stream));
+    enqueue_post(h, r);
     // ---- V columns: Pv = R~^T . U
     enqueue_gemm(h, c, r, BNMTF_KERNEL_GEMM_COLS);
     HIPCHK(hipMemsetAsync(h->acc, 0, 4 * sizeof(double), h->stream));
@@ -425,17 +519,20 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
       ScopedKernelTimer t(h, BNMTF_KERNEL_SWEEP_COLS);
       SweepArgs s = sweep_args(h, c, r, mode, kStreamCols);
       s.acc = h->acc;
-      launch_sweep(s, h->stream);
+      enqueue_sweep(h, c, r, s, true);
     }
+    const bool fast_stats = h->last_sweep_fast;
     if (h->comm) {
-      CHK(comm_allgather_factor(h->comm, c.X, c.KP, c.nglob, h->world, h->stream, c.XT, c.ldT));
+      CHK(comm_allgather_factor(h->comm, c.X, c.KP, c.nglob, h->world, h->stream));
+      if (fast_stats) launch_sum_stats(c.stats, c.stats_blocks, h->acc, h->stream);   // fold the slab before the exchange
       CHK(comm_allreduce_sum(h->comm, h->acc, 4, h->stream));
     }
-    enqueue_gram(h, c);
+    enqueue_post(h, c);
     // ---- tau and the metrics of this sample
     FinishArgs f;
     f.Cr64 = r.C64; f.Cc64 = c.C64; f.sr = r.colsum; f.sc = c.colsum; f.KP = r.KP;
-    f.acc = h->acc; f.n_obs = h->n_obs; f.sumR = h->sumR; f.sumR2 = h->sumR2;
+    f.acc = h->acc; f.stats = (fast_stats && !h->comm) ? c.stats : nullptr; f.nstats = (fast_stats && !h->comm) ? c.stats_blocks : 0;
+    f.n_obs = h->n_obs; f.sumR = h->sumR; f.sumR2 = h->sumR2;
     f.alpha = h->alpha; f.beta = h->beta; f.update = update;
     f.key0 = (uint32_t)h->seed; f.key1 = (uint32_t)(h->seed >> 32); f.it = (uint32_t)h->iteration;
     f.tau_d = h->tau_d; f.tau_f = h->tau_f; f.rec = h->rec + (size_t)it * 5;

@@ -12,7 +12,7 @@ int comm_unique_id(uint8_t out[128]);
 int comm_create(Comm** out, const uint8_t id[128], int rank, int world, hipStream_t st);
 void comm_destroy(Comm* c);
 // gather every rank's freshly drawn block of X ([nglob][KP], rank r owns rows
-// [nglob*r/world, nglob*(r+1)/world)) in place, then rebuild the transposed copy.
-int comm_allgather_factor(Comm* c, float* X, int KP, int nglob, int world, hipStream_t st, float* XT, int ldT);
+// [nglob*r/world, nglob*(r+1)/world)) in place (the caller re-lays it out afterwards).
+int comm_allgather_factor(Comm* c, float* X, int KP, int nglob, int world, hipStream_t st);
 int comm_allreduce_sum(Comm* c, double* buf, int count, hipStream_t st);
 }  // namespace bnmtf

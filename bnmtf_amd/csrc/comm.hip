@@ -99,7 +99,7 @@ void comm_destroy(Comm* c) {
   delete c;
 }
 
-int comm_allgather_factor(Comm* c, float* X, int KP, int nglob, int world, hipStream_t st, float* XT, int ldT) {
+int comm_allgather_factor(Comm* c, float* X, int KP, int nglob, int world, hipStream_t st) {
   auto first = [&](int r) { return (int)(((int64_t)nglob * r) / world); };
   if (nglob % world == 0) {
     const size_t cnt = (size_t)(nglob / world) * KP;
@@ -113,7 +113,6 @@ int comm_allgather_factor(Comm* c, float* X, int KP, int nglob, int world, hipSt
     }
     NCHK(g_api.GroupEnd());
   }
-  launch_transpose(X, nglob, KP, XT, ldT, st);
   return BNMTF_OK;
 }
 

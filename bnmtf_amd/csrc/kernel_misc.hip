@@ -69,7 +69,10 @@ __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
     const double dot = red[0];
     double sp1 = 0.0;
     for (int t = 0; t < KP; ++t) sp1 = fma(a.sr[t], a.sc[t], sp1);
-    const double srp = a.acc[0], sp = sp1 - a.acc[1], spp = dot - a.acc[2];
+    double acc[3] = {a.acc[0], a.acc[1], a.acc[2]};
+    for (int b = 0; b < a.nstats; ++b)
+      for (int t = 0; t < 3; ++t) acc[t] += a.stats[(size_t)b * 4 + t];
+    const double srp = acc[0], sp = sp1 - acc[1], spp = dot - acc[2];
     const double n = a.n_obs;
     const double sse = a.sumR2 - 2.0 * srp + spp;
     const double alpha_s = a.alpha + 0.5 * n, beta_s = a.beta + 0.5 * sse;
@@ -131,6 +134,18 @@ void launch_metric_sums(const MetricArgs& a, hipStream_t st) {
   (void)hipMemsetAsync(a.out6, 0, 6 * sizeof(double), st);
   dim3 grid((a.J + 31) / 32, (a.I + 31) / 32), block(32, 8);
   hipLaunchKernelGGL(metric_kernel, grid, block, 0, st, a);
+}
+
+__global__ void sum_stats_kernel(const double* stats, int nblocks, double* acc) {
+  const int t = threadIdx.x;
+  if (t < 3) {
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += stats[(size_t)b * 4 + t];
+    acc[t] += s;
+  }
+}
+void launch_sum_stats(const double* stats, int nblocks, double* acc, hipStream_t st) {
+  hipLaunchKernelGGL(sum_stats_kernel, dim3(1), dim3(64), 0, st, stats, nblocks, acc);
 }
 
 // ---------------------------------------------------------------------------

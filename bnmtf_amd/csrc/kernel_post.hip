@@ -1,0 +1,96 @@
+// After a half sweep (or a state upload) the freshly written factor X [rows][KP] is
+// re-laid out for its two consumers and its Gram matrix is formed:
+//   XT  [KP][ldT]        column k contiguous      -> LDS panel of the other direction's sweep
+//   XT2 [KP/2][ld2][2]   column pairs interleaved -> pre-pass panels (ds_read_b64)
+//   C = X^T X (fp64), column sums                 -> sweep (fp32 copy) and the SSE identity
+// One pass over X: 128 rows per block staged in LDS; per-block Gram partials go to a
+// slab and are summed by gram_reduce_kernel (deterministic, no atomics).
+#include "kernels.h"
+
+namespace bnmtf {
+
+__global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
+  __shared__ float tile[128 * 68];
+  constexpr int LD = 68;
+  const int KP = a.KP, tid = threadIdx.x;
+  const int r0 = blockIdx.x * 128;
+  const int nr = min(128, a.rows - r0);
+  const float* src = a.X;
+  for (int pass = 0; pass < (a.S2 ? 2 : 1); ++pass) {
+    if (pass == 1) { __syncthreads(); src = a.S2; }
+    for (int t = tid; t < 128 * KP; t += 256) {
+      const int r = t / KP, k = t % KP;
+      tile[r * LD + k] = (r < nr) ? src[(size_t)(r0 + r) * KP + k] : 0.f;
+    }
+    __syncthreads();
+    float* T1 = pass == 0 ? a.XT : a.S2T;
+    if (T1)
+      for (int t = tid; t < 128 * KP; t += 256) {
+        const int k = t >> 7, r = t & 127;
+        if (r < nr) T1[(size_t)k * a.ldT + r0 + r] = tile[r * LD + k];
+      }
+    if (pass == 0 && a.XT2)
+      for (int t = tid; t < 128 * KP; t += 256) {
+        const int kp = t >> 8, rem = t & 255, r = rem >> 1, c = rem & 1;
+        if (r < nr) a.XT2[((size_t)kp * a.ld2 + r0 + r) * 2 + c] = tile[r * LD + 2 * kp + c];
+      }
+    if (pass == 0) {
+      const int ty = tid >> 4, tx = tid & 15;
+      if (4 * ty < KP && 4 * tx < KP) {
+        double acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+        for (int r = 0; r < nr; ++r) {
+          const float4 av = *reinterpret_cast<const float4*>(&tile[r * LD + 4 * ty]);
+          const float4 bv = *reinterpret_cast<const float4*>(&tile[r * LD + 4 * tx]);
+          const double ad[4] = {av.x, av.y, av.z, av.w}, bd[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = fma(ad[i], bd[j], acc[i][j]);
+        }
+        double* out = a.Cpart + (size_t)blockIdx.x * KP * KP;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) out[(4 * ty + i) * KP + 4 * tx + j] = acc[i][j];
+      }
+    }
+    if (tid < KP) {
+      double s = 0.0;
+      for (int r = 0; r < nr; ++r) s += (double)tile[r * LD + tid];
+      (pass == 0 ? a.spart : a.s2part)[(size_t)blockIdx.x * KP + tid] = s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gram_reduce_kernel(PostArgs a, int nblk) {
+  const int KP = a.KP;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < KP * KP) {
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += a.Cpart[(size_t)b * KP * KP + t];
+    a.C64[t] = s;
+    a.C32[t] = (float)s;
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x < KP) {
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += a.spart[(size_t)b * KP + threadIdx.x];
+    a.colsum[threadIdx.x] = s;
+    if (a.S2) {
+      double s2 = 0.0;
+      for (int b = 0; b < nblk; ++b) s2 += a.s2part[(size_t)b * KP + threadIdx.x];
+      a.colsum2[threadIdx.x] = s2;
+    }
+  }
+}
+
+void launch_post(const PostArgs& a, hipStream_t st) {
+  const int nblk = post_blocks(a.rows);
+  hipLaunchKernelGGL(post_kernel, dim3(nblk), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3((a.KP * a.KP + 255) / 256), dim3(256), 0, st, a, nblk);
+}
+
+}  // namespace bnmtf

@@ -34,8 +34,9 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 template <int MODE>
 __global__ __launch_bounds__(256) void sweep_generic_kernel(SweepArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int u = blockIdx.x * 4 + wave;
-  if (u >= a.n) return;
+  const int ui = blockIdx.x * 4 + wave;
+  if (ui >= a.n) return;
+  const int u = a.unit_list ? a.unit_list[ui] : ui;
   const int KP = a.KP, K = a.K;
   const size_t gi = (size_t)a.n0 + u;
 
@@ -117,12 +118,10 @@ __global__ __launch_bounds__(256) void sweep_generic_kernel(SweepArgs a) {
 
   if (lane < K) {
     a.Xself[gi * KP + lane] = x;
-    a.XselfT[(size_t)lane * a.ldT_self + gi] = x;
     if (MODE == kSweepVB) {
       a.mu_self[gi * KP + lane] = mu_l; a.tau_self[gi * KP + lane] = tau_l; a.var_self[gi * KP + lane] = var_l;
       const float s2 = var_l + x * x;
       a.S2self[gi * KP + lane] = s2;
-      a.S2selfT[(size_t)lane * a.ldT_self + gi] = s2;
     }
   }
   if (a.acc) {

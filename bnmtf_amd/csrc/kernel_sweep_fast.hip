@@ -1,0 +1,279 @@
+// K3 fast path: the half sweep of kernel_sweep.hip with everything that is touched
+// K times per row kept on chip.
+//
+//  * a unit (row of the factor being updated) owns one 32-lane half wave; its missing
+//    entries sit in "slots": slot s of lane l holds an entry whose inner index j has
+//    j mod 32 == l, so a ds_read_b32 gather of the other factor's column k from LDS is
+//    bank-conflict free by construction (each half wave hits 32 distinct banks;
+//    sentinel slots read a per-lane zero word).  The price is padding to the fullest
+//    residue class (max_r cnt_r slots instead of cnt/32).
+//  * q_ij (= U_i . V_j on the missing entries), the slot addresses and the previous
+//    column's gathered values live in registers (EM slots per lane, template).
+//  * the other factor's column k ("panel", m floats) is staged in LDS once per block and
+//    k, double buffered; 16 units (8 waves) share it.  C = V^T V sits in LDS too.
+//  * q is rebuilt each sweep by a pre-pass over pair panels (ds_read_b64: two columns per
+//    gather, same conflict-free slots), which is what makes the kernel independent of
+//    how the other direction ordered its entries (and of the GPU count).
+//  * the K draws per unit are sequential, so the Philox work is hoisted: lane l
+//    pre-computes the first two candidates of columns l and l+32; step k broadcasts them.
+//    Only a double rejection (rare) falls back to 32 fresh candidates per round.
+#include "kernels.h"
+#include "device_rng.h"
+
+namespace bnmtf {
+
+__device__ __forceinline__ float dpp_xor_row_sum(float v) {   // all-reduce inside each 16-lane row
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
+__device__ __forceinline__ float half_sum(float v) {          // all-reduce inside each 32-lane half
+  v = dpp_xor_row_sum(v);
+  v += __shfl_xor(v, 16, 64);
+  return v;
+}
+__device__ __forceinline__ double half_sum_d(double v) {
+#pragma unroll
+  for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+// value held by lane (half*32 + src) for every lane of that half
+__device__ __forceinline__ float half_bcast(float v, int src, int half) {
+  const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+  const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src + 32));
+  return half ? a1 : a0;
+}
+__device__ __forceinline__ uint32_t half_bcast_u(uint32_t v, int src, int half) {
+  const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)v, src);
+  const uint32_t a1 = (uint32_t)__builtin_amdgcn_readlane((int)v, src + 32);
+  return half ? a1 : a0;
+}
+
+// candidate value / acceptance from two raw 32-bit words (no Philox here)
+__device__ __forceinline__ bool tn_eval(const TnParams& p, uint32_t r0, uint32_t r1, float* x) {
+  const float u1 = u24(r0), u2 = u24(r1);
+  const float nl = -__logf(u1);
+  const float e = nl / p.lam;
+  const float t = e - p.d;
+  const bool acc_t = u2 <= __expf(-0.5f * t * t);
+  const float z = sqrtf(2.0f * nl) * __cosf(kTwoPi * u2);
+  const bool acc_n = z >= p.a;
+  *x = p.tail ? e / p.rt : p.mu + z / p.rt;
+  return p.tail ? acc_t : acc_n;
+}
+
+// LDS-direct staging of one panel: `chunks` pieces of 1 KiB (64 lanes x 16 B), wave w takes
+// chunks w, w+8, ...  No VGPRs, no ds_write; completion is covered by the vmcnt(0) that
+// __syncthreads() carries while an LDS-DMA is in flight.
+__device__ __forceinline__ void stage_panel(const float* src, float* dst, int chunks, int wave, int lane) {
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  for (int c = wave; c < chunks; c += 8) {
+    __builtin_amdgcn_global_load_lds(src + (size_t)c * 256 + lane * 4, (lds_ptr)(dst + (size_t)c * 256), 16, 0, 0);
+  }
+}
+
+template <int EM, int NX, int MODE>
+__device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastArgs& f, float* lds) {
+  constexpr int KP = NX * 32;
+  const int PW = f.pw;                      // floats per single-column panel (multiple of 256)
+  float* Cs = lds;                          // [KP][KP]
+  float* pan = lds + KP * KP;               // main loop: 2 x PW ; pre-pass: 2 x 2*PW
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l5 = lane & 31;
+  const int pair = blockIdx.x * 8 + wave;
+  const bool wave_on = pair < f.npairs;
+  const uint32_t base = wave_on ? f.pair_base[pair] : 0u;
+  const int E = wave_on ? (int)f.pair_E[pair] : 0;
+  const int u = wave_on ? f.unit_map[2 * pair + half] : -1;
+  const bool valid = u >= 0;
+  const size_t gi = (size_t)a.n0 + (valid ? u : 0);
+  const int K = a.K;
+
+  float x[NX], p[NX], lam[NX];
+#pragma unroll
+  for (int nx = 0; nx < NX; ++nx) {
+    const int kk = l5 + 32 * nx;
+    x[nx] = 0.f; p[nx] = 0.f; lam[nx] = 0.f;
+    if (valid) {
+      x[nx] = a.Xself[gi * KP + kk];
+      for (int s = 0; s < a.split; ++s) p[nx] += a.slabs[((size_t)s * a.n_pad + u) * KP + kk];
+      lam[nx] = a.lambda[(size_t)u * KP + kk];
+    }
+  }
+  uint32_t off[EM];
+  float q[EM], vp[EM];
+#pragma unroll
+  for (int s = 0; s < EM; ++s) {
+    off[s] = (s < E) ? f.off[((size_t)base + s) * 64 + lane] : (uint32_t)(f.mz + l5);   // sentinel: a zero word on bank l5
+    q[s] = 0.f; vp[s] = 0.f;
+  }
+  for (int t = tid; t < KP * KP; t += 512) Cs[t] = a.C32[t];
+
+  // hoisted Philox: candidates 0 and 1 of columns l5 (+32)
+  uint32_t c0a[NX], c0b[NX], c1a[NX], c1b[NX];
+  if (MODE == kSweepDraw) {
+#pragma unroll
+    for (int nx = 0; nx < NX; ++nx) {
+      const uint32_t kk = (uint32_t)(l5 + 32 * nx);
+      const U4 r0 = philox4x32_10((uint32_t)gi, kk, a.it, a.stream, a.key0, a.key1);
+      const U4 r1 = philox4x32_10((uint32_t)gi, kk, a.it, a.stream + 16u, a.key0, a.key1);
+      c0a[nx] = r0.x; c0b[nx] = r0.y; c1a[nx] = r1.x; c1b[nx] = r1.y;
+    }
+  }
+
+  // ------------------------------------------------------------ pre-pass: q = U_i . V_j
+  {
+    const int chunks2 = (2 * PW) / 256;
+    const size_t stride = (size_t)f.ld2_o * 2;
+    stage_panel(f.XoT2, pan, chunks2, wave, lane);
+    __syncthreads();
+    const int npair = KP / 2;
+    for (int kp = 0; kp < npair; ++kp) {
+      if (kp + 1 < npair) stage_panel(f.XoT2 + (size_t)(kp + 1) * stride, pan + (size_t)((kp + 1) & 1) * 2 * PW, chunks2, wave, lane);
+      const float2* cur = reinterpret_cast<const float2*>(pan + (size_t)(kp & 1) * 2 * PW);
+      const int k0 = 2 * kp, k1 = 2 * kp + 1;
+      const float xs0 = (NX == 2 && k0 >= 32) ? x[NX - 1] : x[0];
+      const float x0 = half_bcast(xs0, k0 & 31, half), x1 = half_bcast(xs0, k1 & 31, half);
+#pragma unroll
+      for (int s = 0; s < EM; ++s) {
+        const float2 v = cur[off[s]];
+        q[s] = fmaf(x0, v.x, fmaf(x1, v.y, q[s]));
+      }
+      __syncthreads();
+    }
+  }
+
+  // ------------------------------------------------------------ the K sequential columns
+  const int chunks1 = PW / 256;
+  stage_panel(f.XoT, pan, chunks1, wave, lane);
+  __syncthreads();
+  const float tau = *a.tau;
+  float dprev = 0.f;
+  for (int k = 0; k < K; ++k) {
+    if (k + 1 < K) stage_panel(f.XoT + (size_t)(k + 1) * f.ldT_o, pan + (size_t)((k + 1) & 1) * PW, chunks1, wave, lane);
+    const float* cur = pan + (size_t)(k & 1) * PW;
+    const float xsel = (NX == 2 && k >= 32) ? x[NX - 1] : x[0];
+    const float xk = half_bcast(xsel, k & 31, half);
+    float corr[4] = {0.f, 0.f, 0.f, 0.f}, asq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < EM; ++s) {
+      const float v = cur[off[s]];
+      const float qs = fmaf(dprev, vp[s], q[s]);      // column k-1's update, applied late
+      const float t = fmaf(-xk, v, qs);
+      corr[s & 3] = fmaf(t, v, corr[s & 3]);
+      asq[s & 3] = fmaf(v, v, asq[s & 3]);
+      q[s] = qs; vp[s] = v;
+    }
+    float corr_t = (corr[0] + corr[1]) + (corr[2] + corr[3]);
+    float asq_t = (asq[0] + asq[1]) + (asq[2] + asq[3]);
+#pragma unroll
+    for (int nx = 0; nx < NX; ++nx) {
+      const int kk = l5 + 32 * nx;
+      if (kk != k) corr_t = fmaf(-x[nx], Cs[k * KP + kk], corr_t);
+    }
+    corr_t = half_sum(corr_t);
+    asq_t = half_sum(asq_t);
+    const float ckk = Cs[k * KP + k];
+    const float psel = (NX == 2 && k >= 32) ? p[NX - 1] : p[0];
+    const float lsel = (NX == 2 && k >= 32) ? lam[NX - 1] : lam[0];
+    const float num = half_bcast(psel, k & 31, half) + corr_t;
+    const float tau_p = tau * (ckk - asq_t);
+    const float numer = fmaf(tau, num, -half_bcast(lsel, k & 31, half));
+    const float mu = numer / tau_p;
+    float xnew = 0.f;
+    if (MODE == kSweepDraw) {
+      const TnParams tp = tn_params(mu, tau_p);
+      const uint32_t sa = (NX == 2 && k >= 32) ? c0a[NX - 1] : c0a[0], sb = (NX == 2 && k >= 32) ? c0b[NX - 1] : c0b[0];
+      float xc;
+      bool acc = tn_eval(tp, half_bcast_u(sa, k & 31, half), half_bcast_u(sb, k & 31, half), &xc);
+      bool done = !tp.live || !valid || acc;
+      xnew = (tp.live && valid && acc) ? tn_guard(xc) : 0.f;
+      if (__ballot(!done)) {                                   // candidate 1 (pre-computed)
+        const uint32_t ta = (NX == 2 && k >= 32) ? c1a[NX - 1] : c1a[0], tb = (NX == 2 && k >= 32) ? c1b[NX - 1] : c1b[0];
+        acc = tn_eval(tp, half_bcast_u(ta, k & 31, half), half_bcast_u(tb, k & 31, half), &xc);
+        if (!done && acc) { xnew = tn_guard(xc); done = true; }
+        for (uint32_t round = 0; round < 128u && __ballot(!done); ++round) {   // candidates 2.. : 32 per round
+          float xr;
+          const bool ar = tn_candidate(tp, (uint32_t)gi, (uint32_t)k, a.it, a.stream, 2u + round * 32u + (uint32_t)l5,
+                                       a.key0, a.key1, &xr);
+          const unsigned long long m = __ballot(ar);
+          const uint32_t mh = half ? (uint32_t)(m >> 32) : (uint32_t)m;
+          const int first = mh ? __ffs((int)mh) - 1 : 0;
+          const float xf = __shfl(xr, half * 32 + first, 64);
+          if (!done && mh) { xnew = tn_guard(xf); done = true; }
+        }
+      }
+    } else {
+      xnew = (valid && tau_p > 0.f && mu > 0.f) ? mu : 0.f;
+    }
+    dprev = xnew - xk;
+#pragma unroll
+    for (int nx = 0; nx < NX; ++nx)
+      if (l5 + 32 * nx == k) x[nx] = xnew;
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------ results
+#pragma unroll
+  for (int nx = 0; nx < NX; ++nx) {
+    const int kk = l5 + 32 * nx;
+    if (valid && kk < K) a.Xself[gi * KP + kk] = x[nx];
+  }
+  if (f.stats) {                      // per-block partial sums -> slab, summed by finish_kernel
+    double px = 0.0, sq = 0.0, sq2 = 0.0;
+#pragma unroll
+    for (int nx = 0; nx < NX; ++nx) px += (double)p[nx] * (double)x[nx];
+#pragma unroll
+    for (int s = 0; s < EM; ++s) { const double qv = (double)fmaf(dprev, vp[s], q[s]); sq += qv; sq2 += qv * qv; }
+    px = half_sum_d(px); sq = half_sum_d(sq); sq2 = half_sum_d(sq2);
+    double* red = reinterpret_cast<double*>(pan);      // panels are dead: reuse
+    if (l5 == 0) { red[(wave * 2 + half) * 3 + 0] = valid ? px : 0.0; red[(wave * 2 + half) * 3 + 1] = sq; red[(wave * 2 + half) * 3 + 2] = sq2; }
+    __syncthreads();
+    if (tid < 3) {
+      double s = 0.0;
+      for (int w = 0; w < 16; ++w) s += red[w * 3 + tid];
+      f.stats[(size_t)blockIdx.x * 4 + tid] = s;
+    }
+  }
+}
+
+// One launch covers every block; a block's slot class (template EM) is the smallest class that
+// holds its fullest pair (units are sorted by slot count, so blocks are homogeneous).
+template <int NX, int MODE>
+__global__ __launch_bounds__(512, 2) void sweep_fast_kernel(SweepArgs a, FastArgs f) {
+  extern __shared__ float lds[];
+  const int e0 = (int)f.pair_E[blockIdx.x * 8];      // descending order: first pair of the block is its fullest
+  if (e0 <= 8) sweep_fast_body<8, NX, MODE>(a, f, lds);
+  else if (e0 <= 16) sweep_fast_body<16, NX, MODE>(a, f, lds);
+  else if (e0 <= 24) sweep_fast_body<24, NX, MODE>(a, f, lds);
+  else if (e0 <= 32) sweep_fast_body<32, NX, MODE>(a, f, lds);
+  else if (e0 <= 40) sweep_fast_body<40, NX, MODE>(a, f, lds);
+  else if (e0 <= 48) sweep_fast_body<48, NX, MODE>(a, f, lds);
+  else if (e0 <= kFastMaxSlots) sweep_fast_body<kFastMaxSlots, NX, MODE>(a, f, lds);
+  else if (f.stats && threadIdx.x < 3) f.stats[(size_t)blockIdx.x * 4 + threadIdx.x] = 0.0;   // generic kernel owns these units
+}
+
+size_t sweep_fast_lds_bytes(int KP, int pw) { return sizeof(float) * ((size_t)KP * KP + 4 * (size_t)pw); }
+
+bool sweep_fast_supported(int KP, int pw) { return sweep_fast_lds_bytes(KP, pw) <= 160 * 1024; }
+
+template <int NX, int MODE>
+static void launch_inst(const SweepArgs& a, const FastArgs& f, dim3 grid, size_t lds_bytes, hipStream_t st) {
+  static bool once = false;
+  if (!once) { (void)hipFuncSetAttribute((const void*)sweep_fast_kernel<NX, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+  hipLaunchKernelGGL((sweep_fast_kernel<NX, MODE>), grid, dim3(512), lds_bytes, st, a, f);
+}
+
+void launch_sweep_fast(const SweepArgs& a, const FastArgs& f, hipStream_t st) {
+  const size_t lds_bytes = sweep_fast_lds_bytes(a.KP, f.pw);
+  dim3 grid((f.npairs + 7) / 8);
+  const int nx = a.KP / 32;
+  if (a.mode == kSweepDraw) { if (nx == 1) launch_inst<1, kSweepDraw>(a, f, grid, lds_bytes, st); else launch_inst<2, kSweepDraw>(a, f, grid, lds_bytes, st); }
+  else                      { if (nx == 1) launch_inst<1, kSweepMode>(a, f, grid, lds_bytes, st); else launch_inst<2, kSweepMode>(a, f, grid, lds_bytes, st); }
+}
+
+}  // namespace bnmtf

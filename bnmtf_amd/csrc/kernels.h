@@ -40,6 +40,7 @@ enum SweepMode { kSweepDraw = 0, kSweepMode = 1, kSweepVB = 2 };
 
 struct SweepArgs {
   int n, n0;                 // local units, global index of the first
+  const int* unit_list;      // generic kernel: when non-null, the n units to process (local indices)
   int K, KP;                 // true and padded width
   int mode;                  // SweepMode
   int cond_k;                // >= 0: only evaluate column cond_k, write numer/tau, change nothing
@@ -66,12 +67,41 @@ struct SweepArgs {
 };
 void launch_sweep(const SweepArgs& a, hipStream_t st);
 
+// fast path (kernel_sweep_fast.hip): bank-aware slot layout, q in registers, panels in LDS
+struct FastArgs {
+  const int* unit_map;         // [2*npairs] local unit of each half wave, or -1
+  const uint32_t* pair_E;      // [npairs] slots of the pair (max of its two units)
+  const uint32_t* pair_base;   // [npairs] first slot row of the pair
+  const uint32_t* off;         // [(base+s)*64 + lane] inner index j (j mod 32 == lane mod 32) or mz + lane%32
+  int npairs;                  // pairs in descending slot-count order; block b owns pairs [8b, 8b+8)
+  int mz, pw;                  // inner extent rounded up to 32 (sentinel zero words at mz..mz+31); panel floats pw = round_up(mz+32, 256)
+  const float* XoT; int ldT_o;   // other factor transposed [KP][ldT_o]
+  const float* XoT2; int ld2_o;  // other factor, column pairs interleaved [KP/2][ld2_o][2]
+  double* stats;               // [blocks][4] partial (sum P.X', sum_miss q, sum_miss q^2) or null
+};
+constexpr int kFastMaxSlots = 56;   // blocks whose fullest pair needs more slots per lane go to the generic kernel
+bool sweep_fast_supported(int KP, int pw);
+void launch_sweep_fast(const SweepArgs& a, const FastArgs& f, hipStream_t st);
+
+// relayout + Gram after a sweep / state upload: X -> XT, XT2, partial Gram slabs; then the reduction
+struct PostArgs {
+  const float* X; int rows, KP;
+  float* XT; int ldT; float* XT2; int ld2;
+  double* Cpart; double* spart;          // [blocks][KP*KP], [blocks][KP]
+  double* C64; float* C32; double* colsum;
+  // VB: second moment matrix S2 = var + exp^2
+  const float* S2; float* S2T; double* s2part; double* colsum2;
+};
+void launch_post(const PostArgs& a, hipStream_t st);
+inline int post_blocks(int rows) { return (rows + 127) / 128; }
+
 // ---------------------------------------------------------------------------
 // end of iteration: masked SSE from Gram identities, tau draw, metrics record
 // ---------------------------------------------------------------------------
 struct FinishArgs {
   const double* Cr64; const double* Cc64; const double* sr; const double* sc; int KP;
-  const double* acc;          // [3]
+  const double* acc;          // [3] atomically accumulated sums (generic sweep)
+  const double* stats; int nstats;   // [nstats][4] per-block partial sums (fast sweep), may be null
   double n_obs, sumR, sumR2;  // over the training mask
   double alpha, beta;
   int update;                 // 0 draw, 1 mode (tau = alpha_s/beta_s)
@@ -92,6 +122,7 @@ struct MetricArgs {
 void launch_metric_sums(const MetricArgs& a, hipStream_t st);
 
 // small helpers
+void launch_sum_stats(const double* stats, int nblocks, double* acc, hipStream_t st);   // acc[0..2] += column sums of stats
 void launch_transpose(const float* X, int rows, int KP, float* XT, int ldT, hipStream_t st);
 void launch_tn_sample(const double* mu, const double* tau, size_t n, uint64_t seed, uint32_t it, uint32_t col,
                       uint32_t elem0, double* out, hipStream_t st);

@@ -47,7 +47,16 @@ struct Dir {
   size_t nslots = 0, nmiss = 0;
   // this direction's factor, replicated on every rank
   float* X = nullptr;  int xrows = 0;   // [xrows][KP] row major (GEMM A operand of the other direction)
-  float* XT = nullptr; int ldT = 0;     // [KP][ldT]  (gather source of the other direction)
+  float* XT = nullptr; int ldT = 0;     // [KP][ldT]  (gather source / LDS panels of the other direction)
+  float* XT2 = nullptr;                 // [KP/2][ldT][2] column pairs interleaved (pre-pass panels)
+  double* Cpart = nullptr; double* spart = nullptr; double* s2part = nullptr;   // per-block Gram partials
+  // fast sweep layout (bank-aware slots)
+  int* f_unit_map = nullptr; uint32_t* f_pair_E = nullptr; uint32_t* f_pair_base = nullptr; uint32_t* f_off = nullptr;
+  int f_npairs = 0, f_emax = 0, mz = 0; size_t f_slots = 0;
+  int pw = 0;                                     // LDS panel floats = round_up(mz + 32, 256)
+  int* f_gen_units = nullptr; int f_gen_count = 0;
+  double* stats = nullptr; int stats_blocks = 0;
+  bool fast_ok = false;
   double* C64 = nullptr; float* C32 = nullptr; double* colsum = nullptr;   // Gram of X
   // VB only
   float *mu = nullptr, *tauq = nullptr, *var = nullptr, *S2 = nullptr, *S2T = nullptr;
@@ -77,6 +86,7 @@ struct bnmtf_model {
   double* acc = nullptr;     // [4]
   double* rec = nullptr; size_t rec_cap = 0;
   bool have_state = false;
+  bool use_fast = true, last_sweep_fast = false;   // fast sweep kernel when the shape allows it
   // BNMTF extras
   float* S = nullptr;            // [K][L] on device (row major, unpadded)
   // profiling

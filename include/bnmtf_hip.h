@@ -167,6 +167,9 @@ int bnmtf_gamma_sample(double alpha, double beta, uint64_t seed, uint64_t it, in
 /* when enabled, run() brackets each launch of the listed kernels with hipEvents
  * on the handle's stream; totals are read back with bnmtf_kernel_stats. */
 int bnmtf_set_profiling(bnmtf_handle h, int enable);
+/* sweep kernel selection: 1 (default) = register/LDS-resident fast path when the shape
+ * fits, 0 = always the generic kernel (any mask, q in global memory).  Same results. */
+int bnmtf_set_sweep_path(bnmtf_handle h, int fast);
 int bnmtf_kernel_stats(bnmtf_handle h, int kernel, double* total_ms, uint64_t* launches);
 /* geometry of the last create: padded shapes, split factor, slot counts (for DESIGN/bench) */
 int bnmtf_describe(bnmtf_handle h, char* buf, size_t buflen);

@@ -103,8 +103,9 @@ def test_postrun_api_matches_reference(golden, name):
     assert str(e.value) == "Unrecognised metric for model quality: FAIL."
 
 
+@pytest.mark.parametrize("fast", [True, False])
 @pytest.mark.parametrize("name", ["toy", "r37x29", "r40x33"])
-def test_mode_update_trajectory_matches_oracle(golden, name):
+def test_mode_update_trajectory_matches_oracle(golden, name, fast):
     """Deterministic end-to-end parity: with every draw replaced by the mode
     max(0,mu) (the ICM update, nmf_icm.py:124-134) the whole data path -- both
     contractions, the sequential column loop, q maintenance, Gram-identity SSE, tau,
@@ -115,6 +116,7 @@ def test_mode_update_trajectory_matches_oracle(golden, name):
     o.run(8, draw=False)
     b = bnmf_gibbs_optimised(c["R"], c["M"], int(c["K"]), _pri(c), verbose=False)
     b.U, b.V, b.tau = c["U"].copy(), c["V"].copy(), float(c["tau"])
+    b.set_sweep_path(fast)
     b.run(8, update='mode')
     np.testing.assert_allclose(b.all_performances['MSE'], o.all_performances['MSE'], rtol=2e-4)
     np.testing.assert_allclose(b.all_tau, o.all_tau, rtol=2e-4)
@@ -125,7 +127,8 @@ def test_mode_update_trajectory_matches_oracle(golden, name):
     assert np.allclose(b.U, b.all_U[-1]) and np.allclose(b.V, b.all_V[-1]) and abs(b.tau - b.all_tau[-1]) < 1e-12
 
 
-def test_gibbs_draws_follow_oracle_with_same_philox_stream(golden):
+@pytest.mark.parametrize("fast", [True, False])
+def test_gibbs_draws_follow_oracle_with_same_philox_stream(golden, fast):
     """Same seed, same counters: the device sampler reproduces the oracle's draws
     (first sweep: every element within fp32 noise unless an accept/reject decision
     sits on a rounding boundary) and the MSE trajectory stays together."""
@@ -138,6 +141,7 @@ def test_gibbs_draws_follow_oracle_with_same_philox_stream(golden):
     o.run(30)
     b = bnmf_gibbs_optimised(t["R"], t["M"], K, pri, verbose=False, seed=77)
     b.U, b.V, b.tau = g["U0_seed0"].copy(), g["V0_seed0"].copy(), float(g["tau0_seed0"])
+    b.set_sweep_path(fast)
     b.run(30)
     d0 = np.abs(b.all_U[0] - o.all_U[0]) / (1e-3 + np.abs(o.all_U[0]))
     assert np.mean(d0 < 1e-3) > 0.99
@@ -212,6 +216,12 @@ def test_large_shape_properties():
         assert (np.abs(b.muV(tV, k) - o.muV(tV, k)) <= 2e-5 * sc).all()
     b.run(150)
     mse = b.all_performances['MSE']
+    # the generic sweep kernel gives the same chain (same Philox counters): first iterations agree
+    g2 = bnmf_gibbs_optimised(R, M, K, pri, verbose=False, seed=9)
+    g2.U, g2.V, g2.tau = o.U.copy(), o.V.copy(), o.tau
+    g2.set_sweep_path(False)
+    g2.run(3)
+    np.testing.assert_allclose(g2.all_performances['MSE'], mse[:3], rtol=2e-3)
     print('MSE trajectory', [round(float(m), 3) for m in mse[::10]])
     assert mse[0] > 10 * mse[-1] and 0.8 < mse[-1] < 1.3
     p = b.predict_while_running()
