@@ -75,21 +75,45 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
   }
   d.nslots = idx.size();
 
-  // fast layout: a unit owns a 32-lane half wave; lane r holds the entries with j mod 32 == r
-  // (bank-conflict-free LDS gathers), padded to the fullest residue class; units sorted by
-  // slot count so that the two halves of a wave and the waves of a block are balanced.
+  // fast layout: a unit owns a 32-lane half wave.  Lane r prefers the entries with j mod 32 == r
+  // (bank-conflict-free LDS gathers).  Residue classes are binomially unbalanced, so instead of
+  // padding every lane to the fullest class, a unit gets E = mean + ~1 sigma slots per lane and the
+  // few overflow entries are parked in lanes with room (each costs one 2-way bank conflict).
   d.mz = round_up(m, 32);
   d.pw = round_up(d.mz + 32, 256);
   {
-    std::vector<std::vector<uint32_t>> res((size_t)d.n * 32);
     std::vector<int> Eu(d.n, 0);
+    std::vector<std::vector<uint32_t>> lanes((size_t)d.n * 32);     // per unit, per lane: slot contents
+    std::vector<uint32_t> overflow;
     for (int ul = 0; ul < d.n; ++ul) {
+      std::vector<uint32_t>* L = &lanes[(size_t)ul * 32];
+      size_t cnt = 0;
       for (uint32_t t = ptr[ul]; t < ptr[ul + 1]; ++t) {
         const uint32_t j = idx[t];
-        if (j < (uint32_t)m) res[(size_t)ul * 32 + (j & 31)].push_back(j);
+        if (j < (uint32_t)m) { L[j & 31].push_back(j); ++cnt; }
       }
-      for (int r = 0; r < 32; ++r) Eu[ul] = std::max(Eu[ul], (int)res[(size_t)ul * 32 + r].size());
+      const double mean = (double)cnt / 32.0;
+      int E = (int)std::ceil(mean + std::sqrt(mean));
+      E = std::max(2, (E + 1) & ~1);
+      int emax = 0;
+      for (int r = 0; r < 32; ++r) emax = std::max(emax, (int)L[r].size());
+      if (!getenv("BNMTF_BALANCE")) E = emax;       // default: conflict-free layout (measured faster than the balanced one)
+      if (emax <= E) { E = std::max(2, (emax + 1) & ~1); }
+      else {
+        overflow.clear();
+        for (int r = 0; r < 32; ++r)
+          while ((int)L[r].size() > E) { overflow.push_back(L[r].back()); L[r].pop_back(); }
+        int lane = 0;
+        for (uint32_t j : overflow) {                      // round-robin over lanes with room
+          int tries = 0;
+          while ((int)L[lane].size() >= E && tries < 32) { lane = (lane + 1) & 31; ++tries; }
+          L[lane].push_back(j);
+          lane = (lane + 1) & 31;
+        }
+      }
+      Eu[ul] = E;
     }
+    auto res = [&](int ul, int r) -> const std::vector<uint32_t>& { return lanes[(size_t)ul * 32 + r]; };
     std::vector<int> order(d.n);
     for (int i = 0; i < d.n; ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return Eu[x] > Eu[y]; });
@@ -114,7 +138,7 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
         for (uint32_t sidx = 0; sidx < pE[pi]; ++sidx)
           for (int r = 0; r < 32; ++r) {
             uint32_t v = (uint32_t)(d.mz + r);
-            if (ul >= 0) { const auto& lst = res[(size_t)ul * 32 + r]; if (sidx < lst.size()) v = lst[sidx]; }
+            if (ul >= 0) { const auto& lst = res(ul, r); if (sidx < lst.size()) v = lst[sidx]; }
             off[((size_t)pB[pi] + sidx) * 64 + hh * 32 + r] = v;
           }
       }
@@ -127,16 +151,23 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
     HIPCHK(hipMemcpy(d.f_pair_base, pB.data(), pB.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     CHK(dalloc(&d.f_off, off.size(), false));
     HIPCHK(hipMemcpy(d.f_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    // blocks (8 pairs) whose fullest pair exceeds kFastMaxSlots are left to the generic kernel
+    // leading pairs with more than 32 slots form 8-wave blocks (padded to a multiple of 16 pairs so the
+    // two launches tile the pair list); 8-pair blocks whose fullest pair exceeds kFastMaxSlots are left
+    // to the generic kernel
     {
+      int nhi = 0;
+      while (nhi < d.f_npairs && (int)pE[nhi] > 32) ++nhi;
+      d.f_npairs_hi = std::min(d.f_npairs, (nhi + 15) / 16 * 16);
+      if (d.f_npairs_hi % 8) d.f_npairs_hi = 0 * (nhi = 0);   // tiny problems: everything in the 16-wave launch
       std::vector<int> gen;
       for (int b0 = 0; b0 < d.f_npairs; b0 += 8)
         if ((int)pE[b0] > kFastMaxSlots)
           for (int t = 2 * b0; t < std::min(2 * (b0 + 8), 2 * d.f_npairs); ++t) if (umap[t] >= 0) gen.push_back(umap[t]);
+      d.fast_ok = true;
       d.f_gen_count = (int)gen.size();
       CHK(dalloc(&d.f_gen_units, std::max<size_t>(gen.size(), 1), false));
       if (!gen.empty()) HIPCHK(hipMemcpy(d.f_gen_units, gen.data(), gen.size() * sizeof(int), hipMemcpyHostToDevice));
-      d.stats_blocks = std::max((d.f_npairs + 7) / 8, 1);
+      d.stats_blocks = (d.f_npairs + 7) / 8 + 1;
     }
     CHK(dalloc(&d.stats, (size_t)d.stats_blocks * 4));
   }
@@ -237,12 +268,13 @@ static void enqueue_post(bnmtf_model* h, Dir& d, bool vb = false) {
 static void enqueue_sweep(bnmtf_model* h, Dir& d, const Dir& other, SweepArgs& s, bool want_stats) {
   s.unit_list = nullptr;
   h->last_sweep_fast = false;
-  if (h->use_fast && s.cond_k < 0 && s.mode != kSweepVB && sweep_fast_supported(d.KP, d.pw)) {
+  if (h->use_fast && d.fast_ok && s.cond_k < 0 && s.mode != kSweepVB && sweep_fast_supported(d.KP, d.pw)) {
     FastArgs f;
     f.unit_map = d.f_unit_map; f.pair_E = d.f_pair_E; f.pair_base = d.f_pair_base; f.off = d.f_off;
-    f.npairs = d.f_npairs; f.mz = d.mz; f.pw = d.pw;
+    f.npairs = d.f_npairs; f.npairs_hi = d.f_npairs_hi; f.mz = d.mz; f.pw = d.pw;
     f.XoT = other.XT; f.ldT_o = other.ldT; f.XoT2 = other.XT2; f.ld2_o = other.ldT;
     f.stats = want_stats ? d.stats : nullptr;
+    { const char* e = getenv("BNMTF_SWEEP_DBG"); f.dbg = e ? atoi(e) : 0; }
     SweepArgs s2 = s;
     s2.acc = nullptr;
     launch_sweep_fast(s2, f, h->stream);

@@ -65,13 +65,26 @@ __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
     if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
     __syncthreads();
   }
+  const double dot = red[0];
+  __syncthreads();
+  // per-block sweep statistics: 3 columns, strided over the threads, tree-summed
+  double st3[3] = {0.0, 0.0, 0.0};
+  for (int b = threadIdx.x; b < a.nstats; b += 256)
+    for (int t = 0; t < 3; ++t) st3[t] += a.stats[(size_t)b * 4 + t];
+  for (int t = 0; t < 3; ++t) {
+    red[threadIdx.x] = st3[t];
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+      if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+      __syncthreads();
+    }
+    st3[t] = red[0];
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
-    const double dot = red[0];
     double sp1 = 0.0;
     for (int t = 0; t < KP; ++t) sp1 = fma(a.sr[t], a.sc[t], sp1);
-    double acc[3] = {a.acc[0], a.acc[1], a.acc[2]};
-    for (int b = 0; b < a.nstats; ++b)
-      for (int t = 0; t < 3; ++t) acc[t] += a.stats[(size_t)b * 4 + t];
+    double acc[3] = {a.acc[0] + st3[0], a.acc[1] + st3[1], a.acc[2] + st3[2]};
     const double srp = acc[0], sp = sp1 - acc[1], spp = dot - acc[2];
     const double n = a.n_obs;
     const double sse = a.sumR2 - 2.0 * srp + spp;

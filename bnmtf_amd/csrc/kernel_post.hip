@@ -10,28 +10,29 @@
 namespace bnmtf {
 
 __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
-  __shared__ float tile[128 * 68];
+  constexpr int RB = kPostRows;
+  __shared__ float tile[RB * 68];
   constexpr int LD = 68;
   const int KP = a.KP, tid = threadIdx.x;
-  const int r0 = blockIdx.x * 128;
-  const int nr = min(128, a.rows - r0);
+  const int r0 = blockIdx.x * RB;
+  const int nr = min(RB, a.rows - r0);
   const float* src = a.X;
   for (int pass = 0; pass < (a.S2 ? 2 : 1); ++pass) {
     if (pass == 1) { __syncthreads(); src = a.S2; }
-    for (int t = tid; t < 128 * KP; t += 256) {
+    for (int t = tid; t < RB * KP; t += 256) {
       const int r = t / KP, k = t % KP;
       tile[r * LD + k] = (r < nr) ? src[(size_t)(r0 + r) * KP + k] : 0.f;
     }
     __syncthreads();
     float* T1 = pass == 0 ? a.XT : a.S2T;
     if (T1)
-      for (int t = tid; t < 128 * KP; t += 256) {
-        const int k = t >> 7, r = t & 127;
+      for (int t = tid; t < RB * KP; t += 256) {
+        const int k = t / RB, r = t % RB;
         if (r < nr) T1[(size_t)k * a.ldT + r0 + r] = tile[r * LD + k];
       }
     if (pass == 0 && a.XT2)
-      for (int t = tid; t < 128 * KP; t += 256) {
-        const int kp = t >> 8, rem = t & 255, r = rem >> 1, c = rem & 1;
+      for (int t = tid; t < RB * KP; t += 256) {
+        const int kp = t / (2 * RB), rem = t % (2 * RB), r = rem >> 1, c = rem & 1;
         if (r < nr) a.XT2[((size_t)kp * a.ld2 + r0 + r) * 2 + c] = tile[r * LD + 2 * kp + c];
       }
     if (pass == 0) {
@@ -66,23 +67,32 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
   }
 }
 
+// 32 entries per block, 8 partial-slab strides per entry (lanes e + 32*g), tree-summed in LDS:
+// KP*KP/32 blocks, every slab read is a coalesced 256 B row segment.
 __global__ __launch_bounds__(256) void gram_reduce_kernel(PostArgs a, int nblk) {
+  __shared__ double red[256];
   const int KP = a.KP;
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t < KP * KP) {
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += a.Cpart[(size_t)b * KP * KP + t];
+  const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int t = blockIdx.x * 32 + e;
+  double s = 0.0;
+  for (int b = g; b < nblk; b += 8) s += a.Cpart[(size_t)b * KP * KP + t];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (g == 0) {
+#pragma unroll
+    for (int gg = 1; gg < 8; ++gg) s += red[gg * 32 + e];
     a.C64[t] = s;
     a.C32[t] = (float)s;
   }
-  if (blockIdx.x == 0 && (int)threadIdx.x < KP) {
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += a.spart[(size_t)b * KP + threadIdx.x];
-    a.colsum[threadIdx.x] = s;
-    if (a.S2) {
-      double s2 = 0.0;
-      for (int b = 0; b < nblk; ++b) s2 += a.s2part[(size_t)b * KP + threadIdx.x];
-      a.colsum2[threadIdx.x] = s2;
+  if (blockIdx.x == 0) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < KP * 4; c += 256) {      // 4 partial strides per column
+      const int col = c >> 2, gq = c & 3;
+      double v = 0.0, v2 = 0.0;
+      for (int b = gq; b < nblk; b += 4) { v += a.spart[(size_t)b * KP + col]; if (a.S2) v2 += a.s2part[(size_t)b * KP + col]; }
+      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64);
+      v2 += __shfl_xor(v2, 1, 64); v2 += __shfl_xor(v2, 2, 64);
+      if (gq == 0) { a.colsum[col] = v; if (a.S2) a.colsum2[col] = v2; }
     }
   }
 }
@@ -90,7 +100,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(PostArgs a, int nblk) 
 void launch_post(const PostArgs& a, hipStream_t st) {
   const int nblk = post_blocks(a.rows);
   hipLaunchKernelGGL(post_kernel, dim3(nblk), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3((a.KP * a.KP + 255) / 256), dim3(256), 0, st, a, nblk);
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3(a.KP * a.KP / 32), dim3(256), 0, st, a, nblk);
 }
 
 }  // namespace bnmtf

@@ -17,6 +17,8 @@
 //  * the K draws per unit are sequential, so the Philox work is hoisted: lane l
 //    pre-computes the first two candidates of columns l and l+32; step k broadcasts them.
 //    Only a double rejection (rare) falls back to 32 fresh candidates per round.
+#include <cstdlib>
+
 #include "kernels.h"
 #include "device_rng.h"
 
@@ -31,8 +33,14 @@ __device__ __forceinline__ float dpp_xor_row_sum(float v) {   // all-reduce insi
 }
 __device__ __forceinline__ float half_sum(float v) {          // all-reduce inside each 32-lane half
   v = dpp_xor_row_sum(v);
-  v += __shfl_xor(v, 16, 64);
-  return v;
+#ifdef BNMTF_USE_PERMLANE16
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const unsigned b = __builtin_bit_cast(unsigned, v);
+  const u32x2 r = __builtin_amdgcn_permlane16_swap(b, b, false, false);   // (row0,row0,row2,row2) , (row1,row1,row3,row3)
+  return __builtin_bit_cast(float, r.x) + __builtin_bit_cast(float, r.y);
+#else
+  return v + __shfl_xor(v, 16, 64);
+#endif
 }
 __device__ __forceinline__ double half_sum_d(double v) {
 #pragma unroll
@@ -51,6 +59,36 @@ __device__ __forceinline__ uint32_t half_bcast_u(uint32_t v, int src, int half) 
   return half ? a1 : a0;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// reciprocal-based parameters (v_rcp / v_rsq, ~1 ulp): the sampler needs no correctly rounded division
+struct TnFast { float mu, irt, a, d, ilam; bool live, tail; };
+__device__ __forceinline__ TnFast tn_fast_params(float numer, float tau_p) {
+  TnFast p;
+  p.live = tau_p > 0.0f;
+  const float tp = p.live ? tau_p : 1.0f;
+  p.irt = __frsqrt_rn(tp);                       // sigma
+  p.mu = numer * __frcp_rn(tp);
+  p.a = -p.mu * (tp * p.irt);                    // -mu * sqrt(tau)
+  p.live = p.live && isfinite(p.a);
+  p.d = 2.0f * __frcp_rn(sqrtf(fmaf(p.a, p.a, 4.0f)) + p.a);
+  p.ilam = __frcp_rn(p.a + p.d);
+  p.tail = p.a >= kTnA0;
+  return p;
+}
+__device__ __forceinline__ bool tn_eval_fast(const TnFast& p, uint32_t r0, uint32_t r1, float* x) {
+  const float u1 = u24(r0), u2 = u24(r1);
+  const float nl = -__logf(u1);
+  const float e = nl * p.ilam;
+  const float t = e - p.d;
+  const bool acc_t = u2 <= __expf(-0.5f * t * t);
+  const float z = sqrtf(2.0f * nl) * __cosf(kTwoPi * u2);
+  const bool acc_n = z >= p.a;
+  *x = p.tail ? e * p.irt : fmaf(z, p.irt, p.mu);
+  return p.tail ? acc_t : acc_n;
+}
+
 // candidate value / acceptance from two raw 32-bit words (no Philox here)
 __device__ __forceinline__ bool tn_eval(const TnParams& p, uint32_t r0, uint32_t r1, float* x) {
   const float u1 = u24(r0), u2 = u24(r1);
@@ -67,14 +105,15 @@ __device__ __forceinline__ bool tn_eval(const TnParams& p, uint32_t r0, uint32_t
 // LDS-direct staging of one panel: `chunks` pieces of 1 KiB (64 lanes x 16 B), wave w takes
 // chunks w, w+8, ...  No VGPRs, no ds_write; completion is covered by the vmcnt(0) that
 // __syncthreads() carries while an LDS-DMA is in flight.
+template <int NW>
 __device__ __forceinline__ void stage_panel(const float* src, float* dst, int chunks, int wave, int lane) {
   typedef __attribute__((address_space(3))) void* lds_ptr;
-  for (int c = wave; c < chunks; c += 8) {
+  for (int c = wave; c < chunks; c += NW) {
     __builtin_amdgcn_global_load_lds(src + (size_t)c * 256 + lane * 4, (lds_ptr)(dst + (size_t)c * 256), 16, 0, 0);
   }
 }
 
-template <int EM, int NX, int MODE>
+template <int EM, int NX, int MODE, int NW>
 __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastArgs& f, float* lds) {
   constexpr int KP = NX * 32;
   const int PW = f.pw;                      // floats per single-column panel (multiple of 256)
@@ -84,7 +123,7 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l5 = lane & 31;
-  const int pair = blockIdx.x * 8 + wave;
+  const int pair = blockIdx.x * NW + wave;
   const bool wave_on = pair < f.npairs;
   const uint32_t base = wave_on ? f.pair_base[pair] : 0u;
   const int E = wave_on ? (int)f.pair_E[pair] : 0;
@@ -104,72 +143,80 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
       lam[nx] = a.lambda[(size_t)u * KP + kk];
     }
   }
+  static_assert(EM % 2 == 0, "slots are processed in pairs");
+  constexpr int EH = EM / 2;
   uint32_t off[EM];
-  float q[EM], vp[EM];
+  f32x2 q2[EH], vp2[EH];                   // slots (2h, 2h+1) share a register pair: packed f32 FMAs
 #pragma unroll
-  for (int s = 0; s < EM; ++s) {
+  for (int s = 0; s < EM; ++s)
     off[s] = (s < E) ? f.off[((size_t)base + s) * 64 + lane] : (uint32_t)(f.mz + l5);   // sentinel: a zero word on bank l5
-    q[s] = 0.f; vp[s] = 0.f;
-  }
-  for (int t = tid; t < KP * KP; t += 512) Cs[t] = a.C32[t];
+#pragma unroll
+  for (int h = 0; h < EH; ++h) { q2[h] = f32x2{0.f, 0.f}; vp2[h] = f32x2{0.f, 0.f}; }
+  for (int t = tid; t < KP * KP; t += NW * 64) Cs[t] = a.C32[t];
 
-  // hoisted Philox: candidates 0 and 1 of columns l5 (+32)
-  uint32_t c0a[NX], c0b[NX], c1a[NX], c1b[NX];
+  // hoisted Philox: candidates 0..kHoist-1 of columns l5 (+32)
+  constexpr int kHoist = 4;
+  uint32_t ca[kHoist][NX], cb[kHoist][NX];
   if (MODE == kSweepDraw) {
 #pragma unroll
-    for (int nx = 0; nx < NX; ++nx) {
-      const uint32_t kk = (uint32_t)(l5 + 32 * nx);
-      const U4 r0 = philox4x32_10((uint32_t)gi, kk, a.it, a.stream, a.key0, a.key1);
-      const U4 r1 = philox4x32_10((uint32_t)gi, kk, a.it, a.stream + 16u, a.key0, a.key1);
-      c0a[nx] = r0.x; c0b[nx] = r0.y; c1a[nx] = r1.x; c1b[nx] = r1.y;
-    }
+    for (int c = 0; c < kHoist; ++c)
+#pragma unroll
+      for (int nx = 0; nx < NX; ++nx) {
+        const U4 r = philox4x32_10((uint32_t)gi, (uint32_t)(l5 + 32 * nx), a.it, a.stream + 16u * c, a.key0, a.key1);
+        ca[c][nx] = r.x; cb[c][nx] = r.y;
+      }
   }
 
   // ------------------------------------------------------------ pre-pass: q = U_i . V_j
   {
     const int chunks2 = (2 * PW) / 256;
     const size_t stride = (size_t)f.ld2_o * 2;
-    stage_panel(f.XoT2, pan, chunks2, wave, lane);
+    stage_panel<NW>(f.XoT2, pan, chunks2, wave, lane);
     __syncthreads();
     const int npair = KP / 2;
     for (int kp = 0; kp < npair; ++kp) {
-      if (kp + 1 < npair) stage_panel(f.XoT2 + (size_t)(kp + 1) * stride, pan + (size_t)((kp + 1) & 1) * 2 * PW, chunks2, wave, lane);
+      if (kp + 1 < npair) stage_panel<NW>(f.XoT2 + (size_t)(kp + 1) * stride, pan + (size_t)((kp + 1) & 1) * 2 * PW, chunks2, wave, lane);
       const float2* cur = reinterpret_cast<const float2*>(pan + (size_t)(kp & 1) * 2 * PW);
       const int k0 = 2 * kp, k1 = 2 * kp + 1;
       const float xs0 = (NX == 2 && k0 >= 32) ? x[NX - 1] : x[0];
       const float x0 = half_bcast(xs0, k0 & 31, half), x1 = half_bcast(xs0, k1 & 31, half);
+      const f32x2 x01 = {x0, x1};
 #pragma unroll
-      for (int s = 0; s < EM; ++s) {
-        const float2 v = cur[off[s]];
-        q[s] = fmaf(x0, v.x, fmaf(x1, v.y, q[s]));
+      for (int h = 0; h < EH; ++h) {          // (q2[h], vp2[h]) = (even col, odd col) partial sums of slots 2h, 2h+1
+        const float2 va = cur[off[2 * h]], vb = cur[off[2 * h + 1]];
+        q2[h] = pk_fma(f32x2{va.x, va.y}, x01, q2[h]);
+        vp2[h] = pk_fma(f32x2{vb.x, vb.y}, x01, vp2[h]);
       }
       __syncthreads();
     }
+#pragma unroll
+    for (int h = 0; h < EH; ++h) { q2[h] = f32x2{q2[h].x + q2[h].y, vp2[h].x + vp2[h].y}; vp2[h] = f32x2{0.f, 0.f}; }
   }
 
   // ------------------------------------------------------------ the K sequential columns
   const int chunks1 = PW / 256;
-  stage_panel(f.XoT, pan, chunks1, wave, lane);
+  stage_panel<NW>(f.XoT, pan, chunks1, wave, lane);
   __syncthreads();
   const float tau = *a.tau;
   float dprev = 0.f;
   for (int k = 0; k < K; ++k) {
-    if (k + 1 < K) stage_panel(f.XoT + (size_t)(k + 1) * f.ldT_o, pan + (size_t)((k + 1) & 1) * PW, chunks1, wave, lane);
+    if (k + 1 < K) stage_panel<NW>(f.XoT + (size_t)(k + 1) * f.ldT_o, pan + (size_t)((k + 1) & 1) * PW, chunks1, wave, lane);
     const float* cur = pan + (size_t)(k & 1) * PW;
     const float xsel = (NX == 2 && k >= 32) ? x[NX - 1] : x[0];
     const float xk = half_bcast(xsel, k & 31, half);
-    float corr[4] = {0.f, 0.f, 0.f, 0.f}, asq[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x2 corr2[2] = {{0.f, 0.f}, {0.f, 0.f}}, asq2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+    const f32x2 dp2 = {dprev, dprev}, nxk2 = {-xk, -xk};
 #pragma unroll
-    for (int s = 0; s < EM; ++s) {
-      const float v = cur[off[s]];
-      const float qs = fmaf(dprev, vp[s], q[s]);      // column k-1's update, applied late
-      const float t = fmaf(-xk, v, qs);
-      corr[s & 3] = fmaf(t, v, corr[s & 3]);
-      asq[s & 3] = fmaf(v, v, asq[s & 3]);
-      q[s] = qs; vp[s] = v;
+    for (int h = 0; h < EH; ++h) {
+      const f32x2 v = {cur[off[2 * h]], cur[off[2 * h + 1]]};
+      const f32x2 qs = pk_fma(dp2, vp2[h], q2[h]);    // column k-1's update, applied late
+      const f32x2 t = pk_fma(nxk2, v, qs);
+      corr2[h & 1] = pk_fma(t, v, corr2[h & 1]);
+      asq2[h & 1] = pk_fma(v, v, asq2[h & 1]);
+      q2[h] = qs; vp2[h] = v;
     }
-    float corr_t = (corr[0] + corr[1]) + (corr[2] + corr[3]);
-    float asq_t = (asq[0] + asq[1]) + (asq[2] + asq[3]);
+    float corr_t = (corr2[0].x + corr2[0].y) + (corr2[1].x + corr2[1].y);
+    float asq_t = (asq2[0].x + asq2[0].y) + (asq2[1].x + asq2[1].y);
 #pragma unroll
     for (int nx = 0; nx < NX; ++nx) {
       const int kk = l5 + 32 * nx;
@@ -183,22 +230,25 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
     const float num = half_bcast(psel, k & 31, half) + corr_t;
     const float tau_p = tau * (ckk - asq_t);
     const float numer = fmaf(tau, num, -half_bcast(lsel, k & 31, half));
-    const float mu = numer / tau_p;
     float xnew = 0.f;
     if (MODE == kSweepDraw) {
-      const TnParams tp = tn_params(mu, tau_p);
-      const uint32_t sa = (NX == 2 && k >= 32) ? c0a[NX - 1] : c0a[0], sb = (NX == 2 && k >= 32) ? c0b[NX - 1] : c0b[0];
-      float xc;
-      bool acc = tn_eval(tp, half_bcast_u(sa, k & 31, half), half_bcast_u(sb, k & 31, half), &xc);
-      bool done = !tp.live || !valid || acc;
-      xnew = (tp.live && valid && acc) ? tn_guard(xc) : 0.f;
-      if (__ballot(!done)) {                                   // candidate 1 (pre-computed)
-        const uint32_t ta = (NX == 2 && k >= 32) ? c1a[NX - 1] : c1a[0], tb = (NX == 2 && k >= 32) ? c1b[NX - 1] : c1b[0];
-        acc = tn_eval(tp, half_bcast_u(ta, k & 31, half), half_bcast_u(tb, k & 31, half), &xc);
-        if (!done && acc) { xnew = tn_guard(xc); done = true; }
+      const TnFast tf = tn_fast_params(numer, tau_p);
+      bool done = !tf.live || !valid;
+#pragma unroll
+      for (int c = 0; c < kHoist; ++c) {
+        if (c == 0 || __ballot(!done)) {                      // wave-uniform: later candidates only when someone still needs one
+          const uint32_t sa = (NX == 2 && k >= 32) ? ca[c][NX - 1] : ca[c][0], sb = (NX == 2 && k >= 32) ? cb[c][NX - 1] : cb[c][0];
+          float xc;
+          const bool acc = tn_eval_fast(tf, half_bcast_u(sa, k & 31, half), half_bcast_u(sb, k & 31, half), &xc);
+          if (!done && acc) { xnew = tn_guard(xc); done = true; }
+        }
+      }
+      if (__ballot(!done)) {                                   // rare: fresh candidates kHoist.. : 32 per round
+        TnParams tp;
+        tp.mu = tf.mu; tp.rt = 1.0f / tf.irt; tp.a = tf.a; tp.d = tf.d; tp.lam = tf.a + tf.d; tp.live = tf.live; tp.tail = tf.tail;
         for (uint32_t round = 0; round < 128u && __ballot(!done); ++round) {   // candidates 2.. : 32 per round
           float xr;
-          const bool ar = tn_candidate(tp, (uint32_t)gi, (uint32_t)k, a.it, a.stream, 2u + round * 32u + (uint32_t)l5,
+          const bool ar = tn_candidate(tp, (uint32_t)gi, (uint32_t)k, a.it, a.stream, (uint32_t)kHoist + round * 32u + (uint32_t)l5,
                                        a.key0, a.key1, &xr);
           const unsigned long long m = __ballot(ar);
           const uint32_t mh = half ? (uint32_t)(m >> 32) : (uint32_t)m;
@@ -208,6 +258,7 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
         }
       }
     } else {
+      const float mu = numer / tau_p;
       xnew = (valid && tau_p > 0.f && mu > 0.f) ? mu : 0.f;
     }
     dprev = xnew - xk;
@@ -228,14 +279,17 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
 #pragma unroll
     for (int nx = 0; nx < NX; ++nx) px += (double)p[nx] * (double)x[nx];
 #pragma unroll
-    for (int s = 0; s < EM; ++s) { const double qv = (double)fmaf(dprev, vp[s], q[s]); sq += qv; sq2 += qv * qv; }
+    for (int h = 0; h < EH; ++h) {
+      const double qa = (double)fmaf(dprev, vp2[h].x, q2[h].x), qb = (double)fmaf(dprev, vp2[h].y, q2[h].y);
+      sq += qa + qb; sq2 += qa * qa + qb * qb;
+    }
     px = half_sum_d(px); sq = half_sum_d(sq); sq2 = half_sum_d(sq2);
     double* red = reinterpret_cast<double*>(pan);      // panels are dead: reuse
     if (l5 == 0) { red[(wave * 2 + half) * 3 + 0] = valid ? px : 0.0; red[(wave * 2 + half) * 3 + 1] = sq; red[(wave * 2 + half) * 3 + 2] = sq2; }
     __syncthreads();
     if (tid < 3) {
       double s = 0.0;
-      for (int w = 0; w < 16; ++w) s += red[w * 3 + tid];
+      for (int w = 0; w < 2 * NW; ++w) s += red[w * 3 + tid];
       f.stats[(size_t)blockIdx.x * 4 + tid] = s;
     }
   }
@@ -243,37 +297,58 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
 
 // One launch covers every block; a block's slot class (template EM) is the smallest class that
 // holds its fullest pair (units are sorted by slot count, so blocks are homogeneous).
-template <int NX, int MODE>
-__global__ __launch_bounds__(512, 2) void sweep_fast_kernel(SweepArgs a, FastArgs f) {
+// NW = 16 (1024 threads, 32 units per CU in ONE resident block, <= 128 VGPRs) serves slot counts
+// up to 32; NW = 8 (512 threads, <= 256 VGPRs) serves the fuller units.
+template <int NX, int MODE, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void sweep_fast_kernel(SweepArgs a, FastArgs f) {
   extern __shared__ float lds[];
-  const int e0 = (int)f.pair_E[blockIdx.x * 8];      // descending order: first pair of the block is its fullest
-  if (e0 <= 8) sweep_fast_body<8, NX, MODE>(a, f, lds);
-  else if (e0 <= 16) sweep_fast_body<16, NX, MODE>(a, f, lds);
-  else if (e0 <= 24) sweep_fast_body<24, NX, MODE>(a, f, lds);
-  else if (e0 <= 32) sweep_fast_body<32, NX, MODE>(a, f, lds);
-  else if (e0 <= 40) sweep_fast_body<40, NX, MODE>(a, f, lds);
-  else if (e0 <= 48) sweep_fast_body<48, NX, MODE>(a, f, lds);
-  else if (e0 <= kFastMaxSlots) sweep_fast_body<kFastMaxSlots, NX, MODE>(a, f, lds);
-  else if (f.stats && threadIdx.x < 3) f.stats[(size_t)blockIdx.x * 4 + threadIdx.x] = 0.0;   // generic kernel owns these units
+  const int e0 = (int)f.pair_E[blockIdx.x * NW];      // descending order: first pair of the block is its fullest
+  if (NW == 16) {
+    if (e0 <= 8) sweep_fast_body<8, NX, MODE, NW>(a, f, lds);
+    else if (e0 <= 16) sweep_fast_body<16, NX, MODE, NW>(a, f, lds);
+    else if (e0 <= 24) sweep_fast_body<24, NX, MODE, NW>(a, f, lds);
+    else sweep_fast_body<32, NX, MODE, NW>(a, f, lds);
+  } else {
+    if (e0 <= 8) sweep_fast_body<8, NX, MODE, NW>(a, f, lds);
+    else if (e0 <= 16) sweep_fast_body<16, NX, MODE, NW>(a, f, lds);
+    else if (e0 <= 24) sweep_fast_body<24, NX, MODE, NW>(a, f, lds);
+    else if (e0 <= 32) sweep_fast_body<32, NX, MODE, NW>(a, f, lds);
+    else if (e0 <= 40) sweep_fast_body<40, NX, MODE, NW>(a, f, lds);
+    else if (e0 <= 48) sweep_fast_body<48, NX, MODE, NW>(a, f, lds);
+    else if (e0 <= kFastMaxSlots) sweep_fast_body<kFastMaxSlots, NX, MODE, NW>(a, f, lds);
+    else if (f.stats && threadIdx.x < 3) f.stats[(size_t)blockIdx.x * 4 + threadIdx.x] = 0.0;   // generic kernel owns these units
+  }
 }
 
 size_t sweep_fast_lds_bytes(int KP, int pw) { return sizeof(float) * ((size_t)KP * KP + 4 * (size_t)pw); }
 
 bool sweep_fast_supported(int KP, int pw) { return sweep_fast_lds_bytes(KP, pw) <= 160 * 1024; }
 
-template <int NX, int MODE>
-static void launch_inst(const SweepArgs& a, const FastArgs& f, dim3 grid, size_t lds_bytes, hipStream_t st) {
+template <int NX, int MODE, int NW>
+static void launch_inst(const SweepArgs& a, const FastArgs& f, int nblocks, size_t lds_bytes, hipStream_t st) {
   static bool once = false;
-  if (!once) { (void)hipFuncSetAttribute((const void*)sweep_fast_kernel<NX, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
-  hipLaunchKernelGGL((sweep_fast_kernel<NX, MODE>), grid, dim3(512), lds_bytes, st, a, f);
+  if (!once) { (void)hipFuncSetAttribute((const void*)sweep_fast_kernel<NX, MODE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+  if (nblocks > 0) hipLaunchKernelGGL((sweep_fast_kernel<NX, MODE, NW>), dim3(nblocks), dim3(NW * 64), lds_bytes, st, a, f);
 }
 
+// pairs [0, f.npairs_hi) (slot count > 32) run as 8-wave blocks, the rest as 16-wave blocks
 void launch_sweep_fast(const SweepArgs& a, const FastArgs& f, hipStream_t st) {
   const size_t lds_bytes = sweep_fast_lds_bytes(a.KP, f.pw);
-  dim3 grid((f.npairs + 7) / 8);
   const int nx = a.KP / 32;
-  if (a.mode == kSweepDraw) { if (nx == 1) launch_inst<1, kSweepDraw>(a, f, grid, lds_bytes, st); else launch_inst<2, kSweepDraw>(a, f, grid, lds_bytes, st); }
-  else                      { if (nx == 1) launch_inst<1, kSweepMode>(a, f, grid, lds_bytes, st); else launch_inst<2, kSweepMode>(a, f, grid, lds_bytes, st); }
+  FastArgs lo = f, hi = f;
+  hi.npairs = f.npairs_hi;                                   // first npairs_hi pairs (multiple of 8 and 16)
+  lo.pair_E += f.npairs_hi; lo.pair_base += f.npairs_hi; lo.unit_map += 2 * f.npairs_hi; lo.npairs = f.npairs - f.npairs_hi;
+  if (lo.stats) lo.stats += (size_t)(f.npairs_hi / 8) * 4;
+  int nb_hi = hi.npairs / 8, nb_lo = (lo.npairs + 15) / 16;
+  if (!getenv("BNMTF_FAST_NW16")) { hi = f; nb_hi = (f.npairs + 7) / 8; nb_lo = 0; }   // default: 8-wave blocks only (16-wave blocks spill; kept for experiments)
+#define BNMTF_L(NXV, MODEV)                                                   \
+  do {                                                                        \
+    launch_inst<NXV, MODEV, 8>(a, hi, nb_hi, lds_bytes, st);                  \
+    launch_inst<NXV, MODEV, 16>(a, lo, nb_lo, lds_bytes, st);                 \
+  } while (0)
+  if (a.mode == kSweepDraw) { if (nx == 1) BNMTF_L(1, kSweepDraw); else BNMTF_L(2, kSweepDraw); }
+  else                      { if (nx == 1) BNMTF_L(1, kSweepMode); else BNMTF_L(2, kSweepMode); }
+#undef BNMTF_L
 }
 
 }  // namespace bnmtf

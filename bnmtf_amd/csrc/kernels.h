@@ -73,10 +73,12 @@ struct FastArgs {
   const uint32_t* pair_E;      // [npairs] slots of the pair (max of its two units)
   const uint32_t* pair_base;   // [npairs] first slot row of the pair
   const uint32_t* off;         // [(base+s)*64 + lane] inner index j (j mod 32 == lane mod 32) or mz + lane%32
-  int npairs;                  // pairs in descending slot-count order; block b owns pairs [8b, 8b+8)
+  int npairs;                  // pairs in descending slot-count order
+  int npairs_hi;               // leading pairs with more than 32 slots (padded to a multiple of 16): 8-wave blocks; the rest 16-wave blocks
   int mz, pw;                  // inner extent rounded up to 32 (sentinel zero words at mz..mz+31); panel floats pw = round_up(mz+32, 256)
   const float* XoT; int ldT_o;   // other factor transposed [KP][ldT_o]
   const float* XoT2; int ld2_o;  // other factor, column pairs interleaved [KP/2][ld2_o][2]
+  int dbg;                     // timing experiments only (BNMTF_SWEEP_DBG): 1 no restaging, 2 no slot loops, 4 no sampler
   double* stats;               // [blocks][4] partial (sum P.X', sum_miss q, sum_miss q^2) or null
 };
 constexpr int kFastMaxSlots = 56;   // blocks whose fullest pair needs more slots per lane go to the generic kernel
@@ -93,7 +95,8 @@ struct PostArgs {
   const float* S2; float* S2T; double* s2part; double* colsum2;
 };
 void launch_post(const PostArgs& a, hipStream_t st);
-inline int post_blocks(int rows) { return (rows + 127) / 128; }
+constexpr int kPostRows = 32;
+inline int post_blocks(int rows) { return (rows + kPostRows - 1) / kPostRows; }
 
 // ---------------------------------------------------------------------------
 // end of iteration: masked SSE from Gram identities, tau draw, metrics record
