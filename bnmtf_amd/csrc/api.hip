@@ -97,7 +97,7 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
       E = std::max(2, (E + 1) & ~1);
       int emax = 0;
       for (int r = 0; r < 32; ++r) emax = std::max(emax, (int)L[r].size());
-      if (!getenv("BNMTF_BALANCE")) E = emax;       // default: conflict-free layout (measured faster than the balanced one)
+      if (!getenv("BNMTF_BALANCE")) E = emax;       // default: pad every lane to the fullest residue class (conflict-free; measured faster than the balanced layout, which BNMTF_BALANCE=1 selects for experiments)
       if (emax <= E) { E = std::max(2, (emax + 1) & ~1); }
       else {
         overflow.clear();

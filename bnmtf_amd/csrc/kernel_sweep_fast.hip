@@ -146,12 +146,16 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
   static_assert(EM % 2 == 0, "slots are processed in pairs");
   constexpr int EH = EM / 2;
   uint32_t off[EM];
-  f32x2 q2[EH], vp2[EH];                   // slots (2h, 2h+1) share a register pair: packed f32 FMAs
+  constexpr bool REGATHER = (NW == 16);     // 16-wave blocks: 128-VGPR budget, no room for the previous column's values
+  constexpr int EV = REGATHER ? 1 : EH;
+  f32x2 q2[EH], vp2[EV];                   // slots (2h, 2h+1) share a register pair: packed f32 FMAs
 #pragma unroll
   for (int s = 0; s < EM; ++s)
     off[s] = (s < E) ? f.off[((size_t)base + s) * 64 + lane] : (uint32_t)(f.mz + l5);   // sentinel: a zero word on bank l5
 #pragma unroll
-  for (int h = 0; h < EH; ++h) { q2[h] = f32x2{0.f, 0.f}; vp2[h] = f32x2{0.f, 0.f}; }
+  for (int h = 0; h < EH; ++h) q2[h] = f32x2{0.f, 0.f};
+#pragma unroll
+  for (int h = 0; h < EV; ++h) vp2[h] = f32x2{0.f, 0.f};
   for (int t = tid; t < KP * KP; t += NW * 64) Cs[t] = a.C32[t];
 
   // hoisted Philox: candidates 0..kHoist-1 of columns l5 (+32)
@@ -181,16 +185,27 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
       const float xs0 = (NX == 2 && k0 >= 32) ? x[NX - 1] : x[0];
       const float x0 = half_bcast(xs0, k0 & 31, half), x1 = half_bcast(xs0, k1 & 31, half);
       const f32x2 x01 = {x0, x1};
+      if (REGATHER) {
 #pragma unroll
-      for (int h = 0; h < EH; ++h) {          // (q2[h], vp2[h]) = (even col, odd col) partial sums of slots 2h, 2h+1
-        const float2 va = cur[off[2 * h]], vb = cur[off[2 * h + 1]];
-        q2[h] = pk_fma(f32x2{va.x, va.y}, x01, q2[h]);
-        vp2[h] = pk_fma(f32x2{vb.x, vb.y}, x01, vp2[h]);
+        for (int h = 0; h < EH; ++h) {
+          const float2 va = cur[off[2 * h]], vb = cur[off[2 * h + 1]];
+          q2[h] = pk_fma(f32x2{va.x, vb.x}, f32x2{x0, x0}, q2[h]);
+          q2[h] = pk_fma(f32x2{va.y, vb.y}, f32x2{x1, x1}, q2[h]);
+        }
+      } else {
+#pragma unroll
+        for (int h = 0; h < EH; ++h) {          // (q2[h], vp2[h]) = (even col, odd col) partial sums of slots 2h, 2h+1
+          const float2 va = cur[off[2 * h]], vb = cur[off[2 * h + 1]];
+          q2[h] = pk_fma(f32x2{va.x, va.y}, x01, q2[h]);
+          vp2[h % EV] = pk_fma(f32x2{vb.x, vb.y}, x01, vp2[h % EV]);
+        }
       }
       __syncthreads();
     }
+    if (!REGATHER) {
 #pragma unroll
-    for (int h = 0; h < EH; ++h) { q2[h] = f32x2{q2[h].x + q2[h].y, vp2[h].x + vp2[h].y}; vp2[h] = f32x2{0.f, 0.f}; }
+      for (int h = 0; h < EH; ++h) { q2[h] = f32x2{q2[h].x + q2[h].y, vp2[h % EV].x + vp2[h % EV].y}; vp2[h % EV] = f32x2{0.f, 0.f}; }
+    }
   }
 
   // ------------------------------------------------------------ the K sequential columns
@@ -209,11 +224,11 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
 #pragma unroll
     for (int h = 0; h < EH; ++h) {
       const f32x2 v = {cur[off[2 * h]], cur[off[2 * h + 1]]};
-      const f32x2 qs = pk_fma(dp2, vp2[h], q2[h]);    // column k-1's update, applied late
+      const f32x2 qs = REGATHER ? q2[h] : pk_fma(dp2, vp2[h % EV], q2[h]);    // column k-1's update, applied late
       const f32x2 t = pk_fma(nxk2, v, qs);
       corr2[h & 1] = pk_fma(t, v, corr2[h & 1]);
       asq2[h & 1] = pk_fma(v, v, asq2[h & 1]);
-      q2[h] = qs; vp2[h] = v;
+      if (!REGATHER) { q2[h] = qs; vp2[h % EV] = v; }
     }
     float corr_t = (corr2[0].x + corr2[0].y) + (corr2[1].x + corr2[1].y);
     float asq_t = (asq2[0].x + asq2[0].y) + (asq2[1].x + asq2[1].y);
@@ -265,6 +280,11 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
 #pragma unroll
     for (int nx = 0; nx < NX; ++nx)
       if (l5 + 32 * nx == k) x[nx] = xnew;
+    if (REGATHER) {                         // q += d_k v_k now, re-reading the panel that is still resident
+      const f32x2 dk2 = {dprev, dprev};
+#pragma unroll
+      for (int h = 0; h < EH; ++h) q2[h] = pk_fma(dk2, f32x2{cur[off[2 * h]], cur[off[2 * h + 1]]}, q2[h]);
+    }
     __syncthreads();
   }
 
@@ -280,7 +300,8 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
     for (int nx = 0; nx < NX; ++nx) px += (double)p[nx] * (double)x[nx];
 #pragma unroll
     for (int h = 0; h < EH; ++h) {
-      const double qa = (double)fmaf(dprev, vp2[h].x, q2[h].x), qb = (double)fmaf(dprev, vp2[h].y, q2[h].y);
+      const double qa = REGATHER ? (double)q2[h].x : (double)fmaf(dprev, vp2[h % EV].x, q2[h].x);
+      const double qb = REGATHER ? (double)q2[h].y : (double)fmaf(dprev, vp2[h % EV].y, q2[h].y);
       sq += qa + qb; sq2 += qa * qa + qb * qb;
     }
     px = half_sum_d(px); sq = half_sum_d(sq); sq2 = half_sum_d(sq2);
@@ -340,7 +361,7 @@ void launch_sweep_fast(const SweepArgs& a, const FastArgs& f, hipStream_t st) {
   lo.pair_E += f.npairs_hi; lo.pair_base += f.npairs_hi; lo.unit_map += 2 * f.npairs_hi; lo.npairs = f.npairs - f.npairs_hi;
   if (lo.stats) lo.stats += (size_t)(f.npairs_hi / 8) * 4;
   int nb_hi = hi.npairs / 8, nb_lo = (lo.npairs + 15) / 16;
-  if (!getenv("BNMTF_FAST_NW16")) { hi = f; nb_hi = (f.npairs + 7) / 8; nb_lo = 0; }   // default: 8-wave blocks only (16-wave blocks spill; kept for experiments)
+  if (!getenv("BNMTF_FAST_NW16")) { hi = f; nb_hi = (f.npairs + 7) / 8; nb_lo = 0; }   // default: 8-wave blocks only; the 16-wave variant (one resident block of 32 units, balanced slots, re-gather) measured slower (464 vs 364 us) and is kept for experiments
 #define BNMTF_L(NXV, MODEV)                                                   \
   do {                                                                        \
     launch_inst<NXV, MODEV, 8>(a, hi, nb_hi, lds_bytes, st);                  \
