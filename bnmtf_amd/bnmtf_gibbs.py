@@ -1,0 +1,178 @@
+"""Drop-in for code/models/bnmtf_gibbs_optimised.py (class bnmtf_gibbs_optimised): Gibbs sampler
+for Bayesian non-negative matrix tri-factorisation R ~ F.S.G^T on an MI355X.
+
+    BNMTF = bnmtf_gibbs_optimised(R, M, K, L, priors)
+    BNMTF.initialise(init_S, init_FG)      # init_S: 'random'|'exp'; init_FG: 'random'|'exp'|'kmeans'
+    BNMTF.run(iterations)                  # -> (all_F, all_S, all_G, all_tau)
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from ._base import DeviceModel, broadcast_lambda, check_R_M, metrics_from_sums
+from .kmeans import KMeans
+
+
+class bnmtf_gibbs_optimised(DeviceModel):
+    def __init__(self, R, M, K, L, priors, *, seed=None, device=0, verbose=True, rank=0, world=1, comm_id=None):
+        self.R = np.array(R, dtype=float)
+        self.M = np.array(M, dtype=float)
+        self.K = K
+        self.L = L
+        check_R_M(self.R, self.M)
+        (self.I, self.J) = self.R.shape
+        self.size_Omega = self.M.sum()
+        self.alpha, self.beta = float(priors['alpha']), float(priors['beta'])
+        self.lambdaF = broadcast_lambda(priors['lambdaF'], (self.I, self.K), "lambdaF")
+        self.lambdaS = broadcast_lambda(priors['lambdaS'], (self.K, self.L), "lambdaS")
+        self.lambdaG = broadcast_lambda(priors['lambdaG'], (self.J, self.L), "lambdaG")
+        self.verbose = verbose
+        self._init_device(seed, device, rank, world, comm_id)
+
+    def _lambda_arrays(self):
+        return self.lambdaF, self.lambdaG, self.lambdaS
+
+    def train(self, init, iterations):
+        """bnmtf_gibbs_optimised.py:100-102 (as written there: initialise(init=init) is not a valid
+        keyword of initialise and raises TypeError in the reference too)."""
+        self.initialise(init=init)
+        return self.run(iterations)
+
+    def initialise(self, init_S='random', init_FG='random'):
+        """:106-134."""
+        assert init_S in ['random', 'exp'], "Unknown initialisation option for S: %s. Should be 'random' or 'exp'." % init_S
+        assert init_FG in ['random', 'exp', 'kmeans'], "Unknown initialisation option for S: %s. Should be 'random', 'exp', or 'kmeans." % init_FG
+        self.S = 1. / self.lambdaS
+        if init_S == 'random':
+            self.S = np.random.exponential(scale=1.0 / self.lambdaS)
+        self.F, self.G = 1. / self.lambdaF, 1. / self.lambdaG
+        if init_FG == 'random':
+            self.F = np.random.exponential(scale=1.0 / self.lambdaF)
+            self.G = np.random.exponential(scale=1.0 / self.lambdaG)
+        elif init_FG == 'kmeans':
+            if self.verbose: print("Initialising F using KMeans.")
+            kmeans_F = KMeans(self.R, self.M, self.K)
+            kmeans_F.initialise()
+            kmeans_F.cluster()
+            self.F = kmeans_F.clustering_results + 0.2
+            if self.verbose: print("Initialising G using KMeans.")
+            kmeans_G = KMeans(self.R.T, self.M.T, self.L)
+            kmeans_G.initialise()
+            kmeans_G.cluster()
+            self.G = kmeans_G.clustering_results + 0.2
+        self.tau = self.alpha_s() / self.beta_s()
+
+    def _push(self):
+        _lib.check(_lib.lib().bnmtf_set_state(self._handle(), _lib.ptr(_lib.f64(self.F)), _lib.ptr(_lib.f64(self.S)),
+                                              _lib.ptr(_lib.f64(self.G)), float(getattr(self, "tau", 1.0))))
+
+    def _pull(self):
+        F = np.zeros((self.I, self.K)); S = np.zeros((self.K, self.L)); G = np.zeros((self.J, self.L)); tau = C.c_double()
+        _lib.check(_lib.lib().bnmtf_get_state(self._handle(), _lib.ptr(F), _lib.ptr(S), _lib.ptr(G), C.byref(tau)))
+        self.F, self.S, self.G, self.tau = F, S, G, tau.value
+
+    def run(self, iterations, update='draw', store_samples=True):
+        """:138-180."""
+        it = int(iterations)
+        self._push()
+        F_out = np.zeros((it, self.I, self.K), dtype=np.float32) if store_samples else None
+        S_out = np.zeros((it, self.K, self.L), dtype=np.float32) if store_samples else None
+        G_out = np.zeros((it, self.J, self.L), dtype=np.float32) if store_samples else None
+        taus = np.zeros(it); perf = np.zeros((it, 3)); times = np.zeros(it)
+        _lib.check(_lib.lib().bnmtf_gibbs_run(self._handle(), it, _lib.UPDATE_MODE if update == 'mode' else _lib.UPDATE_DRAW,
+                                              _lib.ptr(F_out), _lib.ptr(S_out), _lib.ptr(G_out), _lib.ptr(taus), _lib.ptr(perf), _lib.ptr(times)))
+        self._pull()
+        self.all_F = F_out.astype(np.float64) if store_samples else np.zeros((0, self.I, self.K))
+        self.all_S = S_out.astype(np.float64) if store_samples else np.zeros((0, self.K, self.L))
+        self.all_G = G_out.astype(np.float64) if store_samples else np.zeros((0, self.J, self.L))
+        self.all_tau = taus
+        self.all_times = list(times)
+        self.all_performances = {'MSE': list(perf[:, 0]), 'R^2': list(perf[:, 1]), 'Rp': list(perf[:, 2])}
+        if self.verbose:
+            for i in range(it):
+                print("Iteration %s. MSE: %s. R^2: %s. Rp: %s." % (i + 1, perf[i, 0], perf[i, 1], perf[i, 2]))
+        return (self.all_F, self.all_S, self.all_G, self.all_tau)
+
+    def triple_dot(self, M1, M2, M3):
+        """:184-185 (host utility on explicit arrays)."""
+        return np.dot(M1, np.dot(M2, M3))
+
+    def alpha_s(self):
+        return self.alpha + self.size_Omega / 2.0
+
+    def beta_s(self):
+        """:192-193."""
+        self._push()
+        out = C.c_double()
+        _lib.check(_lib.lib().bnmtf_beta_s(self._handle(), C.byref(out)))
+        return out.value
+
+    def _cond(self, which, k, l, n):
+        self._push()
+        numer = np.zeros(n); tauk = np.zeros(n)
+        _lib.check(_lib.lib().bnmtf_cond_params(self._handle(), which, int(k), int(l), _lib.ptr(numer), _lib.ptr(tauk)))
+        return numer, tauk
+
+    def tauF(self, k):
+        return self._cond(0, k, 0, self.I)[1]
+
+    def muF(self, tauFk, k):
+        return 1. / np.asarray(tauFk, dtype=float) * self._cond(0, k, 0, self.I)[0]
+
+    def tauS(self, k, l):
+        return float(self._cond(1, k, l, 1)[1][0])
+
+    def muS(self, tauSkl, k, l):
+        return 1. / tauSkl * float(self._cond(1, k, l, 1)[0][0])
+
+    def tauG(self, l):
+        return self._cond(2, 0, l, self.J)[1]
+
+    def muG(self, tauGl, l):
+        return 1. / np.asarray(tauGl, dtype=float) * self._cond(2, 0, l, self.J)[0]
+
+    def approx_expectation(self, burn_in, thinning):
+        """:216-223."""
+        indices = range(burn_in, len(self.all_F), thinning)
+        exp_F = np.array([self.all_F[i] for i in indices]).sum(axis=0) / float(len(indices))
+        exp_S = np.array([self.all_S[i] for i in indices]).sum(axis=0) / float(len(indices))
+        exp_G = np.array([self.all_G[i] for i in indices]).sum(axis=0) / float(len(indices))
+        exp_tau = sum([self.all_tau[i] for i in indices]) / float(len(indices))
+        return (exp_F, exp_S, exp_G, exp_tau)
+
+    def predict(self, M_pred, burn_in, thinning):
+        """:226-232."""
+        (exp_F, exp_S, exp_G, _) = self.approx_expectation(burn_in, thinning)
+        return metrics_from_sums(self._metric_sums(M_pred, exp_F, exp_S, exp_G))
+
+    def predict_while_running(self):
+        """:234-239."""
+        return metrics_from_sums(self._metric_sums(None, self.F, self.S, self.G))
+
+    def quality(self, metric, burn_in, thinning):
+        """:262-280."""
+        assert metric in ['loglikelihood', 'BIC', 'AIC', 'MSE', 'ELBO'], 'Unrecognised metric for model quality: %s.' % metric
+        (expF, expS, expG, exptau) = self.approx_expectation(burn_in, thinning)
+        log_likelihood = self.log_likelihood(expF, expS, expG, exptau)
+        npar = self.I * self.K + self.K * self.L + self.J * self.L
+        if metric == 'loglikelihood':
+            return log_likelihood
+        elif metric == 'BIC':
+            return - 2 * log_likelihood + npar * math.log(self.size_Omega)
+        elif metric == 'AIC':
+            return - 2 * log_likelihood + 2 * npar
+        elif metric == 'MSE':
+            return metrics_from_sums(self._metric_sums(None, expF, expS, expG))['MSE']
+        elif metric == 'ELBO':
+            return 0.
+
+    def log_likelihood(self, expF, expS, expG, exptau):
+        """:282-285."""
+        s = self._metric_sums(None, expF, expS, expG)
+        sse = s[2] - 2.0 * s[5] + s[4]
+        return self.size_Omega / 2. * (math.log(exptau) - math.log(2 * math.pi)) - exptau / 2. * sse
+
+
+bnmtf_gibbs = bnmtf_gibbs_optimised

@@ -288,7 +288,7 @@ static void enqueue_sweep(bnmtf_model* h, Dir& d, const Dir& other, SweepArgs& s
 static SweepArgs sweep_args(bnmtf_model* h, Dir& d, const Dir& other, int mode, uint32_t stream_id) {
   SweepArgs s;
   memset(&s, 0, sizeof(s));
-  s.n = d.n; s.n0 = d.n0; s.K = d.W; s.KP = d.KP; s.mode = mode; s.cond_k = -1;
+  s.n = d.n; s.n0 = d.n0; s.K = d.W; s.KP = d.KP; s.mode = mode; s.cond_k = -1; s.qinit_only = 0;
   s.slabs = d.slabs; s.split = d.split; s.n_pad = d.n_pad; s.lambda = d.lambda;
   s.Xself = d.X; s.XselfT = nullptr; s.ldT_self = d.ldT;
   s.XoT = other.XT; s.ldT_o = other.ldT; s.C32 = other.C32;
@@ -326,6 +326,8 @@ static int set_tau(bnmtf_model* h, double tau) {
   HIPCHK(hipStreamSynchronize(h->stream));
   return BNMTF_OK;
 }
+
+static int bnmtf_alloc_extras(bnmtf_model* h, const double* lambdaS);
 
 static int ensure_rec(bnmtf_model* h, size_t n) {
   if (h->rec_cap >= n) return BNMTF_OK;
@@ -413,6 +415,7 @@ int bnmtf_create(const bnmtf_problem* p, bnmtf_handle* out) {
   if ((rcode = dalloc(&h->tau_f, 1))) return fail(rcode);
   if ((rcode = dalloc(&h->acc, 4))) return fail(rcode);
   if (p->L > 0 && (rcode = dalloc(&h->S, (size_t)p->K * p->L))) return fail(rcode);
+  if (p->L > 0 && (rcode = bnmtf_alloc_extras(h, p->lambda_S))) return fail(rcode);
 
   if (p->world > 1) {
     if ((rcode = comm_create(&h->comm, p->comm_id, p->rank, p->world, h->stream))) return fail(rcode);
@@ -435,7 +438,8 @@ int bnmtf_destroy(bnmtf_handle h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->comm) comm_destroy(h->comm);
-  free_dir(h->rows); free_dir(h->cols);
+  free_dir(h->rows); free_dir(h->cols); free_dir(h->reff); free_dir(h->ceff);
+  dfree(h->slabsS); dfree(h->CfS); dfree(h->deltaS); dfree(h->s_partial); dfree(h->lambdaS); dfree(h->s_numer); dfree(h->s_taup);
   dfree(h->Rfull); dfree(h->Mtrain); dfree(h->Mscratch); dfree(h->Ad); dfree(h->Bd); dfree(h->out6);
   dfree(h->tau_d); dfree(h->tau_f); dfree(h->acc); dfree(h->rec); dfree(h->S);
   for (auto& pe : h->pending_events) { (void)hipEventDestroy(pe.second.first); (void)hipEventDestroy(pe.second.second); }
@@ -697,3 +701,5 @@ int bnmtf_gamma_sample(double alpha, double beta, uint64_t seed, uint64_t it, in
 }
 
 }  // extern "C"
+
+#include "api_models.inc"

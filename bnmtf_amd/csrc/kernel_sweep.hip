@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256) void sweep_generic_kernel(SweepArgs a) {
     for (int k = 0; k < K; ++k) qv = fmaf(__shfl(x, k, 64), a.XoT[(size_t)k * a.ldT_o + j], qv);
     q[e * 64] = qv;
   }
+  if (a.qinit_only) return;
 
   float mu_l = 0.f, tau_l = 0.f, var_l = 0.f;     // VB: per-lane (lane == k) outputs
   const int kbeg = a.cond_k >= 0 ? a.cond_k : 0, kend = a.cond_k >= 0 ? a.cond_k + 1 : K;

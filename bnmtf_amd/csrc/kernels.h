@@ -44,6 +44,7 @@ struct SweepArgs {
   int K, KP;                 // true and padded width
   int mode;                  // SweepMode
   int cond_k;                // >= 0: only evaluate column cond_k, write numer/tau, change nothing
+  int qinit_only;            // generic kernel: compute q = X_i . Xo_j on the missing entries and stop
   // numerators
   const float* slabs; int split, n_pad;
   const float* lambda;       // [n][KP] local
@@ -123,6 +124,35 @@ struct MetricArgs {
   double* out6;
 };
 void launch_metric_sums(const MetricArgs& a, hipStream_t st);
+
+// ---------------------------------------------------------------------------
+// BNMTF (kernel_bnmtf.hip)
+// ---------------------------------------------------------------------------
+struct SmallProductArgs {   // out = X . S (transposeS = 0, out width L) or X . S^T (transposeS = 1, out width K)
+  const float* X; int rows, KPin; const float* S; int K, L; int transposeS; float* out; int KPout;
+};
+void launch_small_product(const SmallProductArgs& a, hipStream_t st);
+void launch_cfs(const double* Cf64, int KPk, const float* S, int K, int L, float* CfS, hipStream_t st);
+struct SRowArgs {           // one row k of S: J-vectors h_k, w_k and per-block partial eta / Omega
+  int n, n0, k, K, L, KPk, KPl;
+  const float* G;                      // [J][KPl]
+  const float* FT; int ldT;            // F transposed [KPk][ldT]
+  const float* slabs; int split, n_pad;   // Pv = R~^T F partial slabs, width KPk
+  const uint32_t* slot_ptr; const uint32_t* idx; float* q;   // generic (64-wide) slots of the cols direction
+  const float* CfS;                    // [K][L] current Cf.S
+  float cfkk; const float* cfkk_ptr;   // Cf[k][k] (read on the device)
+  const float* delta_prev; int apply_prev;   // delta of row k-1: q += F_{i,k-1} (G_j . delta) before use
+  float* partial;                      // [blocks][L + L*L]
+};
+void launch_srow_gather(const SRowArgs& a, int blocks, hipStream_t st);
+struct SDrawArgs {
+  int k, K, L, KPk, nblocks, update, cond_l;
+  const float* partial; float* S; const float* lambdaS; const float* tau;
+  const double* Cf64; float* CfS; float* delta_out;
+  uint32_t key0, key1, it;
+  double* numer_out; double* tau_out;
+};
+void launch_srow_draw(const SDrawArgs& a, hipStream_t st);
 
 // small helpers
 void launch_sum_stats(const double* stats, int nblocks, double* acc, hipStream_t st);   // acc[0..2] += column sums of stats

@@ -90,6 +90,10 @@ struct bnmtf_model {
   bool use_fast = true, last_sweep_fast = false;   // fast sweep kernel when the shape allows it
   // BNMTF extras
   float* S = nullptr;            // [K][L] on device (row major, unpadded)
+  bnmtf::Dir reff, ceff;         // effective factors U_eff = F S (I x L), V_eff = G S^T (J x K): factor storage only
+  float *slabsS = nullptr, *CfS = nullptr, *deltaS = nullptr, *s_partial = nullptr, *lambdaS = nullptr;
+  double *s_numer = nullptr, *s_taup = nullptr;
+  int s_blocks = 0;
   // profiling
   bool profiling = false;
   double kernel_ms[BNMTF_KERNEL_COUNT] = {0};

@@ -163,6 +163,7 @@ int bnmtf_gamma_sample(double alpha, double beta, uint64_t seed, uint64_t it, in
 #define BNMTF_KERNEL_GEMM_COLS 1   /* Pv = R~^T . U    ("the U^T.R step")          */
 #define BNMTF_KERNEL_SWEEP_ROWS 2
 #define BNMTF_KERNEL_SWEEP_COLS 3
+#define BNMTF_KERNEL_SWEEP_S 4      /* BNMTF: the K*L sequential S entries */
 #define BNMTF_KERNEL_COUNT 8
 /* when enabled, run() brackets each launch of the listed kernels with hipEvents
  * on the handle's stream; totals are read back with bnmtf_kernel_stats. */

@@ -1,0 +1,107 @@
+"""BNMTF Gibbs on the device vs the reference-generated vectors and the oracle."""
+import numpy as np
+import pytest
+
+from bnmtf_amd import bnmtf_gibbs_optimised
+from oracle import bnmtf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _pri(c):
+    return dict(alpha=float(c["alpha"]), beta=float(c["beta"]), lambdaF=c["lambdaF"], lambdaS=c["lambdaS"], lambdaG=c["lambdaG"])
+
+
+def _model(c, **kw):
+    b = bnmtf_gibbs_optimised(c["R"], c["M"], int(c["K"]), int(c["L"]), _pri(c), verbose=False, **kw)
+    b.F, b.S, b.G, b.tau = c["F"].copy(), c["S"].copy(), c["G"].copy(), float(c["tau"])
+    return b
+
+
+@pytest.mark.parametrize("name", ["t5x3", "toy", "r37x29"])
+def test_conditional_parameters_match_reference(golden, name):
+    """tauF/muF, tauS/muS, tauG/muG (bnmtf_gibbs_optimised.py:195-211) through the hot-path kernels.
+    mu tolerances are absolute, scaled by the size of the cancelling terms (fp32 products of O(|R| |F| |G|))."""
+    c = golden("bnmtf_gibbs_cond.npz").case(name)
+    b = _model(c)
+    K, L = b.K, b.L
+    M, R, F, S, G, tau = c["M"], c["R"], c["F"], c["S"], c["G"], float(c["tau"])
+    assert abs(b.beta_s() - float(c["beta_s"])) <= 2e-6 * abs(float(c["beta_s"]))
+    P = np.abs(F) @ np.abs(S) @ np.abs(G).T
+    for k in range(K):
+        np.testing.assert_allclose(b.tauF(k), c["tauF"][k], rtol=5e-6)
+        sg = np.abs(S[k] @ G.T)
+        sc = tau * ((M * (np.abs(R) + P)) @ sg) / c["tauF"][k]
+        assert (np.abs(b.muF(c["tauF"][k], k) - c["muF"][k]) <= 3e-5 * sc + 1e-6).all()
+        for l in range(L):
+            assert abs(b.tauS(k, l) - c["tauS"][k, l]) <= 1e-5 * c["tauS"][k, l]
+            sc = tau * (M * (np.abs(R) + P) * np.outer(np.abs(F[:, k]), np.abs(G[:, l]))).sum() / c["tauS"][k, l]
+            assert abs(b.muS(c["tauS"][k, l], k, l) - c["muS"][k, l]) <= 3e-5 * sc + 1e-6
+    for l in range(L):
+        np.testing.assert_allclose(b.tauG(l), c["tauG"][l], rtol=5e-6)
+        fs = np.abs(F @ S[:, l])
+        sc = tau * ((M * (np.abs(R) + P)).T @ fs) / c["tauG"][l]
+        assert (np.abs(b.muG(c["tauG"][l], l) - c["muG"][l]) <= 3e-5 * sc + 1e-6).all()
+    p = b.predict_while_running()
+    np.testing.assert_allclose([p["MSE"], p["R^2"]], c["perf"][:2], rtol=3e-6)
+    b.all_F, b.all_S, b.all_G, b.all_tau = list(c["all_F"]), list(c["all_S"]), list(c["all_G"]), list(c["all_tau"])
+    pp = b.predict(c["M_test"], 2, 3)
+    np.testing.assert_allclose([pp["MSE"], pp["R^2"], pp["Rp"]], c["predict"], rtol=3e-6)
+    q = [b.quality(m, 2, 3) for m in ["loglikelihood", "BIC", "AIC", "MSE", "ELBO"]]
+    np.testing.assert_allclose(q, c["quality"], rtol=3e-6)
+
+
+@pytest.mark.parametrize("fast", [True, False])
+@pytest.mark.parametrize("name", ["toy", "r37x29"])
+def test_mode_update_trajectory_matches_oracle(golden, name, fast):
+    """Deterministic parity of the whole F / S / G / tau data path (draws replaced by the mode)."""
+    c = golden("bnmtf_gibbs_cond.npz").case(name)
+    o = O.BNMTFGibbsOracle(c["R"], c["M"], int(c["K"]), int(c["L"]), _pri(c))
+    o.F, o.S, o.G, o.tau = c["F"].copy(), c["S"].copy(), c["G"].copy(), float(c["tau"])
+    o.run(6, draw=False)
+    b = _model(c)
+    b.set_sweep_path(fast)
+    b.run(6, update='mode')
+    np.testing.assert_allclose(b.all_performances['MSE'], o.all_performances['MSE'], rtol=5e-4)
+    np.testing.assert_allclose(b.all_tau, o.all_tau, rtol=5e-4)
+    assert np.abs(b.all_S[0] - o.all_S[0]).max() < 5e-4 * max(1.0, np.abs(o.all_S[0]).max())
+    assert np.abs(b.all_F[0] - o.all_F[0]).max() < 5e-4 * max(1.0, np.abs(o.all_F[0]).max())
+    assert np.abs(b.all_G[0] - o.all_G[0]).max() < 5e-4 * max(1.0, np.abs(o.all_G[0]).max())
+
+
+def test_gibbs_draws_follow_oracle_and_reference_bands(golden):
+    t = golden("toy_data.npz").case("bnmtf")
+    g = golden("gibbs_trajectories.npz").case("bnmtf")
+    I, J = t["R"].shape; K = L = 5
+    pri = dict(alpha=1., beta=1., lambdaF=0.1 * np.ones((I, K)), lambdaS=0.1 * np.ones((K, L)), lambdaG=0.1 * np.ones((J, L)))
+    np.random.seed(3)
+    b = bnmtf_gibbs_optimised(t["R"], t["M"], K, L, pri, verbose=False, seed=21)
+    b.initialise('random', 'random')
+    o = O.BNMTFGibbsOracle(t["R"], t["M"], K, L, pri, seed=21)
+    o.F, o.S, o.G, o.tau = b.F.copy(), b.S.copy(), b.G.copy(), b.tau
+    o.run(3)
+    b.run(200)
+    # same Philox stream: first sweep agrees element-wise up to fp32 noise
+    d0 = np.abs(b.all_F[0] - o.all_F[0]) / (1e-3 + np.abs(o.all_F[0]))
+    assert np.mean(d0 < 2e-3) > 0.98
+    assert np.abs(b.all_S[0] - o.all_S[0]).max() < 5e-3 * np.abs(o.all_S[0]).max()
+    np.testing.assert_allclose(b.all_performances['MSE'][:2], o.all_performances['MSE'][:2], rtol=2e-3)
+    # converged level vs the seeded reference runs (tests/golden/make_golden.py)
+    mse = np.array(b.all_performances['MSE']); ref = g["mse"]
+    assert ref[:, 150:].mean(axis=1).min() * 0.9 < mse[150:].mean() < ref[:, 150:].mean(axis=1).max() * 1.1
+    p = b.predict_while_running()
+    assert abs(p["MSE"] - mse[-1]) < 5e-5 * mse[-1]
+    assert b.all_F.shape == (200, I, K) and b.all_S.shape == (200, K, L) and b.all_G.shape == (200, J, L)
+
+
+def test_kmeans_initialisation_runs():
+    from bnmtf_amd.synthetic import generate_bnmtf
+    R, M, _, _, _ = generate_bnmtf(60, 40, 3, 2, 0.1, seed_data=5, seed_mask=6)
+    pri = dict(alpha=1., beta=1., lambdaF=0.1, lambdaS=0.1, lambdaG=0.1)
+    b = bnmtf_gibbs_optimised(R, M, 3, 2, pri, verbose=False, seed=1)
+    import random; random.seed(0); np.random.seed(0)
+    b.initialise('random', 'kmeans')
+    assert set(np.unique(b.F)) <= {0.2, 1.2} and np.allclose(b.F.sum(axis=1), 1.0 + 0.2 * 3)
+    assert set(np.unique(b.G)) <= {0.2, 1.2}
+    b.run(5)
+    assert np.isfinite(b.all_performances['MSE']).all()
