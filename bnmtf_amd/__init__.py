@@ -6,5 +6,6 @@ no CPU fallback: every model method that computes goes through the library."""
 from ._lib import BnmtfError, device_count, lib, LIB_PATH, EXPORTS
 from .bnmf_gibbs import bnmf_gibbs_optimised, bnmf_gibbs
 from .bnmtf_gibbs import bnmtf_gibbs_optimised, bnmtf_gibbs
+from .bnmf_vb import bnmf_vb_optimised, bnmf_vb
 
-__all__ = ["bnmf_gibbs_optimised", "bnmf_gibbs", "bnmtf_gibbs_optimised", "bnmtf_gibbs", "device_count", "BnmtfError", "lib", "LIB_PATH", "EXPORTS"]
+__all__ = ["bnmf_gibbs_optimised", "bnmf_gibbs", "bnmtf_gibbs_optimised", "bnmtf_gibbs", "bnmf_vb_optimised", "bnmf_vb", "device_count", "BnmtfError", "lib", "LIB_PATH", "EXPORTS"]

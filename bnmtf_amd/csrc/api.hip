@@ -212,6 +212,7 @@ static void free_dir(Dir& d) {
   dfree(d.X); dfree(d.XT); dfree(d.C64); dfree(d.C32); dfree(d.colsum); dfree(d.colsum2);
   dfree(d.XT2); dfree(d.Cpart); dfree(d.spart); dfree(d.s2part); dfree(d.f_unit_map); dfree(d.f_pair_E);
   dfree(d.f_pair_base); dfree(d.f_off); dfree(d.stats); dfree(d.f_gen_units);
+  dfree(d.vb_stats);
   dfree(d.mu); dfree(d.tauq); dfree(d.var); dfree(d.S2); dfree(d.S2T); dfree(d.numer); dfree(d.taup);
 }
 
@@ -288,7 +289,7 @@ static void enqueue_sweep(bnmtf_model* h, Dir& d, const Dir& other, SweepArgs& s
 static SweepArgs sweep_args(bnmtf_model* h, Dir& d, const Dir& other, int mode, uint32_t stream_id) {
   SweepArgs s;
   memset(&s, 0, sizeof(s));
-  s.n = d.n; s.n0 = d.n0; s.K = d.W; s.KP = d.KP; s.mode = mode; s.cond_k = -1; s.qinit_only = 0;
+  s.n = d.n; s.n0 = d.n0; s.K = d.W; s.KP = d.KP; s.mode = mode; s.cond_k = -1; s.qinit_only = 0; s.only_k = -1; s.vb_moments = 1; s.vb_stats = nullptr;
   s.slabs = d.slabs; s.split = d.split; s.n_pad = d.n_pad; s.lambda = d.lambda;
   s.Xself = d.X; s.XselfT = nullptr; s.ldT_self = d.ldT;
   s.XoT = other.XT; s.ldT_o = other.ldT; s.C32 = other.C32;
@@ -441,6 +442,7 @@ int bnmtf_destroy(bnmtf_handle h) {
   free_dir(h->rows); free_dir(h->cols); free_dir(h->reff); free_dir(h->ceff);
   dfree(h->slabsS); dfree(h->CfS); dfree(h->deltaS); dfree(h->s_partial); dfree(h->lambdaS); dfree(h->s_numer); dfree(h->s_taup);
   dfree(h->Rfull); dfree(h->Mtrain); dfree(h->Mscratch); dfree(h->Ad); dfree(h->Bd); dfree(h->out6);
+  dfree(h->A2d); dfree(h->B2d); dfree(h->vb_rec);
   dfree(h->tau_d); dfree(h->tau_f); dfree(h->acc); dfree(h->rec); dfree(h->S);
   for (auto& pe : h->pending_events) { (void)hipEventDestroy(pe.second.first); (void)hipEventDestroy(pe.second.second); }
   for (auto e : h->event_pool) (void)hipEventDestroy(e);
@@ -643,7 +645,7 @@ int bnmtf_metric_sums(bnmtf_handle h, const uint8_t* Mp, const double* A, const 
     mask = h->Mscratch;
   }
   MetricArgs m;
-  m.R = h->Rfull; m.Mp = mask; m.I = I; m.J = J; m.A = h->Ad; m.B = h->Bd; m.K = Kc; m.out6 = h->out6;
+  m.R = h->Rfull; m.Mp = mask; m.I = I; m.J = J; m.A = h->Ad; m.B = h->Bd; m.K = Kc; m.out6 = h->out6; m.A2 = nullptr; m.B2 = nullptr;
   launch_metric_sums(m, h->stream);
   HIPCHK(hipMemcpyAsync(sums_out, h->out6, 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));

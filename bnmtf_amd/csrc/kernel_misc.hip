@@ -104,6 +104,58 @@ __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
     a.rec[4] = sse;
   }
 }
+// VB end of iteration (bnmf_vb_optimised.py:181-187, 213-215): exp_square_diff from Gram identities,
+// exptau = alpha_s / beta_s, training-mask metrics, and the O((I+J)K) sums elbo() needs.
+__global__ __launch_bounds__(256) void vb_finish_kernel(VbFinishArgs a) {
+  __shared__ double red[256];
+  const int KP = a.KP;
+  auto block_sum = [&](double v) {
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) { if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w]; __syncthreads(); }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+  };
+  double s = 0.0;
+  for (int t = threadIdx.x; t < KP * KP; t += 256) s = fma(a.Cr64[t], a.Cc64[t], s);
+  const double dot = block_sum(s);
+  double su[6], sv[6];
+  for (int c = 0; c < 6; ++c) {
+    double v = 0.0;
+    for (int b = threadIdx.x; b < a.nr; b += 256) v += a.stats_r[(size_t)b * 8 + c];
+    su[c] = block_sum(v);
+    v = 0.0;
+    for (int b = threadIdx.x; b < a.nc; b += 256) v += a.stats_c[(size_t)b * 8 + c];
+    sv[c] = block_sum(v);
+  }
+  if (threadIdx.x == 0) {
+    double sp1 = 0.0, s22 = 0.0, sdd = 0.0;
+    for (int t = 0; t < KP; ++t) {
+      sp1 = fma(a.sr[t], a.sc[t], sp1);
+      s22 = fma(a.s2r[t], a.s2c[t], s22);
+      sdd = fma(a.Cr64[t * KP + t], a.Cc64[t * KP + t], sdd);
+    }
+    const double srp = a.acc[0], sp = sp1 - a.acc[1], spp = dot - a.acc[2];
+    const double n = a.n_obs;
+    const double sse = a.sumR2 - 2.0 * srp + spp;
+    const double esd = sse + (s22 - sv[4]) - (sdd - sv[5]);
+    const double alpha_s = a.alpha + 0.5 * n, beta_s = a.beta + 0.5 * esd;
+    const double exptau = alpha_s / beta_s;
+    *a.tau_d = exptau; *a.tau_f = (float)exptau;
+    const double ss_tot = a.sumR2 - a.sumR * a.sumR / n;
+    const double cov = srp - a.sumR * sp / n, vp = spp - sp * sp / n;
+    a.rec[0] = exptau; a.rec[1] = sse / n;
+    a.rec[2] = ss_tot != 0.0 ? 1.0 - sse / ss_tot : __longlong_as_double(0x7ff0000000000000LL);
+    a.rec[3] = cov / (sqrt(ss_tot) * sqrt(vp));
+    a.rec[4] = esd; a.rec[5] = beta_s;
+    for (int c = 0; c < 4; ++c) { a.rec[6 + c] = su[c]; a.rec[10 + c] = sv[c]; }
+  }
+}
+void launch_vb_finish(const VbFinishArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(vb_finish_kernel, dim3(1), dim3(256), 0, st, a);
+}
+
 void launch_finish(const FinishArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, a);
 }
@@ -114,7 +166,7 @@ void launch_finish(const FinishArgs& a, hipStream_t st) {
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void metric_kernel(MetricArgs a) {
   __shared__ double At[32 * 65], Bt[32 * 65];
-  __shared__ double red[6][256];
+  __shared__ double red[7][256];
   const int K = a.K;
   const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
   const int tid = threadIdx.y * 32 + threadIdx.x;
@@ -124,27 +176,48 @@ __global__ __launch_bounds__(256) void metric_kernel(MetricArgs a) {
     Bt[r * 65 + k] = (j0 + r < a.J) ? a.B[(size_t)(j0 + r) * K + k] : 0.0;
   }
   __syncthreads();
-  double s[6] = {0, 0, 0, 0, 0, 0};
+  double s[7] = {0, 0, 0, 0, 0, 0, 0};
   const int j = j0 + threadIdx.x;
   for (int rr = 0; rr < 4; ++rr) {
     const int il = threadIdx.y + 8 * rr, i = i0 + il;
     if (i < a.I && j < a.J && a.Mp[(size_t)i * a.J + j]) {
-      double pr = 0.0;
-      for (int k = 0; k < K; ++k) pr = fma(At[il * 65 + k], Bt[threadIdx.x * 65 + k], pr);
+      double pr = 0.0, sq = 0.0;
+      for (int k = 0; k < K; ++k) {
+        const double av = At[il * 65 + k], bv = Bt[threadIdx.x * 65 + k];
+        pr = fma(av, bv, pr);
+        sq = fma(av * av, bv * bv, sq);
+      }
       const double r = (double)a.R[(size_t)i * a.J + j];
-      s[0] += 1.0; s[1] += r; s[2] += r * r; s[3] += pr; s[4] += pr * pr; s[5] += r * pr;
+      s[0] += 1.0; s[1] += r; s[2] += r * r; s[3] += pr; s[4] += pr * pr; s[5] += r * pr; s[6] -= sq;
     }
   }
-  for (int m = 0; m < 6; ++m) red[m][tid] = s[m];
+  if (a.A2) {                                  // second-moment product A2_i . B2_j (VB exp_square_diff)
+    __syncthreads();
+    for (int t = tid; t < 32 * K; t += 256) {
+      const int r = t / K, k = t % K;
+      At[r * 65 + k] = (i0 + r < a.I) ? a.A2[(size_t)(i0 + r) * K + k] : 0.0;
+      Bt[r * 65 + k] = (j0 + r < a.J) ? a.B2[(size_t)(j0 + r) * K + k] : 0.0;
+    }
+    __syncthreads();
+    for (int rr = 0; rr < 4; ++rr) {
+      const int il = threadIdx.y + 8 * rr, i = i0 + il;
+      if (i < a.I && j < a.J && a.Mp[(size_t)i * a.J + j]) {
+        double pr = 0.0;
+        for (int k = 0; k < K; ++k) pr = fma(At[il * 65 + k], Bt[threadIdx.x * 65 + k], pr);
+        s[6] += pr;
+      }
+    }
+  }
+  for (int m = 0; m < 7; ++m) red[m][tid] = s[m];
   __syncthreads();
   for (int w = 128; w >= 1; w >>= 1) {
-    if (tid < w) for (int m = 0; m < 6; ++m) red[m][tid] += red[m][tid + w];
+    if (tid < w) for (int m = 0; m < 7; ++m) red[m][tid] += red[m][tid + w];
     __syncthreads();
   }
-  if (tid < 6) atomicAdd(a.out6 + tid, red[tid][0]);
+  if (tid < 7) atomicAdd(a.out6 + tid, red[tid][0]);
 }
 void launch_metric_sums(const MetricArgs& a, hipStream_t st) {
-  (void)hipMemsetAsync(a.out6, 0, 6 * sizeof(double), st);
+  (void)hipMemsetAsync(a.out6, 0, 8 * sizeof(double), st);
   dim3 grid((a.J + 31) / 32, (a.I + 31) / 32), block(32, 8);
   hipLaunchKernelGGL(metric_kernel, grid, block, 0, st, a);
 }

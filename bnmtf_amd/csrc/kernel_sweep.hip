@@ -62,19 +62,24 @@ __global__ __launch_bounds__(256) void sweep_generic_kernel(SweepArgs a) {
   if (a.qinit_only) return;
 
   float mu_l = 0.f, tau_l = 0.f, var_l = 0.f;     // VB: per-lane (lane == k) outputs
-  const int kbeg = a.cond_k >= 0 ? a.cond_k : 0, kend = a.cond_k >= 0 ? a.cond_k + 1 : K;
+  float var_in = 0.f;
+  if (MODE == kSweepVB && lane < KP) { mu_l = a.mu_self[gi * KP + lane]; tau_l = a.tau_self[gi * KP + lane]; var_l = var_in = a.var_self[gi * KP + lane]; }
+  const int only = a.cond_k >= 0 ? a.cond_k : a.only_k;
+  const int kbeg = only >= 0 ? only : 0, kend = only >= 0 ? only + 1 : K;
+  double e_quad = 0.0, e_lerfc = 0.0, e_ltau = 0.0, e_lamx = 0.0, e_q2 = 0.0, e_q3 = 0.0;   // VB: ELBO / exp_square_diff pieces
   for (int k = kbeg; k < kend; ++k) {
     const float xk = __shfl(x, k, 64);
     const float* vcol = a.XoT + (size_t)k * a.ldT_o;
-    float corr = 0.f, asq = 0.f;
+    float corr = 0.f, asq = 0.f, vsq = 0.f;
     for (int e = 0; e < E; ++e) {
       const uint32_t j = idx[e * 64];
       const float v = vcol[j];
       const float t = fmaf(-xk, v, q[e * 64]);
       corr = fmaf(t, v, corr);
-      if (MODE == kSweepVB) asq += a.S2oT[(size_t)k * a.ldT_o + j];
+      if (MODE == kSweepVB) { asq += a.S2oT[(size_t)k * a.ldT_o + j]; vsq = fmaf(v, v, vsq); }
       else asq = fmaf(v, v, asq);
     }
+    if (MODE == kSweepVB) vsq = wave_sum(vsq);
     const float ckl = (lane < KP) ? a.C32[(size_t)k * KP + lane] : 0.f;
     if (lane < KP && lane != k) corr = fmaf(-x, ckl, corr);
     corr = wave_sum(corr);
@@ -105,9 +110,18 @@ __global__ __launch_bounds__(256) void sweep_generic_kernel(SweepArgs a) {
       xnew = (tau_p > 0.f && mu > 0.f) ? mu : 0.f;
     } else {
       double e_, v_;
-      tn_moments((double)mu, (double)tau_p, &e_, &v_);
+      if (a.vb_moments) tn_moments((double)mu, (double)tau_p, &e_, &v_);
+      else { e_ = (double)xk; v_ = (double)__shfl(var_in, k, 64); }       // update_U(k) without update_exp_U(k)
       xnew = (float)e_;
       if (lane == k) { mu_l = mu; tau_l = tau_p; var_l = (float)v_; }
+      // pieces of elbo() (:163-177) and of exp_square_diff (:185-187) for this (unit, k)
+      const double dm = e_ - (double)mu;
+      e_quad += 0.5 * (double)tau_p * (v_ + dm * dm);
+      e_lerfc += log(0.5 * erfc(-(double)mu * sqrt((double)tau_p) * 0.7071067811865476));
+      e_ltau += log((double)tau_p);
+      e_lamx += (double)__shfl(lam, k, 64) * e_;
+      e_q2 += (v_ + e_ * e_) * (double)asq;                       // sum_miss S2self_k S2other_k
+      e_q3 += e_ * e_ * (double)vsq;                               // sum_miss exp_self_k^2 exp_other_k^2
     }
     const float delta = xnew - xk;
     if (lane == k) x = xnew;
@@ -124,6 +138,10 @@ __global__ __launch_bounds__(256) void sweep_generic_kernel(SweepArgs a) {
       const float s2 = var_l + x * x;
       a.S2self[gi * KP + lane] = s2;
     }
+  }
+  if (MODE == kSweepVB && a.vb_stats && lane == 0) {          // per-unit partial sums -> slab, summed by the VB finish kernel
+    double* o = a.vb_stats + (size_t)u * 8;
+    o[0] = e_quad; o[1] = e_lerfc; o[2] = e_ltau; o[3] = e_lamx; o[4] = e_q2; o[5] = e_q3;
   }
   if (a.acc) {
     double px = wave_sum_d((double)p * (double)x);

@@ -45,6 +45,9 @@ struct SweepArgs {
   int mode;                  // SweepMode
   int cond_k;                // >= 0: only evaluate column cond_k, write numer/tau, change nothing
   int qinit_only;            // generic kernel: compute q = X_i . Xo_j on the missing entries and stop
+  int only_k;                // >= 0 (VB hooks): update only this column (update_U(k) / update_V(k))
+  int vb_moments;            // VB: also refresh exp/var from the new mu/tau (update_exp_U(k))
+  double* vb_stats;          // VB: [n][8] per-unit ELBO / exp_square_diff partial sums (may be null)
   // numerators
   const float* slabs; int split, n_pad;
   const float* lambda;       // [n][KP] local
@@ -114,6 +117,16 @@ struct FinishArgs {
   double* rec;                // [5]: tau, MSE, R2, Rp, SSE  (slot of this iteration)
 };
 void launch_finish(const FinishArgs& a, hipStream_t st);
+struct VbFinishArgs {
+  const double* Cr64; const double* Cc64; const double* sr; const double* sc; const double* s2r; const double* s2c; int KP;
+  const double* acc;                   // [3] sum P.X', sum_miss q, sum_miss q^2 (cols sweep)
+  const double* stats_r; int nr;       // [nr][8] rows-sweep per-unit sums
+  const double* stats_c; int nc;       // [nc][8] cols-sweep per-unit sums
+  double n_obs, sumR, sumR2, alpha, beta;
+  double* tau_d; float* tau_f;         // exptau
+  double* rec;                         // [16]: exptau, MSE, R2, Rp, ESD, beta_s, then 4 ELBO sums for U and 4 for V
+};
+void launch_vb_finish(const VbFinishArgs& a, hipStream_t st);
 
 // ---------------------------------------------------------------------------
 // direct masked metric sums in fp64 (predict / validation path)
@@ -121,7 +134,8 @@ void launch_finish(const FinishArgs& a, hipStream_t st);
 struct MetricArgs {
   const float* R; const uint8_t* Mp; int I, J;
   const double* A; const double* B; int K;     // A [I][K], B [J][K]
-  double* out6;
+  const double* A2; const double* B2;          // optional (VB): second-moment factors; out[6] = sum_mask (A2_i.B2_j - sum_k A_ik^2 B_jk^2)
+  double* out6;                                // 8 doubles
 };
 void launch_metric_sums(const MetricArgs& a, hipStream_t st);
 

@@ -62,6 +62,7 @@ struct Dir {
   // VB only
   float *mu = nullptr, *tauq = nullptr, *var = nullptr, *S2 = nullptr, *S2T = nullptr;
   double* colsum2 = nullptr;
+  double* vb_stats = nullptr;           // VB: [n][8] per-unit partial sums
   // cond-params scratch
   double *numer = nullptr, *taup = nullptr;
   std::vector<uint32_t> obs_count;      // host, all nglob units
@@ -86,7 +87,8 @@ struct bnmtf_model {
   double* tau_d = nullptr; float* tau_f = nullptr;
   double* acc = nullptr;     // [4]
   double* rec = nullptr; size_t rec_cap = 0;
-  bool have_state = false;
+  bool have_state = false, vb_ready = false;
+  double *A2d = nullptr, *B2d = nullptr, *vb_rec = nullptr; size_t vb_rec_cap = 0;
   bool use_fast = true, last_sweep_fast = false;   // fast sweep kernel when the shape allows it
   // BNMTF extras
   float* S = nullptr;            // [K][L] on device (row major, unpadded)

@@ -132,10 +132,11 @@ int bnmf_vb_get_state(bnmtf_handle h, double* muU, double* tauU, double* expU, d
 int bnmf_vb_update(bnmtf_handle h, int which, int k, int moments);
 /* exp_square_diff() (:185-187) */
 int bnmf_vb_exp_square_diff(bnmtf_handle h, double* out);
-/* run(iterations) (:121-153).  exptau_out[n_iter] (all_exp_tau), perf_out[n_iter][3],
- * elbo_terms_out[n_iter][4] = {exp_square_diff, sum log(0.5 erfc(-muU sqrt(tauU/2))),
- * same for V, beta_s} -- the O(I*J) / O((I+J)K) pieces of elbo() (:163-177) that live
- * on the device; the host finishes the scalar algebra. times_out[n_iter]. */
+/* run(iterations) (:121-153).  exptau_out[n_iter] (all_exp_tau), perf_out[n_iter][3], times_out[n_iter],
+ * elbo_terms_out[n_iter][10] = the O(I*J) / O((I+J)K) pieces of elbo() (:163-177) that live on the device:
+ *   {exp_square_diff, beta_s,
+ *    sum tauU/2 (varU+(expU-muU)^2), sum log(0.5 erfc(-muU sqrt(tauU/2))), sum log tauU, sum lambdaU expU,
+ *    the same four for V};  the host finishes the scalar algebra (digamma, gammaln). */
 int bnmf_vb_run(bnmtf_handle h, int n_iter, double* exptau_out, double* perf_out,
                 double* elbo_terms_out, double* times_out);
 

@@ -1,0 +1,103 @@
+"""BNMF VB on the device: deterministic trajectory (init='exp') against the reference's own run
+(tests/golden/bnmf_vb.npz), and the reference's known-answer tests."""
+import math
+
+import numpy as np
+import pytest
+
+from bnmtf_amd import bnmf_vb_optimised
+
+pytestmark = pytest.mark.gpu
+
+
+def test_toy_trajectory_matches_reference(golden):
+    """Config-5 algorithm on config-1 data: MSE / exptau / ELBO per iteration vs the reference.
+    The q-parameters live on the device in fp32 (reductions fp64); 20 deterministic fixed-point
+    iterations amplify that rounding: rel 1e-3 on MSE and exptau, 5e-5 relative on the ELBO."""
+    g = golden("bnmf_vb.npz").case("toy")
+    t = golden("toy_data.npz").case("bnmf")
+    I, J = t["R"].shape; K = 10
+    b = bnmf_vb_optimised(t["R"], t["M"], K, dict(alpha=1., beta=1., lambdaU=0.1 * np.ones((I, K)), lambdaV=0.1 * np.ones((J, K))), verbose=False)
+    b.initialise('exp')
+    assert abs(b.exptau - float(g["init_exptau"])) < 2e-6 * b.exptau
+    np.testing.assert_allclose(b.expU, g["init_expU"], rtol=1e-9)
+    assert abs(b.exp_square_diff() - float(g["init_esd"])) < 2e-6 * float(g["init_esd"])
+    b.run(20)
+    np.testing.assert_allclose(b.all_performances['MSE'], g["mse"], rtol=1e-3)
+    np.testing.assert_allclose(b.all_performances['MSE'][:5], g["mse"][:5], rtol=2e-5)
+    np.testing.assert_allclose(b.all_exp_tau, g["exptau"], rtol=1e-3)
+    np.testing.assert_allclose(b.all_elbo, g["elbo"], rtol=5e-5)
+    for nm in ["expU", "expV", "muU", "muV", "tauU", "tauV"]:
+        ref = g["it20/" + nm]
+        assert np.abs(getattr(b, nm) - ref).max() < 2e-3 * np.abs(ref).max(), nm
+    assert abs(b.elbo() - g["elbo"][-1]) < 5e-5 * abs(g["elbo"][-1])
+    q = [b.quality(m) for m in ["loglikelihood", "BIC", "AIC", "MSE", "ELBO"]]
+    np.testing.assert_allclose(q, g["quality"], rtol=1e-3)
+    p = b.predict(t["M"])
+    np.testing.assert_allclose([p["MSE"], p["R^2"], p["Rp"]], g["final_perf"], rtol=1e-3)
+    assert len(b.all_times) == 20
+
+
+def test_ragged_case_matches_reference(golden):
+    g = golden("bnmf_vb.npz").case("r31x23")
+    K = 4
+    b = bnmf_vb_optimised(g["R"], g["M"], K, dict(alpha=2., beta=.5, lambdaU=g["lambdaU"], lambdaV=g["lambdaV"]), verbose=False)
+    b.initialise('exp', {"tauU": g["tauU0"], "tauV": g["tauV0"]})
+    b.run(10)
+    np.testing.assert_allclose(b.all_performances['MSE'], g["mse"], rtol=1e-3)
+    np.testing.assert_allclose(b.all_elbo, g["elbo"], rtol=1e-4)
+    assert np.abs(b.expU - g["it10/expU"]).max() < 2e-3 * np.abs(g["it10/expU"]).max()
+
+
+def test_known_answers_of_reference_tests():
+    """tests/code/test_bnmf_vb_optimised.py:218-311."""
+    I, J, K = 5, 3, 2
+    R = np.ones((I, J)); M = np.ones((I, J)); M[0, 0] = M[2, 2] = M[3, 1] = 0
+    lambdaU = 2 * np.ones((I, K)); lambdaV = 3 * np.ones((J, K))
+    pri = dict(alpha=3, beta=1, lambdaU=lambdaU, lambdaV=lambdaV)
+    b = bnmf_vb_optimised(R, M, K, pri, verbose=False)
+    b.expU = 1. / lambdaU; b.expV = 1. / lambdaV; b.varU = 2 * np.ones((I, K)); b.varV = 3 * np.ones((J, K))
+    assert abs(b.exp_square_diff() - 172.66666666666666) < 2e-5      # expV = 1/3 is rounded to fp32 on the device
+    b.update_tau()
+    assert b.alpha_s == 3 + 12. / 2. and abs(b.beta_s - (1 + 172.66666666666666 / 2.)) < 2e-5
+    for k in range(K):
+        b = bnmf_vb_optimised(R, M, K, pri, verbose=False)
+        b.muU = np.zeros((I, K)); b.tauU = np.zeros((I, K)); b.muV = np.zeros((J, K)); b.tauV = np.zeros((J, K))
+        b.expU = 1. / lambdaU; b.expV = 1. / lambdaV; b.varU = 2 * np.ones((I, K)); b.varV = 3 * np.ones((J, K))
+        b.exptau = 3.
+        b.update_U(k)
+        for i in range(I):
+            w = (M[i] * (b.expV[:, k] ** 2 + b.varV[:, k])).sum()
+            assert abs(b.tauU[i, k] - 3. * w) < 1e-5 * 3. * w
+            ref = (1. / (3. * w)) * (-2. + 3. * (M[i] * ((R[i] - b.expU[i] @ b.expV.T + b.expU[i, k] * b.expV[:, k]) * b.expV[:, k])).sum())
+            assert abs(b.muU[i, k] - ref) < 1e-5
+        b.update_V(k)
+        for j in range(J):
+            w = (M[:, j] * (b.expU[:, k] ** 2 + b.varU[:, k])).sum()
+            assert abs(b.tauV[j, k] - 3. * w) < 1e-5 * 3. * w
+    b = bnmf_vb_optimised(R, M, K, pri, verbose=False)
+    b.initialise()
+    assert abs(b.exptau - (3 + 12. / 2.) / (1 + 35.4113198623 / 2.)) < 1e-6
+    assert abs(b.explogtau - (2.1406414779556 - math.log(1 + 35.4113198623 / 2.))) < 1e-6
+    b.tauU = 4 * np.ones((I, K)); b.update_exp_U(0)
+    assert np.abs(b.expU[:, 0] - (0.5 + 0.5 * 0.2876155949126352)).max() < 1e-5
+    assert np.abs(b.varU[:, 0] - 0.25 * (1. - 0.37033832534958433)).max() < 1e-5
+    with pytest.raises(AssertionError) as e:
+        b.quality('FAIL')
+    assert str(e.value) == "Unrecognised metric for model quality: FAIL."
+
+
+def test_large_shape_identity():
+    """1536 x 1024, K=16: the Gram-identity exp_square_diff used inside run() equals the direct fp64 kernel."""
+    from bnmtf_amd.synthetic import generate_bnmf
+    I, J, K = 1536, 1024, 16
+    R, M, _, _ = generate_bnmf(I, J, K, 0.1, seed_data=7, seed_mask=8)
+    b = bnmf_vb_optimised(R, M, K, dict(alpha=1., beta=1., lambdaU=0.1, lambdaV=0.1), verbose=False)
+    b.initialise('exp')
+    b.run(15)
+    mse = b.all_performances['MSE']
+    assert mse[-1] < mse[0] / 100
+    esd = b.exp_square_diff()
+    assert abs(b.beta_s - (1. + 0.5 * esd)) < 5e-5 * b.beta_s
+    p = b.predict(M)
+    assert abs(p["MSE"] - mse[-1]) < 1e-4 * mse[-1]
