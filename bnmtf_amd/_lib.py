@@ -31,6 +31,7 @@ _SIGS = {
     "bnmtf_last_error": ([], C.c_char_p),
     "bnmtf_device_count": ([C.POINTER(C.c_int)], C.c_int),
     "bnmtf_comm_unique_id": ([_P], C.c_int),
+    "bnmtf_shard_range": ([C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)], C.c_int),
     "bnmtf_create": ([C.POINTER(Problem), C.POINTER(_P)], C.c_int),
     "bnmtf_destroy": ([_P], C.c_int),
     "bnmtf_sync": ([_P], C.c_int),

@@ -23,6 +23,9 @@ void set_error(const char* fmt, ...) {
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+}  // namespace bnmtf
+extern "C" int bnmtf_shard_range(int64_t n, int rank, int world, int64_t* first, int64_t* count);
+namespace bnmtf {
 
 template <typename T>
 static int dalloc(T** p, size_t count, bool zero = true) {
@@ -43,8 +46,11 @@ static void dfree(T*& p) {
 template <typename Get>
 static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const double* lambda, Get get) {
   d.nglob = nglob; d.m = m; d.W = W; d.KP = W <= 32 ? 32 : 64;
-  d.n0 = (int)(((int64_t)nglob * rank) / world);
-  d.n = (int)(((int64_t)nglob * (rank + 1)) / world) - d.n0;
+  {
+    int64_t first = 0, count = 0;
+    (void)bnmtf_shard_range(nglob, rank, world, &first, &count);
+    d.n0 = (int)first; d.n = (int)count;
+  }
   d.n_pad = round_up(std::max(d.n, 1), 128);
   // split of the inner dimension: aim at >= 2 blocks per CU, >= 64 inner rows per wave
   const int tiles = d.n_pad / 128;
@@ -357,6 +363,13 @@ int bnmtf_device_count(int* count) {
 }
 
 int bnmtf_comm_unique_id(uint8_t out[128]) { return comm_unique_id(out); }
+
+int bnmtf_shard_range(int64_t n, int rank, int world, int64_t* first, int64_t* count) {
+  if (world < 1 || rank < 0 || rank >= world || n < 0) { set_error("bad shard request"); return BNMTF_EINVAL; }
+  *first = n * rank / world;
+  *count = n * (rank + 1) / world - *first;
+  return BNMTF_OK;
+}
 
 int bnmtf_create(const bnmtf_problem* p, bnmtf_handle* out) {
   *out = nullptr;

@@ -69,6 +69,9 @@ typedef struct bnmtf_problem {
 int bnmtf_version(void);
 const char* bnmtf_last_error(void);
 int bnmtf_device_count(int* count);
+/* the contiguous block of `n` units (rows for the U/F sweep, columns for V/G) owned by `rank`:
+ * first = n*rank/world, count = n*(rank+1)/world - first.  Pure function, no GPU needed. */
+int bnmtf_shard_range(int64_t n, int rank, int world, int64_t* first, int64_t* count);
 /* rank 0 makes the id, the host code ships it to the other ranks */
 int bnmtf_comm_unique_id(uint8_t out[128]);
 

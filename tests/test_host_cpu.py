@@ -1,0 +1,160 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads and exports every symbol
+the header declares, the classes reproduce the reference's constructor contract (exact assertion
+messages), the NumPy-only post-run helpers, and failing loudly without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import bnmtf_amd
+from bnmtf_amd import _lib, bnmf_gibbs_optimised, bnmtf_gibbs_optimised, bnmf_vb_optimised
+from bnmtf_amd.comm import shard_range
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "bnmtf_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(bnmt?f_\w+)\s*\(", hdr, flags=re.M))
+    assert declared, "no declarations parsed"
+    lib = bnmtf_amd.lib()
+    for name in declared:
+        assert hasattr(lib, name), "libbnmtf_hip.so does not export %s" % name
+    assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
+    assert lib.bnmtf_version() >= 100
+
+
+def test_no_cpu_fallback_without_gpu():
+    if bnmtf_amd.device_count() > 0:
+        pytest.skip("a GPU is present")
+    R = np.ones((4, 3)); M = np.ones((4, 3))
+    b = bnmf_gibbs_optimised(R, M, 2, dict(alpha=1, beta=1, lambdaU=1., lambdaV=1.), verbose=False)
+    b.U = np.ones((4, 2)); b.V = np.ones((3, 2)); b.tau = 1.0
+    with pytest.raises(bnmtf_amd.BnmtfError):
+        b.run(1)
+    with pytest.raises(bnmtf_amd.BnmtfError):
+        b.beta_s()
+    from bnmtf_amd import distributions as D
+    with pytest.raises(bnmtf_amd.BnmtfError):
+        D.TN_vector_draw([1.0], [1.0])
+
+
+@pytest.mark.parametrize("cls", ["bnmf", "vb"])
+def test_constructor_contract_bnmf(cls):
+    """tests/code/test_bnmf_gibbs_optimised.py:14-105 (same text for bnmf_vb_optimised)."""
+    mk = (lambda R, M, K, p: bnmf_gibbs_optimised(R, M, K, p, verbose=False)) if cls == "bnmf" else \
+         (lambda R, M, K, p: bnmf_vb_optimised(R, M, K, p, verbose=False))
+    M = np.ones((2, 3)); I, J, K = 5, 3, 1
+    priors = {'alpha': 3, 'beta': 1, 'lambdaU': np.ones((I, K)), 'lambdaV': np.ones((J, K))}
+    with pytest.raises(AssertionError) as e:
+        mk(np.ones(3), M, K, priors)
+    assert str(e.value) == "Input matrix R is not a two-dimensional array, but instead 1-dimensional."
+    with pytest.raises(AssertionError) as e:
+        mk(np.ones((4, 3, 2)), M, K, priors)
+    assert str(e.value) == "Input matrix R is not a two-dimensional array, but instead 3-dimensional."
+    with pytest.raises(AssertionError) as e:
+        mk(np.ones((3, 2)), M, K, priors)
+    assert str(e.value) == "Input matrix R is not of the same size as the indicator matrix M: (3, 2) and (2, 3) respectively."
+    R4 = np.ones((2, 3))
+    with pytest.raises(AssertionError) as e:
+        mk(R4, M, K, {'alpha': 3, 'beta': 1, 'lambdaU': np.ones((3, 1)), 'lambdaV': np.ones((3, 1))})
+    assert str(e.value) == "Prior matrix lambdaU has the wrong shape: (3, 1) instead of (2, 1)."
+    with pytest.raises(AssertionError) as e:
+        mk(R4, M, K, {'alpha': 3, 'beta': 1, 'lambdaU': np.ones((2, 1)), 'lambdaV': np.ones((4, 1))})
+    assert str(e.value) == "Prior matrix lambdaV has the wrong shape: (4, 1) instead of (3, 1)."
+    pr = {'alpha': 3, 'beta': 1, 'lambdaU': np.ones((2, 1)), 'lambdaV': np.ones((3, 1))}
+    with pytest.raises(AssertionError) as e:
+        mk(R4, [[1, 1, 1], [0, 0, 0]], K, pr)
+    assert str(e.value) == "Fully unobserved row in R, row 1."
+    with pytest.raises(AssertionError) as e:
+        mk(R4, [[1, 1, 0], [1, 0, 0]], K, pr)
+    assert str(e.value) == "Fully unobserved column in R, column 2."
+    I, J, K = 3, 2, 2
+    R5 = 2 * np.ones((I, J)); M5 = np.ones((I, J))
+    b = mk(R5, M5, K, {'alpha': 3, 'beta': 1, 'lambdaU': 3., 'lambdaV': 4.})
+    assert np.array_equal(b.R, R5) and np.array_equal(b.M, M5) and (b.I, b.J, b.K) == (I, J, K)
+    assert b.size_Omega == I * J and b.alpha == 3 and b.beta == 1
+    assert np.array_equal(b.lambdaU, 3. * np.ones((I, K))) and np.array_equal(b.lambdaV, 4. * np.ones((J, K)))
+    # keyword form used by the cross-validation drivers (line_search_cross_validation.py:109-114)
+    b = (bnmf_gibbs_optimised if cls == "bnmf" else bnmf_vb_optimised)(R=R5, M=M5, K=K, priors={'alpha': 3, 'beta': 1, 'lambdaU': 3., 'lambdaV': 4.})
+    assert b.K == K
+
+
+def test_constructor_contract_bnmtf():
+    """tests/code/test_bnmtf_gibbs_optimised.py constructor checks."""
+    I, J, K, L = 5, 3, 1, 2
+    pri = {'alpha': 3, 'beta': 1, 'lambdaF': np.ones((I, K)), 'lambdaS': np.ones((K, L)), 'lambdaG': np.ones((J, L))}
+    with pytest.raises(AssertionError) as e:
+        bnmtf_gibbs_optimised(np.ones(3), np.ones((2, 3)), K, L, pri)
+    assert str(e.value) == "Input matrix R is not a two-dimensional array, but instead 1-dimensional."
+    R4 = np.ones((2, 3)); M = np.ones((2, 3))
+    with pytest.raises(AssertionError) as e:
+        bnmtf_gibbs_optimised(R4, M, K, L, {'alpha': 3, 'beta': 1, 'lambdaF': np.ones((3, 1)), 'lambdaS': np.ones((1, 2)), 'lambdaG': np.ones((3, 2))})
+    assert str(e.value) == "Prior matrix lambdaF has the wrong shape: (3, 1) instead of (2, 1)."
+    with pytest.raises(AssertionError) as e:
+        bnmtf_gibbs_optimised(R4, M, K, L, {'alpha': 3, 'beta': 1, 'lambdaF': np.ones((2, 1)), 'lambdaS': np.ones((2, 2)), 'lambdaG': np.ones((3, 2))})
+    assert str(e.value) == "Prior matrix lambdaS has the wrong shape: (2, 2) instead of (1, 2)."
+    with pytest.raises(AssertionError) as e:
+        bnmtf_gibbs_optimised(R4, M, K, L, {'alpha': 3, 'beta': 1, 'lambdaF': np.ones((2, 1)), 'lambdaS': np.ones((1, 2)), 'lambdaG': np.ones((4, 2))})
+    assert str(e.value) == "Prior matrix lambdaG has the wrong shape: (4, 2) instead of (3, 2)."
+    b = bnmtf_gibbs_optimised(R4, M, K, L, {'alpha': 3, 'beta': 1, 'lambdaF': 2., 'lambdaS': 3., 'lambdaG': 4.}, verbose=False)
+    assert np.array_equal(b.lambdaS, 3. * np.ones((K, L))) and b.L == L
+    with pytest.raises(AssertionError) as e:
+        b.initialise(init_S='nope')
+    assert str(e.value) == "Unknown initialisation option for S: nope. Should be 'random' or 'exp'."
+
+
+def test_postrun_host_helpers(golden):
+    """approx_expectation accepts lists (tests :240-267); compute_MSE/R2/Rp closed forms (:308-328)."""
+    I, J, K = 5, 3, 2
+    b = bnmf_gibbs_optimised(np.ones((I, J)), np.ones((I, J)), K, {'alpha': 3, 'beta': 1, 'lambdaU': 2., 'lambdaV': 3.}, verbose=False)
+    b.all_U = [np.ones((I, K)) * 3 * m ** 2 for m in range(1, 11)]
+    b.all_V = [np.ones((J, K)) * 2 * m ** 2 for m in range(1, 11)]
+    b.all_tau = [m ** 2 for m in range(1, 11)]
+    eU, eV, et = b.approx_expectation(2, 3)
+    assert et == (9. + 36. + 81.) / 3. and np.array_equal(eU, (9. + 36. + 81.) * np.ones((I, K)))
+    assert np.array_equal(eV, (9. + 36. + 81.) * (2. / 3.) * np.ones((J, K)))
+    R = np.array([[1, 2], [3, 4]], dtype=float); Mp = np.array([[0, 0], [1, 1]])
+    Rp = np.array([[500, 550], [1220, 1342]], dtype=float)
+    import math
+    assert b.compute_MSE(Mp, R, Rp) == (1217 ** 2 + 1338 ** 2) / 2.0
+    assert b.compute_R2(Mp, R, Rp) == 1. - (1217 ** 2 + 1338 ** 2) / (0.5 ** 2 + 0.5 ** 2)
+    assert b.compute_Rp(Mp, R, Rp) == 61. / (math.sqrt(.5) * math.sqrt(7442.))
+    with pytest.raises(AssertionError) as e:
+        b.initialise('nope')
+    assert str(e.value) == "Unknown initialisation option: nope. Should be 'random' or 'exp'."
+    with pytest.raises(AssertionError) as e:
+        b.quality('FAIL', 0, 1)
+    assert str(e.value) == "Unrecognised metric for model quality: FAIL."
+    from bnmtf_amd._base import metrics_from_sums
+    from oracle import bnmtf_oracle as O
+    c = golden("bnmf_gibbs_cond.npz").case("r37x29")
+    m = metrics_from_sums(O.metric_sums(c["M"], c["R"], c["U"] @ c["V"].T))
+    np.testing.assert_allclose([m["MSE"], m["R^2"], m["Rp"]], c["perf"], rtol=1e-9)
+
+
+def test_shard_ranges_partition_everything():
+    for n in (1, 7, 100, 8192, 8191):
+        for world in (1, 2, 3, 8):
+            if world > n:
+                continue
+            pos = 0
+            for r in range(world):
+                first, count = shard_range(n, r, world)
+                assert first == pos and count >= n // world
+                pos += count
+            assert pos == n
+
+
+def test_masked_kmeans_helper():
+    from bnmtf_amd.kmeans import KMeans
+    import random
+    rs = np.random.RandomState(0)
+    X = np.vstack([rs.normal(0, .1, (20, 6)), rs.normal(5, .1, (20, 6)), rs.normal(-5, .1, (20, 6))])
+    Mk = (rs.rand(60, 6) > 0.2).astype(float); Mk[:, 0] = 1
+    random.seed(1)
+    km = KMeans(X, Mk, 3); km.initialise(); km.cluster()
+    assert km.clustering_results.shape == (60, 3) and (km.clustering_results.sum(axis=1) == 1).all()
+    lab = km.clustering_results.argmax(axis=1)
+    assert len(set(lab[:20])) == 1 and len(set(lab[20:40])) == 1 and len(set(lab[40:])) == 1 and len(set(lab)) == 3

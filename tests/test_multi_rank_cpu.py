@@ -1,0 +1,106 @@
+"""world_size-2 (gloo, CPU) check of the multi-GPU scheme libbnmtf_hip.so implements with RCCL:
+rows of R split over the ranks for the U sweep, columns for the V sweep (bnmtf_shard_range), the
+freshly drawn factor blocks all-gathered after each half sweep, three scalars all-reduced for the
+Gram-identity SSE, tau drawn redundantly from the same Philox counter.  The per-shard arithmetic is
+the oracle's (no GPU here); what is verified is the partition / exchange / RNG-keying design:
+two ranks reproduce the single-process chain."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from bnmtf_amd.comm import shard_range
+from oracle import bnmtf_oracle as O
+from oracle import rng
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _problem():
+    rs = np.random.RandomState(11)
+    I, J, K = 23, 17, 4
+    R = rs.exponential(1.0, (I, K)) @ rs.exponential(1.0, (J, K)).T + rs.normal(0, 1, (I, J))
+    M = (rs.rand(I, J) > 0.25).astype(float); M[:, 0] = 1; M[0, :] = 1
+    pri = dict(alpha=1., beta=1., lambdaU=0.3, lambdaV=0.6)
+    U0 = rs.exponential(1.0, (I, K)); V0 = rs.exponential(1.0, (J, K))
+    return R, M, K, pri, U0, V0
+
+
+def _gather_blocks(local_block, n, cols, rank, world):
+    """all-gather of ragged row blocks (what comm_allgather_factor does with ncclAllGather / grouped broadcasts)"""
+    out = np.zeros((n, cols))
+    bufs = [None] * world
+    dist.all_gather_object(bufs, local_block)
+    for r in range(world):
+        f, c = shard_range(n, r, world)
+        out[f:f + c] = bufs[r]
+    return out
+
+
+def _sharded_run(rank, world, port, iters, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    R, M, K, pri, U0, V0 = _problem()
+    o = O.BNMFGibbsOracle(R, M, K, pri, seed=99)
+    o.U, o.V = U0.copy(), V0.copy()
+    o.tau = o.alpha_s() / o.beta_s()
+    I, J = R.shape
+    r0, nr = shard_range(I, rank, world); c0, nc = shard_range(J, rank, world)
+    rows = np.arange(r0, r0 + nr); cols = np.arange(c0, c0 + nc)
+    Mbar = 1.0 - M
+    taus, mses = [], []
+    for it in range(iters):
+        for k in range(K):                       # this rank's rows only; counters use GLOBAL row indices
+            t = o.tauU(k)[rows]; m = o.muU(o.tauU(k), k)[rows]
+            o.U[rows, k] = rng.tn_draw(m, t, rows, k, it, rng.STREAM_ROWS, o.seed)
+        o.U = _gather_blocks(o.U[rows], I, K, rank, world)
+        for k in range(K):
+            t = o.tauV(k)[cols]; m = o.muV(o.tauV(k), k)[cols]
+            o.V[cols, k] = rng.tn_draw(m, t, cols, k, it, rng.STREAM_COLS, o.seed)
+        Vloc = o.V[cols]
+        o.V = _gather_blocks(Vloc, J, K, rank, world)
+        # the three per-rank partial sums the cols sweep produces (over this rank's columns)
+        Pv = (M * R).T[cols] @ o.U                                   # R~^T U, own columns
+        qm = (Mbar * (o.U @ o.V.T))[:, cols]                         # q on the missing entries of own columns
+        acc = torch.tensor([(Pv * Vloc).sum(), qm.sum(), (qm ** 2).sum()], dtype=torch.float64)
+        dist.all_reduce(acc)
+        srp, sq, sq2 = acc.tolist()
+        spp = ((o.U.T @ o.U) * (o.V.T @ o.V)).sum() - sq2
+        sse = (M * R * R).sum() - 2.0 * srp + spp
+        o.tau = rng.gamma_draw(o.alpha_s(), o.beta + 0.5 * sse, it, o.seed)
+        taus.append(o.tau); mses.append(sse / M.sum())
+    if rank == 0:
+        q.put((o.U, o.V, taus, mses))
+    # every rank holds the same replicated state
+    chk = torch.tensor([o.U.sum(), o.V.sum(), o.tau], dtype=torch.float64)
+    lo = chk.clone(); hi = chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    assert torch.equal(lo, hi)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_sweep_reproduces_single_process_chain():
+    iters = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_run, args=(r, 2, port, iters, q)) for r in range(2)]
+    for p in procs: p.start()
+    U, V, taus, mses = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60); assert p.exitcode == 0
+    R, M, K, pri, U0, V0 = _problem()
+    o = O.BNMFGibbsOracle(R, M, K, pri, seed=99)
+    o.U, o.V = U0.copy(), V0.copy(); o.tau = o.alpha_s() / o.beta_s()
+    o.run(iters)
+    np.testing.assert_allclose(U, o.U, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(V, o.V, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(taus, o.all_tau, rtol=1e-9)
+    np.testing.assert_allclose(mses, o.all_performances["MSE"], rtol=1e-9)
