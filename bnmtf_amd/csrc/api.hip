@@ -433,6 +433,10 @@ int bnmtf_create(const bnmtf_problem* p, bnmtf_handle* out) {
 
   if (p->world > 1) {
     if ((rcode = comm_create(&h->comm, p->comm_id, p->rank, p->world, h->stream))) return fail(rcode);
+  } else if (getenv("BNMTF_FORCE_COMM")) {     // test hook: run the RCCL exchange path with a 1-rank communicator
+    uint8_t id[128];
+    if ((rcode = comm_unique_id(id))) return fail(rcode);
+    if ((rcode = comm_create(&h->comm, id, 0, 1, h->stream))) return fail(rcode);
   }
 
   char buf[512];

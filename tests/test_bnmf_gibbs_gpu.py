@@ -227,3 +227,19 @@ def test_large_shape_properties():
     p = b.predict_while_running()
     assert abs(p["MSE"] - mse[-1]) < 5e-5 * mse[-1]
     assert abs(p["Rp"] - b.all_performances['Rp'][-1]) < 1e-5
+
+
+def test_rccl_exchange_path_with_one_rank(golden, monkeypatch):
+    """The multi-GPU exchange code (dlopen'd RCCL: in-place all-gather of the factor blocks, all-reduce of the
+    three sums) run with a 1-rank communicator must leave the chain unchanged."""
+    c = golden("bnmf_gibbs_cond.npz").case("r37x29")
+    res = []
+    for force in (False, True):
+        if force:
+            monkeypatch.setenv("BNMTF_FORCE_COMM", "1")
+        b = bnmf_gibbs_optimised(c["R"], c["M"], int(c["K"]), _pri(c), verbose=False, seed=5)
+        b.U, b.V, b.tau = c["U"].copy(), c["V"].copy(), float(c["tau"])
+        b.run(5)
+        res.append((b.all_U.copy(), b.all_tau.copy(), list(b.all_performances['MSE'])))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    np.testing.assert_allclose(res[0][2], res[1][2], rtol=1e-12)
