@@ -157,6 +157,19 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
     HIPCHK(hipMemcpy(d.f_pair_base, pB.data(), pB.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     CHK(dalloc(&d.f_off, off.size(), false));
     HIPCHK(hipMemcpy(d.f_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    {   // 16-bit packed slot pairs for the pair-step kernel
+      d.pair_ok = d.mz + 32 < 65536;
+      std::vector<uint32_t> off16(std::max<size_t>(rows_total / 2, 1) * 64, 0);
+      if (d.pair_ok)
+        for (size_t r2 = 0; r2 < rows_total / 2; ++r2)
+          for (int l = 0; l < 64; ++l) off16[r2 * 64 + l] = (off[(2 * r2) * 64 + l] & 0xFFFFu) | (off[(2 * r2 + 1) * 64 + l] << 16);
+      CHK(dalloc(&d.f_off16, off16.size(), false));
+      HIPCHK(hipMemcpy(d.f_off16, off16.data(), off16.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      int nhi = 0;
+      while (nhi < d.f_npairs && (int)pE[nhi] > 40) ++nhi;
+      d.f_npairs_hi40 = std::min(d.f_npairs, (nhi + 15) / 16 * 16);
+      if (d.f_npairs_hi40 % 8) d.f_npairs_hi40 = 0;
+    }
     // leading pairs with more than 32 slots form 8-wave blocks (padded to a multiple of 16 pairs so the
     // two launches tile the pair list); 8-pair blocks whose fullest pair exceeds kFastMaxSlots are left
     // to the generic kernel
@@ -173,7 +186,7 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
       d.f_gen_count = (int)gen.size();
       CHK(dalloc(&d.f_gen_units, std::max<size_t>(gen.size(), 1), false));
       if (!gen.empty()) HIPCHK(hipMemcpy(d.f_gen_units, gen.data(), gen.size() * sizeof(int), hipMemcpyHostToDevice));
-      d.stats_blocks = (d.f_npairs + 7) / 8 + 1;
+      d.stats_blocks = (d.f_npairs + 7) / 8 + 2;
     }
     CHK(dalloc(&d.stats, (size_t)d.stats_blocks * 4));
   }
@@ -217,7 +230,7 @@ static void free_dir(Dir& d) {
   dfree(d.big); dfree(d.slabs); dfree(d.lambda); dfree(d.slot_ptr); dfree(d.idx); dfree(d.q);
   dfree(d.X); dfree(d.XT); dfree(d.C64); dfree(d.C32); dfree(d.colsum); dfree(d.colsum2);
   dfree(d.XT2); dfree(d.Cpart); dfree(d.spart); dfree(d.s2part); dfree(d.f_unit_map); dfree(d.f_pair_E);
-  dfree(d.f_pair_base); dfree(d.f_off); dfree(d.stats); dfree(d.f_gen_units);
+  dfree(d.f_pair_base); dfree(d.f_off); dfree(d.f_off16); dfree(d.stats); dfree(d.f_gen_units);
   dfree(d.vb_stats);
   dfree(d.mu); dfree(d.tauq); dfree(d.var); dfree(d.S2); dfree(d.S2T); dfree(d.numer); dfree(d.taup);
 }
@@ -284,7 +297,13 @@ static void enqueue_sweep(bnmtf_model* h, Dir& d, const Dir& other, SweepArgs& s
     { const char* e = getenv("BNMTF_SWEEP_DBG"); f.dbg = e ? atoi(e) : 0; }
     SweepArgs s2 = s;
     s2.acc = nullptr;
-    launch_sweep_fast(s2, f, h->stream);
+    f.off16 = d.f_off16;
+    const char* kern = getenv("BNMTF_SWEEP_KERNEL");           // "fast" (default) | "pair" (two columns per barrier; same speed at 8 waves, kept for experiments)
+    if (d.pair_ok && kern && !strcmp(kern, "pair")) {
+      const bool nw16 = getenv("BNMTF_PAIR_NW8") == nullptr && d.f_npairs_hi40 < d.f_npairs;
+      if (nw16) f.npairs_hi = d.f_npairs_hi40;
+      launch_sweep_pair(s2, f, nw16, h->stream);
+    } else launch_sweep_fast(s2, f, h->stream);
     h->last_sweep_fast = true;
     if (d.f_gen_count == 0) return;
     s.unit_list = d.f_gen_units;           // the few units with more than kFastMaxSlots slots per lane

@@ -67,40 +67,39 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
   }
 }
 
-// 32 entries per block, 8 partial-slab strides per entry (lanes e + 32*g), tree-summed in LDS:
-// KP*KP/32 blocks, every slab read is a coalesced 256 B row segment.
-__global__ __launch_bounds__(256) void gram_reduce_kernel(PostArgs a, int nblk) {
-  __shared__ double red[256];
+// 32 entries per block, 32 partial-slab strides per entry (thread = entry e + 32*g), tree-summed in LDS:
+// KP*KP/32 blocks of 1024 threads, every slab read is a coalesced 256 B row segment, <= nblk/32 serial loads.
+__global__ __launch_bounds__(1024) void gram_reduce_kernel(PostArgs a, int nblk) {
+  __shared__ double red[1024];
   const int KP = a.KP;
   const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int t = blockIdx.x * 32 + e;
   double s = 0.0;
-  for (int b = g; b < nblk; b += 8) s += a.Cpart[(size_t)b * KP * KP + t];
+  for (int b = g; b < nblk; b += 32) s += a.Cpart[(size_t)b * KP * KP + t];
   red[threadIdx.x] = s;
   __syncthreads();
-  if (g == 0) {
-#pragma unroll
-    for (int gg = 1; gg < 8; ++gg) s += red[gg * 32 + e];
-    a.C64[t] = s;
-    a.C32[t] = (float)s;
+  for (int w = 16; w >= 1; w >>= 1) {
+    if (g < w) red[threadIdx.x] += red[threadIdx.x + 32 * w];
+    __syncthreads();
   }
+  if (g == 0) { a.C64[t] = red[e]; a.C32[t] = (float)red[e]; }
   if (blockIdx.x == 0) {
     __syncthreads();
-    for (int c = threadIdx.x; c < KP * 4; c += 256) {      // 4 partial strides per column
-      const int col = c >> 2, gq = c & 3;
-      double v = 0.0, v2 = 0.0;
-      for (int b = gq; b < nblk; b += 4) { v += a.spart[(size_t)b * KP + col]; if (a.S2) v2 += a.s2part[(size_t)b * KP + col]; }
-      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64);
-      v2 += __shfl_xor(v2, 1, 64); v2 += __shfl_xor(v2, 2, 64);
-      if (gq == 0) { a.colsum[col] = v; if (a.S2) a.colsum2[col] = v2; }
-    }
+    // column sums: 16 partial strides per column (KP <= 64 columns)
+    const int col = threadIdx.x >> 4, gq = threadIdx.x & 15;
+    double v = 0.0, v2 = 0.0;
+    if (col < KP)
+      for (int b = gq; b < nblk; b += 16) { v += a.spart[(size_t)b * KP + col]; if (a.S2) v2 += a.s2part[(size_t)b * KP + col]; }
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) { v += __shfl_xor(v, m, 64); v2 += __shfl_xor(v2, m, 64); }
+    if (col < KP && gq == 0) { a.colsum[col] = v; if (a.S2) a.colsum2[col] = v2; }
   }
 }
 
 void launch_post(const PostArgs& a, hipStream_t st) {
   const int nblk = post_blocks(a.rows);
   hipLaunchKernelGGL(post_kernel, dim3(nblk), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3(a.KP * a.KP / 32), dim3(256), 0, st, a, nblk);
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3(a.KP * a.KP / 32), dim3(1024), 0, st, a, nblk);
 }
 
 }  // namespace bnmtf

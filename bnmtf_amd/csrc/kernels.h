@@ -77,6 +77,7 @@ struct FastArgs {
   const uint32_t* pair_E;      // [npairs] slots of the pair (max of its two units)
   const uint32_t* pair_base;   // [npairs] first slot row of the pair
   const uint32_t* off;         // [(base+s)*64 + lane] inner index j (j mod 32 == lane mod 32) or mz + lane%32
+  const uint32_t* off16;       // [(base/2+h)*64 + lane] slots 2h (low 16 bits) and 2h+1 (high) packed, for the pair-step kernel
   int npairs;                  // pairs in descending slot-count order
   int npairs_hi;               // leading pairs with more than 32 slots (padded to a multiple of 16): 8-wave blocks; the rest 16-wave blocks
   int mz, pw;                  // inner extent rounded up to 32 (sentinel zero words at mz..mz+31); panel floats pw = round_up(mz+32, 256)
@@ -88,6 +89,8 @@ struct FastArgs {
 constexpr int kFastMaxSlots = 56;   // blocks whose fullest pair needs more slots per lane go to the generic kernel
 bool sweep_fast_supported(int KP, int pw);
 void launch_sweep_fast(const SweepArgs& a, const FastArgs& f, hipStream_t st);
+// pair-step kernel (kernel_sweep_pair.hip); f.npairs_hi = leading pairs with more than 40 slots when nw16
+void launch_sweep_pair(const SweepArgs& a, const FastArgs& f, bool nw16, hipStream_t st);
 
 // relayout + Gram after a sweep / state upload: X -> XT, XT2, partial Gram slabs; then the reduction
 struct PostArgs {
