@@ -54,10 +54,12 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
   d.n_pad = round_up(std::max(d.n, 1), 128);
   // split of the inner dimension: aim at >= 2 blocks per CU, >= 64 inner rows per wave
   const int tiles = d.n_pad / 128;
-  int split = std::max(1, 512 / tiles);
+  // one resident block per CU at KP = 64 (the GEMM holds 332 registers per lane), two at KP = 32
+  int split = std::max(1, (d.KP == 64 ? 256 : 512) / tiles);
+  if (const char* e = getenv("BNMTF_GEMM_SPLIT")) split = std::max(1, atoi(e));
   const int max_split = std::max(1, m / (4 * 64));
   d.split = std::min(split, max_split);
-  d.ipw = round_up((m + d.split * 4 - 1) / (d.split * 4), 16);
+  d.ipw = round_up((m + d.split * 4 - 1) / (d.split * 4), 32);   // multiple of the GEMM's 2*U register-pipeline group
   d.inner_pad = d.split * 4 * d.ipw;
 
   std::vector<float> big((size_t)d.inner_pad * d.n_pad, 0.0f);

@@ -15,6 +15,8 @@
 // 512 B row segments.  A wave owns 128 output columns x KP and a private slice of the
 // inner dimension; the four waves of a block reduce through LDS and the block writes
 // one partial slab, which the sweep kernel sums in its prologue.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace bnmtf {
@@ -22,8 +24,8 @@ namespace bnmtf {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int MT>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
+template <int MT, int U, int WPS>
+__global__ __launch_bounds__(256, WPS) void gemm_kernel(GemmArgs a) {
   constexpr int KP = MT * 32;
   constexpr int NACC = MT * 4 * 16;            // accumulator floats per lane
   __shared__ float red[2][NACC * 64];          // 2 x 32 KiB (MT=2)
@@ -47,10 +49,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[mt][t][g] = 0.0f;
 
-  constexpr int U = 8;                          // r-pairs in flight per wave
-  for (int kk = 0; kk < ipw; kk += 2 * U) {
-    f32x4 b[U];
-    float av[U][MT];
+  // Software pipeline in registers: while the MFMAs of group g run, the loads of group g+1 are in flight
+  // (U r-pairs = U KiB of `big` per wave; one wave per SIMD, so the wave has to cover its own HBM latency).
+  f32x4 b0[U], b1[U];
+  float a0[U][MT], a1[U][MT];
+  auto load_group = [&](f32x4 (&b)[U], float (&av)[U][MT]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       b[u] = *reinterpret_cast<const f32x4*>(bp + u * bstep);
@@ -59,6 +62,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     }
     bp += U * bstep;
     xp += U * 2 * KP;
+  };
+  auto mfma_group = [&](const f32x4 (&b)[U], const float (&av)[U][MT]) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -66,6 +71,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
           acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][mt], b[u][t], acc[mt][t], 0, 0, 0);
+  };
+  const int ngroups = ipw / (2 * U);              // ipw is a multiple of 2*U (host pads)
+  if (WPS == 1) {                                 // three register sets: two groups in flight behind the one being multiplied
+    f32x4 b2[U]; float a2[U][MT];
+    load_group(b0, a0);
+    if (ngroups > 1) load_group(b1, a1);
+    for (int g = 0; g < ngroups; g += 3) {
+      if (g + 2 < ngroups) load_group(b2, a2);
+      mfma_group(b0, a0);
+      if (g + 1 < ngroups) {
+        if (g + 3 < ngroups) load_group(b0, a0);
+        mfma_group(b1, a1);
+      }
+      if (g + 2 < ngroups) {
+        if (g + 4 < ngroups) load_group(b1, a1);
+        mfma_group(b2, a2);
+      }
+    }
+  } else {
+    load_group(b0, a0);
+    for (int g = 0; g < ngroups; g += 2) {
+      if (g + 1 < ngroups) load_group(b1, a1);
+      mfma_group(b0, a0);
+      if (g + 1 < ngroups) {
+        if (g + 2 < ngroups) load_group(b0, a0);
+        mfma_group(b1, a1);
+      }
+    }
   }
 
   // cross-wave tree reduction through LDS: (2,3) -> (0,1), then 1 -> 0
@@ -108,8 +141,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 
 void launch_gemm(const GemmArgs& a, int KP, hipStream_t st) {
   dim3 grid(a.n_pad / 128, a.split), block(256);
-  if (KP == 32) hipLaunchKernelGGL(gemm_kernel<1>, grid, block, 0, st, a);
-  else          hipLaunchKernelGGL(gemm_kernel<2>, grid, block, 0, st, a);
+  static const bool u8 = getenv("BNMTF_GEMM_U8") != nullptr;     // experiment: 8-deep groups, two waves per SIMD
+  if (KP == 32) hipLaunchKernelGGL((gemm_kernel<1, 16, 2>), grid, block, 0, st, a);
+  else if (u8)  hipLaunchKernelGGL((gemm_kernel<2, 8, 2>), grid, block, 0, st, a);
+  else          hipLaunchKernelGGL((gemm_kernel<2, 16, 1>), grid, block, 0, st, a);
 }
 
 }  // namespace bnmtf
