@@ -27,9 +27,12 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 
 PEAK_HBM_GBS = 8000.0
 
 WORKLOADS = {
-    "bnmf_8192_k64": dict(I=8192, J=8192, K=64),
-    "bnmf_4096_k32": dict(I=4096, J=4096, K=32),
+    "bnmf_8192_k64": dict(I=8192, J=8192, K=64),          # BASELINE.json metric config (headline)
+    "bnmf_4096_k32": dict(I=4096, J=4096, K=32),          # configs[1]
     "bnmf_1024_k16": dict(I=1024, J=1024, K=16),
+    "bnmtf_4096_k32": dict(I=4096, J=4096, K=32, L=32),   # configs[3]
+    "vb_8192_k64": dict(I=8192, J=8192, K=64, vb=True),   # configs[4]
+    "vb_4096_k32": dict(I=4096, J=4096, K=32, vb=True),
 }
 
 
@@ -60,6 +63,42 @@ def cpu_baseline(R, M, K, pri, seed):
             "sample": "oracle/bnmtf_oracle.py (NumPy fp64, as written): 1 of %d U-column updates %.2fs, 1 of %d V-column "
                       "updates %.2fs, tau+metrics %.2fs at full size; iteration = %d*(U+V)+tail = %.1fs"
                       % (K, t1 - t0, K, t2 - t1, t3 - t2, K, sec_per_iter)}
+
+
+def side_workload(a, w, rank, world):
+    """BNMTF Gibbs / BNMF VB timing lines (single GPU; not the headline metric)."""
+    import bnmtf_amd
+    from bnmtf_amd import _lib
+    from bnmtf_amd.synthetic import generate_bnmf, generate_bnmtf
+    assert world == 1, "BNMTF / VB workloads are single-GPU"
+    I, J, K = w["I"], w["J"], w["K"]
+    L = _lib.lib()
+    np.random.seed(0)
+    if w.get("vb"):
+        R, M, _, _ = generate_bnmf(I, J, K, 0.1, seed_data=0, seed_mask=1)
+        m = bnmtf_amd.bnmf_vb_optimised(R, M, K, dict(alpha=1.0, beta=1.0, lambdaU=0.1, lambdaV=0.1), verbose=False)
+        m.initialise("exp")
+        m._push()
+        run = lambda n, perf=None: _lib.check(L.bnmf_vb_run(m._handle(), n, None, _lib.ptr(perf), None, None))
+        name = "BNMF VB iterations/sec"
+    else:
+        R, M, _, _, _ = generate_bnmtf(I, J, K, w["L"], 0.1, seed_data=0, seed_mask=1)
+        m = bnmtf_amd.bnmtf_gibbs_optimised(R, M, K, w["L"], dict(alpha=1.0, beta=1.0, lambdaF=0.1, lambdaS=0.1, lambdaG=0.1), seed=0, verbose=False)
+        m.initialise("random", "random")
+        m._push()
+        run = lambda n, perf=None: _lib.check(L.bnmtf_gibbs_run(m._handle(), n, 0, None, None, None, None, _lib.ptr(perf), None))
+        name = "BNMTF Gibbs iterations/sec"
+    run(a.warmup)
+    perf = np.zeros((a.steps, 3))
+    _lib.check(L.bnmtf_sync(m._handle()))
+    t0 = time.perf_counter()
+    run(a.steps, perf)
+    _lib.check(L.bnmtf_sync(m._handle()))
+    dt = time.perf_counter() - t0
+    print(json.dumps({"metric": "%s (%s)" % (name, a.workload), "value": a.steps / dt, "unit": "iterations/s", "n_gpus": 1,
+                      "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
+                      "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": a.workload}, "mse_first_last": [float(perf[0, 0]), float(perf[-1, 0])]}))
 
 
 def main():
@@ -101,6 +140,8 @@ def main():
 
     w = WORKLOADS[a.workload]
     I, J, K = w["I"], w["J"], w["K"]
+    if "L" in w or w.get("vb"):
+        return side_workload(a, w, rank, world)
     R, M, _, _ = generate_bnmf(I, J, K, 0.1, tau=1.0, seed_data=0, seed_mask=1)
     pri = dict(alpha=1.0, beta=1.0, lambdaU=0.1, lambdaV=0.1)
 

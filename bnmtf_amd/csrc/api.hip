@@ -181,14 +181,17 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
       d.f_npairs_hi = std::min(d.f_npairs, (nhi + 15) / 16 * 16);
       if (d.f_npairs_hi % 8) d.f_npairs_hi = 0 * (nhi = 0);   // tiny problems: everything in the 16-wave launch
       std::vector<int> gen;
-      for (int b0 = 0; b0 < d.f_npairs; b0 += 8)
+      // waves per block: 8 when there are enough units for >= 256 blocks, else 4 or 2 (multi-GPU shards, small problems)
+      d.f_nw = d.f_npairs >= 8 * 256 ? 8 : (d.f_npairs >= 4 * 256 ? 4 : (d.f_npairs >= 2 * 64 ? 2 : 8));
+      if (const char* e = getenv("BNMTF_FAST_NW")) d.f_nw = atoi(e) == 2 ? 2 : (atoi(e) == 4 ? 4 : 8);
+      for (int b0 = 0; b0 < d.f_npairs; b0 += d.f_nw)
         if ((int)pE[b0] > kFastMaxSlots)
-          for (int t = 2 * b0; t < std::min(2 * (b0 + 8), 2 * d.f_npairs); ++t) if (umap[t] >= 0) gen.push_back(umap[t]);
+          for (int t = 2 * b0; t < std::min(2 * (b0 + d.f_nw), 2 * d.f_npairs); ++t) if (umap[t] >= 0) gen.push_back(umap[t]);
       d.fast_ok = true;
       d.f_gen_count = (int)gen.size();
       CHK(dalloc(&d.f_gen_units, std::max<size_t>(gen.size(), 1), false));
       if (!gen.empty()) HIPCHK(hipMemcpy(d.f_gen_units, gen.data(), gen.size() * sizeof(int), hipMemcpyHostToDevice));
-      d.stats_blocks = (d.f_npairs + 7) / 8 + 2;
+      d.stats_blocks = (d.f_npairs + d.f_nw - 1) / d.f_nw + 2;
     }
     CHK(dalloc(&d.stats, (size_t)d.stats_blocks * 4));
   }
@@ -293,7 +296,7 @@ static void enqueue_sweep(bnmtf_model* h, Dir& d, const Dir& other, SweepArgs& s
   if (h->use_fast && d.fast_ok && s.cond_k < 0 && s.mode != kSweepVB && sweep_fast_supported(d.KP, d.pw)) {
     FastArgs f;
     f.unit_map = d.f_unit_map; f.pair_E = d.f_pair_E; f.pair_base = d.f_pair_base; f.off = d.f_off;
-    f.npairs = d.f_npairs; f.npairs_hi = d.f_npairs_hi; f.mz = d.mz; f.pw = d.pw;
+    f.npairs = d.f_npairs; f.npairs_hi = d.f_npairs_hi; f.mz = d.mz; f.pw = d.pw; f.nw = d.f_nw;
     f.XoT = other.XT; f.ldT_o = other.ldT; f.XoT2 = other.XT2; f.ld2_o = other.ldT;
     f.stats = want_stats ? d.stats : nullptr;
     { const char* e = getenv("BNMTF_SWEEP_DBG"); f.dbg = e ? atoi(e) : 0; }

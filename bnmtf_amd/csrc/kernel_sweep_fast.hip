@@ -321,7 +321,7 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
 // NW = 16 (1024 threads, 32 units per CU in ONE resident block, <= 128 VGPRs) serves slot counts
 // up to 32; NW = 8 (512 threads, <= 256 VGPRs) serves the fuller units.
 template <int NX, int MODE, int NW>
-__global__ __launch_bounds__(NW * 64, NW / 4) void sweep_fast_kernel(SweepArgs a, FastArgs f) {
+__global__ __launch_bounds__(NW * 64, (NW >= 8 ? NW / 4 : 2)) void sweep_fast_kernel(SweepArgs a, FastArgs f) {
   extern __shared__ float lds[];
   const int e0 = (int)f.pair_E[blockIdx.x * NW];      // descending order: first pair of the block is its fullest
   if (NW == 16) {
@@ -352,20 +352,32 @@ static void launch_inst(const SweepArgs& a, const FastArgs& f, int nblocks, size
   if (nblocks > 0) hipLaunchKernelGGL((sweep_fast_kernel<NX, MODE, NW>), dim3(nblocks), dim3(NW * 64), lds_bytes, st, a, f);
 }
 
-// pairs [0, f.npairs_hi) (slot count > 32) run as 8-wave blocks, the rest as 16-wave blocks
+// Blocks of NW waves (2*NW units).  8 waves is the throughput shape; when a rank owns few units (row/column
+// shards of a multi-GPU run, small problems) 4- or 2-wave blocks keep every CU busy instead of a few.
 void launch_sweep_fast(const SweepArgs& a, const FastArgs& f, hipStream_t st) {
   const size_t lds_bytes = sweep_fast_lds_bytes(a.KP, f.pw);
   const int nx = a.KP / 32;
-  FastArgs lo = f, hi = f;
-  hi.npairs = f.npairs_hi;                                   // first npairs_hi pairs (multiple of 8 and 16)
-  lo.pair_E += f.npairs_hi; lo.pair_base += f.npairs_hi; lo.unit_map += 2 * f.npairs_hi; lo.npairs = f.npairs - f.npairs_hi;
-  if (lo.stats) lo.stats += (size_t)(f.npairs_hi / 8) * 4;
-  int nb_hi = hi.npairs / 8, nb_lo = (lo.npairs + 15) / 16;
-  if (!getenv("BNMTF_FAST_NW16")) { hi = f; nb_hi = (f.npairs + 7) / 8; nb_lo = 0; }   // default: 8-wave blocks only; the 16-wave variant (one resident block of 32 units, balanced slots, re-gather) measured slower (464 vs 364 us) and is kept for experiments
-#define BNMTF_L(NXV, MODEV)                                                   \
-  do {                                                                        \
-    launch_inst<NXV, MODEV, 8>(a, hi, nb_hi, lds_bytes, st);                  \
-    launch_inst<NXV, MODEV, 16>(a, lo, nb_lo, lds_bytes, st);                 \
+  if (getenv("BNMTF_FAST_NW16")) {                 // experiment: 16-wave blocks for pairs with <= 32 slots
+    FastArgs lo = f, hi = f;
+    hi.npairs = f.npairs_hi;
+    lo.pair_E += f.npairs_hi; lo.pair_base += f.npairs_hi; lo.unit_map += 2 * f.npairs_hi; lo.npairs = f.npairs - f.npairs_hi;
+    if (lo.stats) lo.stats += (size_t)(f.npairs_hi / 8) * 4;
+    const int nb_hi = hi.npairs / 8, nb_lo = (lo.npairs + 15) / 16;
+    if (a.mode == kSweepDraw) {
+      if (nx == 1) { launch_inst<1, kSweepDraw, 8>(a, hi, nb_hi, lds_bytes, st); launch_inst<1, kSweepDraw, 16>(a, lo, nb_lo, lds_bytes, st); }
+      else         { launch_inst<2, kSweepDraw, 8>(a, hi, nb_hi, lds_bytes, st); launch_inst<2, kSweepDraw, 16>(a, lo, nb_lo, lds_bytes, st); }
+    } else {
+      if (nx == 1) { launch_inst<1, kSweepMode, 8>(a, hi, nb_hi, lds_bytes, st); launch_inst<1, kSweepMode, 16>(a, lo, nb_lo, lds_bytes, st); }
+      else         { launch_inst<2, kSweepMode, 8>(a, hi, nb_hi, lds_bytes, st); launch_inst<2, kSweepMode, 16>(a, lo, nb_lo, lds_bytes, st); }
+    }
+    return;
+  }
+  const int nw = f.nw;
+#define BNMTF_L(NXV, MODEV)                                                                       \
+  do {                                                                                            \
+    if (nw == 2) launch_inst<NXV, MODEV, 2>(a, f, (f.npairs + 1) / 2, lds_bytes, st);             \
+    else if (nw == 4) launch_inst<NXV, MODEV, 4>(a, f, (f.npairs + 3) / 4, lds_bytes, st);        \
+    else launch_inst<NXV, MODEV, 8>(a, f, (f.npairs + 7) / 8, lds_bytes, st);                     \
   } while (0)
   if (a.mode == kSweepDraw) { if (nx == 1) BNMTF_L(1, kSweepDraw); else BNMTF_L(2, kSweepDraw); }
   else                      { if (nx == 1) BNMTF_L(1, kSweepMode); else BNMTF_L(2, kSweepMode); }

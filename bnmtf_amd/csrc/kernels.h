@@ -78,6 +78,7 @@ struct FastArgs {
   const uint32_t* pair_base;   // [npairs] first slot row of the pair
   const uint32_t* off;         // [(base+s)*64 + lane] inner index j (j mod 32 == lane mod 32) or mz + lane%32
   const uint32_t* off16;       // [(base/2+h)*64 + lane] slots 2h (low 16 bits) and 2h+1 (high) packed, for the pair-step kernel
+  int nw;                      // waves per block of the fast sweep (2, 4 or 8)
   int npairs;                  // pairs in descending slot-count order
   int npairs_hi;               // leading pairs with more than 32 slots (padded to a multiple of 16): 8-wave blocks; the rest 16-wave blocks
   int mz, pw;                  // inner extent rounded up to 32 (sentinel zero words at mz..mz+31); panel floats pw = round_up(mz+32, 256)
