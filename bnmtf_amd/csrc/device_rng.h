@@ -69,6 +69,20 @@ __device__ __forceinline__ bool tn_candidate(const TnParams& p, uint32_t elem, u
   return acc;
 }
 
+// acceptance / value of a candidate from two raw 32-bit words (Philox done elsewhere)
+__device__ __forceinline__ bool tn_eval_words(const TnParams& p, uint32_t r0, uint32_t r1, float* x) {
+  const float u1 = u24(r0), u2 = u24(r1);
+  const float nl = -logf(u1);
+  if (p.tail) {
+    const float e = nl / p.lam, t = e - p.d;
+    *x = e / p.rt;
+    return u2 <= expf(-0.5f * t * t);
+  }
+  const float z = sqrtf(2.0f * nl) * cosf(kTwoPi * u2);
+  *x = p.mu + z / p.rt;
+  return z >= p.a;
+}
+
 __device__ __forceinline__ float tn_guard(float x) { return (isfinite(x) && x >= 0.0f) ? x : 0.0f; }
 
 // Serial form (one thread per draw): used by the stand-alone hook and the S sweep.

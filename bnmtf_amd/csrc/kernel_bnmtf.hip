@@ -78,21 +78,32 @@ __global__ __launch_bounds__(256) void srow_gather_kernel(SRowArgs a) {
   for (int u = blockIdx.x * 4 + wave; u < a.n; u += gridDim.x * 4) {
     const float g = (lane < L) ? a.G[((size_t)a.n0 + u) * a.KPl + lane] : 0.f;
     const float dj = wsum(g * dprev_l);                              // G_j . delta_{k-1}
-    float pv = 0.f;
-    if (lane == 0) for (int s = 0; s < a.split; ++s) pv += a.slabs[((size_t)s * a.n_pad + u) * a.KPk + k];
+    float pv = 0.f;                                                   // Pv_jk = sum of the contraction's partial slabs
+    for (int s = lane; s < a.split; s += 64) pv += a.slabs[((size_t)s * a.n_pad + u) * a.KPk + k];
     const uint32_t s0 = a.slot_ptr[u], s1 = a.slot_ptr[u + 1];
+    const uint32_t* __restrict__ idxp = a.idx;
+    float* __restrict__ qp = a.q;
+    const bool upd = k > 0 && a.apply_prev;
     float hm = 0.f, wm = 0.f;
-    for (uint32_t e = s0 + lane; e < s1; e += 64) {
-      const uint32_t i = a.idx[e];
-      float qv = a.q[e];
-      if (k > 0 && a.apply_prev) { qv = fmaf(FTp[i], dj, qv); a.q[e] = qv; }
-      const float f = FTk[i];
-      hm = fmaf(qv, f, hm);
-      wm = fmaf(f, f, wm);
+    for (uint32_t e = s0 + lane; e < s1; e += 128) {                 // two independent slots per trip
+      const uint32_t e2 = e + 64;
+      const bool two = e2 < s1;
+      const uint32_t i0 = idxp[e], i1 = two ? idxp[e2] : idxp[e];
+      float q0 = qp[e], q1 = two ? qp[e2] : 0.f;
+      const float f0 = FTk[i0], f1 = two ? FTk[i1] : 0.f;
+      if (upd) {
+        q0 = fmaf(FTp[i0], dj, q0); qp[e] = q0;
+        if (two) { q1 = fmaf(FTp[i1], dj, q1); qp[e2] = q1; }
+      }
+      hm = fmaf(q0, f0, fmaf(q1, f1, hm));
+      wm = fmaf(f0, f0, fmaf(f1, f1, wm));
     }
-    hm = wsum(hm); wm = wsum(wm);
-    const float gc = wsum(g * cfs_l);                                // sum_l' G_jl' (Cf S)_kl'
-    const float h = __shfl(pv, 0, 64) - gc + hm;
+    // one combined butterfly for the four per-unit sums (hm, wm, pv, G.CfS)
+    float r0 = hm, r1 = wm, r2 = pv, r3 = g * cfs_l;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { r0 += __shfl_xor(r0, m, 64); r1 += __shfl_xor(r1, m, 64); r2 += __shfl_xor(r2, m, 64); r3 += __shfl_xor(r3, m, 64); }
+    hm = r0; wm = r1;
+    const float h = r2 - r3 + hm;
     const float w = cfkk - wm;
     eta = fmaf(g, h, eta);
     const float wg = w * g;
@@ -101,11 +112,16 @@ __global__ __launch_bounds__(256) void srow_gather_kernel(SRowArgs a) {
       if (lp < L) om[lp] = fmaf(wg, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g), lp)), om[lp]);
   }
   // block partials -> slab [block][L + L*L]
-  atomicAdd(&red[64 * 65 + lane], eta);
+  // the four waves add their partials in turn (LDS float atomics compile to a CAS loop here: 60k stall cycles)
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+      red[64 * 65 + lane] += eta;
 #pragma unroll
-  for (int lp = 0; lp < 64; ++lp)
-    if (lp < L) atomicAdd(&red[lane * 65 + lp], om[lp]);
-  __syncthreads();
+      for (int lp = 0; lp < 64; ++lp)
+        if (lp < L) red[lane * 65 + lp] += om[lp];
+    }
+    __syncthreads();
+  }
   float* out = a.partial + (size_t)blockIdx.x * (L + L * L);
   for (int t = threadIdx.x; t < L + L * L; t += 256)
     out[t] = (t < L) ? red[64 * 65 + t] : red[((t - L) / L) * 65 + (t - L) % L];
@@ -114,20 +130,43 @@ void launch_srow_gather(const SRowArgs& a, int blocks, hipStream_t st) {
   hipLaunchKernelGGL(srow_gather_kernel, dim3(blocks), dim3(256), 0, st, a);
 }
 
-// Single block: reduce the partials, run the L sequential conditionals of row k, write S[k][:],
+// sum the per-block partial (eta, Omega) slabs: 32 outputs per block, 32 partial strides per output
+__global__ __launch_bounds__(1024) void srow_reduce_kernel(const float* partial, int nblocks, int nvals, float* out) {
+  __shared__ float red[1024];
+  const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int t = blockIdx.x * 32 + e;
+  float s = 0.f;
+  if (t < nvals)
+    for (int b = g; b < nblocks; b += 32) s += partial[(size_t)b * nvals + t];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 16; w >= 1; w >>= 1) {
+    if (g < w) red[threadIdx.x] += red[threadIdx.x + 32 * w];
+    __syncthreads();
+  }
+  if (g == 0 && t < nvals) out[t] = red[e];
+}
+
+// Single block: run the L sequential conditionals of row k on the reduced (eta, Omega), write S[k][:],
 // delta_k, and keep Cf.S current.  cond_l >= 0: only evaluate (k, cond_l) and write numer/tau.
 __global__ __launch_bounds__(1024) void srow_draw_kernel(SDrawArgs a) {
   __shared__ float eta[64], Om[64 * 65], delta[64], srow[64];
   const int L = a.L, K = a.K, k = a.k, tid = threadIdx.x;
   for (int t = tid; t < L + L * L; t += 1024) {
-    float s = 0.f;
-    for (int b = 0; b < a.nblocks; ++b) s += a.partial[(size_t)b * (L + L * L) + t];
+    const float s = a.partial[t];
     if (t < L) eta[t] = s; else Om[((t - L) / L) * 65 + (t - L) % L] = s;
   }
   if (tid < L) { delta[tid] = 0.f; srow[tid] = a.S[k * L + tid]; }
   __syncthreads();
-  if (tid < 64) {                                   // one wave: the sequential l loop, 64 candidates per round
+  if (tid < 64) {                                   // one wave: the sequential l loop
     const float tau = *a.tau;
+    // hoisted Philox: lane l holds candidates 0 and 1 of entry (k, l)
+    uint32_t c0a = 0, c0b = 0, c1a = 0, c1b = 0;
+    if (a.update == 0 && a.cond_l < 0 && tid < L) {
+      const U4 r0 = philox4x32_10(0u, (uint32_t)(k * L + tid), a.it, kStreamS, a.key0, a.key1);
+      const U4 r1 = philox4x32_10(0u, (uint32_t)(k * L + tid), a.it, kStreamS + 16u, a.key0, a.key1);
+      c0a = r0.x; c0b = r0.y; c1a = r1.x; c1b = r1.y;
+    }
     const int lbeg = a.cond_l >= 0 ? a.cond_l : 0, lend = a.cond_l >= 0 ? a.cond_l + 1 : L;
     for (int l = lbeg; l < lend; ++l) {
       float corr = (tid < l && a.cond_l < 0) ? delta[tid] * Om[tid * 65 + l] : 0.f;
@@ -142,11 +181,20 @@ __global__ __launch_bounds__(1024) void srow_draw_kernel(SDrawArgs a) {
       if (a.update == 0) {
         const TnParams tp = tn_params(mu, tau_p);
         if (tp.live) {
-          for (uint32_t round = 0; round < 64u; ++round) {
-            float xc;
-            const bool acc = tn_candidate(tp, 0u, (uint32_t)(k * L + l), a.it, kStreamS, round * 64u + tid, a.key0, a.key1, &xc);
-            const unsigned long long m = __ballot(acc);
-            if (m) { snew = tn_guard(__shfl(xc, __ffsll((long long)m) - 1, 64)); break; }
+          // candidates 0, 1 from the hoisted words (lane l), then 64 fresh candidates per round
+          const uint32_t w0a = (uint32_t)__builtin_amdgcn_readlane((int)c0a, l), w0b = (uint32_t)__builtin_amdgcn_readlane((int)c0b, l);
+          const uint32_t w1a = (uint32_t)__builtin_amdgcn_readlane((int)c1a, l), w1b = (uint32_t)__builtin_amdgcn_readlane((int)c1b, l);
+          float x0, x1;
+          const bool a0 = tn_eval_words(tp, w0a, w0b, &x0), a1 = tn_eval_words(tp, w1a, w1b, &x1);
+          if (a0) snew = tn_guard(x0);
+          else if (a1) snew = tn_guard(x1);
+          else {
+            for (uint32_t round = 0; round < 64u; ++round) {
+              float xc;
+              const bool acc = tn_candidate(tp, 0u, (uint32_t)(k * L + l), a.it, kStreamS, 2u + round * 64u + tid, a.key0, a.key1, &xc);
+              const unsigned long long m = __ballot(acc);
+              if (m) { snew = tn_guard(__shfl(xc, __ffsll((long long)m) - 1, 64)); break; }
+            }
           }
         }
       } else {
@@ -166,7 +214,11 @@ __global__ __launch_bounds__(1024) void srow_draw_kernel(SDrawArgs a) {
   }
 }
 void launch_srow_draw(const SDrawArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(srow_draw_kernel, dim3(1), dim3(1024), 0, st, a);
+  const int nvals = a.L + a.L * a.L;
+  hipLaunchKernelGGL(srow_reduce_kernel, dim3((nvals + 31) / 32), dim3(1024), 0, st, a.partial, a.nblocks, nvals, a.reduced);
+  SDrawArgs b = a;
+  b.partial = a.reduced;
+  hipLaunchKernelGGL(srow_draw_kernel, dim3(1), dim3(1024), 0, st, b);
 }
 
 }  // namespace bnmtf

@@ -165,7 +165,7 @@ struct SRowArgs {           // one row k of S: J-vectors h_k, w_k and per-block 
 void launch_srow_gather(const SRowArgs& a, int blocks, hipStream_t st);
 struct SDrawArgs {
   int k, K, L, KPk, nblocks, update, cond_l;
-  const float* partial; float* S; const float* lambdaS; const float* tau;
+  const float* partial; float* reduced; float* S; const float* lambdaS; const float* tau;
   const double* Cf64; float* CfS; float* delta_out;
   uint32_t key0, key1, it;
   double* numer_out; double* tau_out;
