@@ -207,6 +207,13 @@ def main():
         # whole-iteration bound: max(t_MFMA, t_HBM) of the two contractions, SURVEY.md 8(d)
         t_mfma = 4.0 * I * J * K / (PEAK_F32_MFMA_TFLOPS * 1e12) / world
         t_hbm = (2.0 * I * J * 4.125 + 8.0 * (I + J) * K) / (PEAK_HBM_GBS * 1e9) / world
+        traffic = None
+        try:     # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (profiles/traffic.json)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if a.workload == "bnmf_8192_k64" and world == 1:
+                traffic = tj["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "Gibbs iterations/sec (BNMF, I=J=8192, K=64)" if a.workload == "bnmf_8192_k64" else "Gibbs iterations/sec (%s)" % a.workload,
             "value": a.steps / dt, "unit": "Gibbs iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -220,7 +227,7 @@ def main():
                          "peak": PEAK_F32_MFMA_TFLOPS if K >= 64 else PEAK_HBM_GBS,
                          "unit": "TFLOP/s" if K >= 64 else "GB/s",
                          "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if K >= 64 else bytes_alg / (g["avg_us"] * 1e-6) / 1e9 / PEAK_HBM_GBS,
-                         "traffic": None,
+                         "traffic": traffic,
                          "algorithmic_per_launch": {"flop": flops, "bytes": bytes_alg},
                          "avg_launch_us": g["avg_us"]},
             "iteration_bound": {"t_mfma_us": 1e6 * t_mfma, "t_hbm_us": 1e6 * t_hbm,
