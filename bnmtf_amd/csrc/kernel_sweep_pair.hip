@@ -55,22 +55,22 @@ __device__ __forceinline__ TnF tnf_params(float numer, float tau_p) {
   TnF p;
   p.live = tau_p > 0.0f;
   const float tp = p.live ? tau_p : 1.0f;
-  p.irt = __frsqrt_rn(tp);
-  p.mu = numer * __frcp_rn(tp);
+  p.irt = __builtin_amdgcn_rsqf(tp);             // v_rsq_f32 / v_rcp_f32 / v_sqrt_f32: ~1 ulp, one instruction each
+  p.mu = numer * __builtin_amdgcn_rcpf(tp);
   p.a = -p.mu * (tp * p.irt);
   p.live = p.live && isfinite(p.a);
-  p.d = 2.0f * __frcp_rn(sqrtf(fmaf(p.a, p.a, 4.0f)) + p.a);
-  p.ilam = __frcp_rn(p.a + p.d);
+  p.d = 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(p.a, p.a, 4.0f)) + p.a);
+  p.ilam = __builtin_amdgcn_rcpf(p.a + p.d);
   p.tail = p.a >= kTnA0;
   return p;
 }
 __device__ __forceinline__ bool tnf_eval(const TnF& p, uint32_t r0, uint32_t r1, float* x) {
   const float u1 = u24(r0), u2 = u24(r1);
-  const float nl = -__logf(u1);
+  const float nl = -0.69314718f * __builtin_amdgcn_logf(u1);            // v_log_f32 is log2
   const float e = nl * p.ilam;
   const float t = e - p.d;
-  const bool acc_t = u2 <= __expf(-0.5f * t * t);
-  const float z = sqrtf(2.0f * nl) * __cosf(kTwoPi * u2);
+  const bool acc_t = u2 <= __builtin_amdgcn_exp2f(-0.72134752f * t * t);   // exp(-t^2/2) via v_exp_f32 (2^x)
+  const float z = __builtin_amdgcn_sqrtf(2.0f * nl) * __builtin_amdgcn_cosf(u2);   // v_cos_f32 takes revolutions
   const bool acc_n = z >= p.a;
   *x = p.tail ? e * p.irt : fmaf(z, p.irt, p.mu);
   return p.tail ? acc_t : acc_n;
