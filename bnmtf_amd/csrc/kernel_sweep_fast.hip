@@ -17,7 +17,9 @@
 //  * the K draws per unit are sequential, so the Philox work is hoisted: lane l
 //    pre-computes the first two candidates of columns l and l+32; step k broadcasts them.
 //    Only a double rejection (rare) falls back to 32 fresh candidates per round.
+#include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.h"
 #include "device_rng.h"
@@ -89,19 +91,6 @@ __device__ __forceinline__ bool tn_eval_fast(const TnFast& p, uint32_t r0, uint3
   return p.tail ? acc_t : acc_n;
 }
 
-// candidate value / acceptance from two raw 32-bit words (no Philox here)
-__device__ __forceinline__ bool tn_eval(const TnParams& p, uint32_t r0, uint32_t r1, float* x) {
-  const float u1 = u24(r0), u2 = u24(r1);
-  const float nl = -__logf(u1);
-  const float e = nl / p.lam;
-  const float t = e - p.d;
-  const bool acc_t = u2 <= __expf(-0.5f * t * t);
-  const float z = sqrtf(2.0f * nl) * __cosf(kTwoPi * u2);
-  const bool acc_n = z >= p.a;
-  *x = p.tail ? e / p.rt : p.mu + z / p.rt;
-  return p.tail ? acc_t : acc_n;
-}
-
 // LDS-direct staging of one panel: `chunks` pieces of 1 KiB (64 lanes x 16 B), wave w takes
 // chunks w, w+8, ...  No VGPRs, no ds_write; completion is covered by the vmcnt(0) that
 // __syncthreads() carries while an LDS-DMA is in flight.
@@ -113,12 +102,21 @@ __device__ __forceinline__ void stage_panel(const float* src, float* dst, int ch
   }
 }
 
+constexpr int kPanelStride = 9216;              // floats between the two single-column panel buffers (>= pw)
+typedef __attribute__((address_space(3))) const float lds_cf;
+typedef __attribute__((address_space(3))) const f32x2 lds_cf2;
+typedef __attribute__((address_space(3))) float* lds_fp;
+
 template <int EM, int NX, int MODE, int NW>
 __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastArgs& f, float* lds) {
   constexpr int KP = NX * 32;
-  const int PW = f.pw;                      // floats per single-column panel (multiple of 256)
+  constexpr int EH = EM / 2;
+  constexpr int kHoist = 4;
+  static_assert(EM % 2 == 0, "slots are processed in pairs");
+  const int PW = f.pw;                      // floats per single-column panel (multiple of 256, <= kPanelStride)
   float* Cs = lds;                          // [KP][KP]
-  float* pan = lds + KP * KP;               // main loop: 2 x PW ; pre-pass: 2 x 2*PW
+  float* pan = lds + KP * KP;               // main loop: buffers at 0 and kPanelStride ; pre-pass: 2 x 2*PW
+  const uint32_t pan_b = (uint32_t)(uintptr_t)(lds_fp)pan;   // LDS byte address of `pan`
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -143,23 +141,19 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
       lam[nx] = a.lambda[(size_t)u * KP + kk];
     }
   }
-  static_assert(EM % 2 == 0, "slots are processed in pairs");
-  constexpr int EH = EM / 2;
-  uint32_t off[EM];
-  constexpr bool REGATHER = (NW == 16);     // 16-wave blocks: 128-VGPR budget, no room for the previous column's values
-  constexpr int EV = REGATHER ? 1 : EH;
-  f32x2 q2[EH], vp2[EV];                   // slots (2h, 2h+1) share a register pair: packed f32 FMAs
+  // slot addresses as LDS BYTE addresses inside panel buffer 0 (sentinel: a zero word on bank l5)
+  uint32_t addr[EM];
+  f32x2 q2[EH], vp2[EH];                   // slots (2h, 2h+1) share a register pair: packed f32 FMAs
 #pragma unroll
-  for (int s = 0; s < EM; ++s)
-    off[s] = (s < E) ? f.off[((size_t)base + s) * 64 + lane] : (uint32_t)(f.mz + l5);   // sentinel: a zero word on bank l5
+  for (int s = 0; s < EM; ++s) {
+    const uint32_t j = (s < E) ? f.off[((size_t)base + s) * 64 + lane] : (uint32_t)(f.mz + l5);
+    addr[s] = pan_b + 4u * j;
+  }
 #pragma unroll
-  for (int h = 0; h < EH; ++h) q2[h] = f32x2{0.f, 0.f};
-#pragma unroll
-  for (int h = 0; h < EV; ++h) vp2[h] = f32x2{0.f, 0.f};
+  for (int h = 0; h < EH; ++h) { q2[h] = f32x2{0.f, 0.f}; vp2[h] = f32x2{0.f, 0.f}; }
   for (int t = tid; t < KP * KP; t += NW * 64) Cs[t] = a.C32[t];
 
   // hoisted Philox: candidates 0..kHoist-1 of columns l5 (+32)
-  constexpr int kHoist = 4;
   uint32_t ca[kHoist][NX], cb[kHoist][NX];
   if (MODE == kSweepDraw) {
 #pragma unroll
@@ -171,7 +165,7 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
       }
   }
 
-  // ------------------------------------------------------------ pre-pass: q = U_i . V_j
+  // ------------------------------------------------------------ pre-pass: q = U_i . V_j  (pair panels)
   {
     const int chunks2 = (2 * PW) / 256;
     const size_t stride = (size_t)f.ld2_o * 2;
@@ -180,32 +174,23 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
     const int npair = KP / 2;
     for (int kp = 0; kp < npair; ++kp) {
       if (kp + 1 < npair) stage_panel<NW>(f.XoT2 + (size_t)(kp + 1) * stride, pan + (size_t)((kp + 1) & 1) * 2 * PW, chunks2, wave, lane);
-      const float2* cur = reinterpret_cast<const float2*>(pan + (size_t)(kp & 1) * 2 * PW);
+      // element j of a pair panel sits 8 j bytes in: 2 * addr - pan_b (+ the buffer's offset)
+      const uint32_t boff = (uint32_t)((kp & 1) * 2 * PW) * 4u - pan_b;
       const int k0 = 2 * kp, k1 = 2 * kp + 1;
       const float xs0 = (NX == 2 && k0 >= 32) ? x[NX - 1] : x[0];
       const float x0 = half_bcast(xs0, k0 & 31, half), x1 = half_bcast(xs0, k1 & 31, half);
       const f32x2 x01 = {x0, x1};
-      if (REGATHER) {
 #pragma unroll
-        for (int h = 0; h < EH; ++h) {
-          const float2 va = cur[off[2 * h]], vb = cur[off[2 * h + 1]];
-          q2[h] = pk_fma(f32x2{va.x, vb.x}, f32x2{x0, x0}, q2[h]);
-          q2[h] = pk_fma(f32x2{va.y, vb.y}, f32x2{x1, x1}, q2[h]);
-        }
-      } else {
-#pragma unroll
-        for (int h = 0; h < EH; ++h) {          // (q2[h], vp2[h]) = (even col, odd col) partial sums of slots 2h, 2h+1
-          const float2 va = cur[off[2 * h]], vb = cur[off[2 * h + 1]];
-          q2[h] = pk_fma(f32x2{va.x, va.y}, x01, q2[h]);
-          vp2[h % EV] = pk_fma(f32x2{vb.x, vb.y}, x01, vp2[h % EV]);
-        }
+      for (int h = 0; h < EH; ++h) {          // (q2[h], vp2[h]) = (even col, odd col) partial sums of slots 2h, 2h+1
+        const f32x2 va = *(lds_cf2*)(uintptr_t)(2u * addr[2 * h] + boff);
+        const f32x2 vb = *(lds_cf2*)(uintptr_t)(2u * addr[2 * h + 1] + boff);
+        q2[h] = pk_fma(va, x01, q2[h]);
+        vp2[h] = pk_fma(vb, x01, vp2[h]);
       }
       __syncthreads();
     }
-    if (!REGATHER) {
 #pragma unroll
-      for (int h = 0; h < EH; ++h) { q2[h] = f32x2{q2[h].x + q2[h].y, vp2[h % EV].x + vp2[h % EV].y}; vp2[h % EV] = f32x2{0.f, 0.f}; }
-    }
+    for (int h = 0; h < EH; ++h) { q2[h] = f32x2{q2[h].x + q2[h].y, vp2[h].x + vp2[h].y}; vp2[h] = f32x2{0.f, 0.f}; }
   }
 
   // ------------------------------------------------------------ the K sequential columns
@@ -214,21 +199,34 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
   __syncthreads();
   const float tau = *a.tau;
   float dprev = 0.f;
-  for (int k = 0; k < K; ++k) {
-    if (k + 1 < K) stage_panel<NW>(f.XoT + (size_t)(k + 1) * f.ldT_o, pan + (size_t)((k + 1) & 1) * PW, chunks1, wave, lane);
-    const float* cur = pan + (size_t)(k & 1) * PW;
-    const float xsel = (NX == 2 && k >= 32) ? x[NX - 1] : x[0];
-    const float xk = half_bcast(xsel, k & 31, half);
-    f32x2 corr2[2] = {{0.f, 0.f}, {0.f, 0.f}}, asq2[2] = {{0.f, 0.f}, {0.f, 0.f}};
-    const f32x2 dp2 = {dprev, dprev}, nxk2 = {-xk, -xk};
+
+  // One column.  BUF (which panel buffer holds column k) and HI (k >= 32: which register of x/p/lam/ca/cb
+  // owns column k) are compile-time, so the buffer offset is a ds_read immediate.
+  auto column = [&](auto buf_c, auto hi_c, int k) {
+    constexpr int BUF = decltype(buf_c)::value;
+    constexpr int HI = decltype(hi_c)::value;
+    if (k + 1 < K) stage_panel<NW>(f.XoT + (size_t)(k + 1) * f.ldT_o, pan + (size_t)(1 - BUF) * kPanelStride, chunks1, wave, lane);
+    const float xk = half_bcast(x[HI], k & 31, half);
+    // (A) column k-1's update, from the registers that still hold v_{k-1}
+    const f32x2 dp2 = {dprev, dprev};
+#pragma unroll
+    for (int h = 0; h < EH; ++h) q2[h] = pk_fma(dp2, vp2[h], q2[h]);
+    __builtin_amdgcn_sched_barrier(0);
+    // (B) gather v_k into those registers: address register + immediate, no VALU
 #pragma unroll
     for (int h = 0; h < EH; ++h) {
-      const f32x2 v = {cur[off[2 * h]], cur[off[2 * h + 1]]};
-      const f32x2 qs = REGATHER ? q2[h] : pk_fma(dp2, vp2[h % EV], q2[h]);    // column k-1's update, applied late
-      const f32x2 t = pk_fma(nxk2, v, qs);
-      corr2[h & 1] = pk_fma(t, v, corr2[h & 1]);
-      asq2[h & 1] = pk_fma(v, v, asq2[h & 1]);
-      if (!REGATHER) { q2[h] = qs; vp2[h % EV] = v; }
+      asm volatile("" : "+v"(addr[2 * h]), "+v"(addr[2 * h + 1]));   // opaque: keeps addr + const from being hoisted into registers
+      vp2[h].x = *(lds_cf*)(uintptr_t)(addr[2 * h] + (uint32_t)(BUF * kPanelStride * 4));
+      vp2[h].y = *(lds_cf*)(uintptr_t)(addr[2 * h + 1] + (uint32_t)(BUF * kPanelStride * 4));
+    }
+    // (C) sum (q - x_k v) v  and  sum v^2
+    f32x2 corr2[2] = {{0.f, 0.f}, {0.f, 0.f}}, asq2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+    const f32x2 nxk2 = {-xk, -xk};
+#pragma unroll
+    for (int h = 0; h < EH; ++h) {
+      const f32x2 t = pk_fma(nxk2, vp2[h], q2[h]);
+      corr2[h & 1] = pk_fma(t, vp2[h], corr2[h & 1]);
+      asq2[h & 1] = pk_fma(vp2[h], vp2[h], asq2[h & 1]);
     }
     float corr_t = (corr2[0].x + corr2[0].y) + (corr2[1].x + corr2[1].y);
     float asq_t = (asq2[0].x + asq2[0].y) + (asq2[1].x + asq2[1].y);
@@ -240,11 +238,9 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
     corr_t = half_sum(corr_t);
     asq_t = half_sum(asq_t);
     const float ckk = Cs[k * KP + k];
-    const float psel = (NX == 2 && k >= 32) ? p[NX - 1] : p[0];
-    const float lsel = (NX == 2 && k >= 32) ? lam[NX - 1] : lam[0];
-    const float num = half_bcast(psel, k & 31, half) + corr_t;
+    const float num = half_bcast(p[HI], k & 31, half) + corr_t;
     const float tau_p = tau * (ckk - asq_t);
-    const float numer = fmaf(tau, num, -half_bcast(lsel, k & 31, half));
+    const float numer = fmaf(tau, num, -half_bcast(lam[HI], k & 31, half));
     float xnew = 0.f;
     if (MODE == kSweepDraw) {
       const TnFast tf = tn_fast_params(numer, tau_p);
@@ -252,16 +248,15 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
 #pragma unroll
       for (int c = 0; c < kHoist; ++c) {
         if (c == 0 || __ballot(!done)) {                      // wave-uniform: later candidates only when someone still needs one
-          const uint32_t sa = (NX == 2 && k >= 32) ? ca[c][NX - 1] : ca[c][0], sb = (NX == 2 && k >= 32) ? cb[c][NX - 1] : cb[c][0];
           float xc;
-          const bool acc = tn_eval_fast(tf, half_bcast_u(sa, k & 31, half), half_bcast_u(sb, k & 31, half), &xc);
+          const bool acc = tn_eval_fast(tf, half_bcast_u(ca[c][HI], k & 31, half), half_bcast_u(cb[c][HI], k & 31, half), &xc);
           if (!done && acc) { xnew = tn_guard(xc); done = true; }
         }
       }
       if (__ballot(!done)) {                                   // rare: fresh candidates kHoist.. : 32 per round
         TnParams tp;
         tp.mu = tf.mu; tp.rt = 1.0f / tf.irt; tp.a = tf.a; tp.d = tf.d; tp.lam = tf.a + tf.d; tp.live = tf.live; tp.tail = tf.tail;
-        for (uint32_t round = 0; round < 128u && __ballot(!done); ++round) {   // candidates 2.. : 32 per round
+        for (uint32_t round = 0; round < 128u && __ballot(!done); ++round) {
           float xr;
           const bool ar = tn_candidate(tp, (uint32_t)gi, (uint32_t)k, a.it, a.stream, (uint32_t)kHoist + round * 32u + (uint32_t)l5,
                                        a.key0, a.key1, &xr);
@@ -277,15 +272,22 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
       xnew = (valid && tau_p > 0.f && mu > 0.f) ? mu : 0.f;
     }
     dprev = xnew - xk;
-#pragma unroll
-    for (int nx = 0; nx < NX; ++nx)
-      if (l5 + 32 * nx == k) x[nx] = xnew;
-    if (REGATHER) {                         // q += d_k v_k now, re-reading the panel that is still resident
-      const f32x2 dk2 = {dprev, dprev};
-#pragma unroll
-      for (int h = 0; h < EH; ++h) q2[h] = pk_fma(dk2, f32x2{cur[off[2 * h]], cur[off[2 * h + 1]]}, q2[h]);
-    }
+    if (l5 + 32 * HI == k) x[HI] = xnew;
     __syncthreads();
+  };
+  using c0 = std::integral_constant<int, 0>;
+  using c1 = std::integral_constant<int, 1>;
+  using chi = std::integral_constant<int, NX - 1>;
+  const int K0 = K < 32 ? K : 32;
+  for (int k = 0; k < K0; k += 2) {
+    column(c0{}, c0{}, k);
+    if (k + 1 < K0) column(c1{}, c0{}, k + 1);
+  }
+  if (NX == 2) {                            // here K0 == 32: column 32 is in buffer 0 again
+    for (int k = 32; k < K; k += 2) {
+      column(c0{}, chi{}, k);
+      if (k + 1 < K) column(c1{}, chi{}, k + 1);
+    }
   }
 
   // ------------------------------------------------------------ results
@@ -300,8 +302,7 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
     for (int nx = 0; nx < NX; ++nx) px += (double)p[nx] * (double)x[nx];
 #pragma unroll
     for (int h = 0; h < EH; ++h) {
-      const double qa = REGATHER ? (double)q2[h].x : (double)fmaf(dprev, vp2[h % EV].x, q2[h].x);
-      const double qb = REGATHER ? (double)q2[h].y : (double)fmaf(dprev, vp2[h % EV].y, q2[h].y);
+      const double qa = (double)fmaf(dprev, vp2[h].x, q2[h].x), qb = (double)fmaf(dprev, vp2[h].y, q2[h].y);
       sq += qa + qb; sq2 += qa * qa + qb * qb;
     }
     px = half_sum_d(px); sq = half_sum_d(sq); sq2 = half_sum_d(sq2);
@@ -318,32 +319,27 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
 
 // One launch covers every block; a block's slot class (template EM) is the smallest class that
 // holds its fullest pair (units are sorted by slot count, so blocks are homogeneous).
-// NW = 16 (1024 threads, 32 units per CU in ONE resident block, <= 128 VGPRs) serves slot counts
-// up to 32; NW = 8 (512 threads, <= 256 VGPRs) serves the fuller units.
 template <int NX, int MODE, int NW>
-__global__ __launch_bounds__(NW * 64, (NW >= 8 ? NW / 4 : 2)) void sweep_fast_kernel(SweepArgs a, FastArgs f) {
+__global__ __launch_bounds__(NW * 64, 2) void sweep_fast_kernel(SweepArgs a, FastArgs f) {
   extern __shared__ float lds[];
   const int e0 = (int)f.pair_E[blockIdx.x * NW];      // descending order: first pair of the block is its fullest
-  if (NW == 16) {
-    if (e0 <= 8) sweep_fast_body<8, NX, MODE, NW>(a, f, lds);
-    else if (e0 <= 16) sweep_fast_body<16, NX, MODE, NW>(a, f, lds);
-    else if (e0 <= 24) sweep_fast_body<24, NX, MODE, NW>(a, f, lds);
-    else sweep_fast_body<32, NX, MODE, NW>(a, f, lds);
-  } else {
-    if (e0 <= 8) sweep_fast_body<8, NX, MODE, NW>(a, f, lds);
-    else if (e0 <= 16) sweep_fast_body<16, NX, MODE, NW>(a, f, lds);
-    else if (e0 <= 24) sweep_fast_body<24, NX, MODE, NW>(a, f, lds);
-    else if (e0 <= 32) sweep_fast_body<32, NX, MODE, NW>(a, f, lds);
-    else if (e0 <= 40) sweep_fast_body<40, NX, MODE, NW>(a, f, lds);
-    else if (e0 <= 48) sweep_fast_body<48, NX, MODE, NW>(a, f, lds);
-    else if (e0 <= kFastMaxSlots) sweep_fast_body<kFastMaxSlots, NX, MODE, NW>(a, f, lds);
-    else if (f.stats && threadIdx.x < 3) f.stats[(size_t)blockIdx.x * 4 + threadIdx.x] = 0.0;   // generic kernel owns these units
-  }
+  if (e0 <= 8) sweep_fast_body<8, NX, MODE, NW>(a, f, lds);
+  else if (e0 <= 16) sweep_fast_body<16, NX, MODE, NW>(a, f, lds);
+  else if (e0 <= 24) sweep_fast_body<24, NX, MODE, NW>(a, f, lds);
+  else if (e0 <= 32) sweep_fast_body<32, NX, MODE, NW>(a, f, lds);
+  else if (e0 <= 40) sweep_fast_body<40, NX, MODE, NW>(a, f, lds);
+  else if (e0 <= 48) sweep_fast_body<48, NX, MODE, NW>(a, f, lds);
+  else if (e0 <= kFastMaxSlots) sweep_fast_body<kFastMaxSlots, NX, MODE, NW>(a, f, lds);
+  else if (f.stats && threadIdx.x < 3) f.stats[(size_t)blockIdx.x * 4 + threadIdx.x] = 0.0;   // generic kernel owns these units
 }
 
-size_t sweep_fast_lds_bytes(int KP, int pw) { return sizeof(float) * ((size_t)KP * KP + 4 * (size_t)pw); }
+// C | max(pre-pass: two pair panels = 4 pw , main loop: two single panels kPanelStride apart)
+size_t sweep_fast_lds_bytes(int KP, int pw) {
+  const size_t panels = std::max<size_t>(4 * (size_t)pw, (size_t)kPanelStride + pw);
+  return sizeof(float) * ((size_t)KP * KP + panels);
+}
 
-bool sweep_fast_supported(int KP, int pw) { return sweep_fast_lds_bytes(KP, pw) <= 160 * 1024; }
+bool sweep_fast_supported(int KP, int pw) { return pw <= kPanelStride && sweep_fast_lds_bytes(KP, pw) <= 160 * 1024; }
 
 template <int NX, int MODE, int NW>
 static void launch_inst(const SweepArgs& a, const FastArgs& f, int nblocks, size_t lds_bytes, hipStream_t st) {
@@ -357,21 +353,6 @@ static void launch_inst(const SweepArgs& a, const FastArgs& f, int nblocks, size
 void launch_sweep_fast(const SweepArgs& a, const FastArgs& f, hipStream_t st) {
   const size_t lds_bytes = sweep_fast_lds_bytes(a.KP, f.pw);
   const int nx = a.KP / 32;
-  if (getenv("BNMTF_FAST_NW16")) {                 // experiment: 16-wave blocks for pairs with <= 32 slots
-    FastArgs lo = f, hi = f;
-    hi.npairs = f.npairs_hi;
-    lo.pair_E += f.npairs_hi; lo.pair_base += f.npairs_hi; lo.unit_map += 2 * f.npairs_hi; lo.npairs = f.npairs - f.npairs_hi;
-    if (lo.stats) lo.stats += (size_t)(f.npairs_hi / 8) * 4;
-    const int nb_hi = hi.npairs / 8, nb_lo = (lo.npairs + 15) / 16;
-    if (a.mode == kSweepDraw) {
-      if (nx == 1) { launch_inst<1, kSweepDraw, 8>(a, hi, nb_hi, lds_bytes, st); launch_inst<1, kSweepDraw, 16>(a, lo, nb_lo, lds_bytes, st); }
-      else         { launch_inst<2, kSweepDraw, 8>(a, hi, nb_hi, lds_bytes, st); launch_inst<2, kSweepDraw, 16>(a, lo, nb_lo, lds_bytes, st); }
-    } else {
-      if (nx == 1) { launch_inst<1, kSweepMode, 8>(a, hi, nb_hi, lds_bytes, st); launch_inst<1, kSweepMode, 16>(a, lo, nb_lo, lds_bytes, st); }
-      else         { launch_inst<2, kSweepMode, 8>(a, hi, nb_hi, lds_bytes, st); launch_inst<2, kSweepMode, 16>(a, lo, nb_lo, lds_bytes, st); }
-    }
-    return;
-  }
   const int nw = f.nw;
 #define BNMTF_L(NXV, MODEV)                                                                       \
   do {                                                                                            \
