@@ -102,6 +102,18 @@ __device__ __forceinline__ void stage_panel(const float* src, float* dst, int ch
   }
 }
 
+#ifdef BNMTF_PHASE_TIMING
+// debug build only (make timing): shader-clock stamps at the phase boundaries; a few blocks print their sums
+__device__ __forceinline__ unsigned long long tick(float dep) {
+  unsigned long long t;
+  asm volatile("s_waitcnt lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
+  return t;
+}
+#define TICK(i, dep) do { const unsigned long long t_ = tick(dep); ph[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define TICK(i, dep) do { } while (0)
+#endif
+
 constexpr int kPanelStride = 9216;              // floats between the two single-column panel buffers (>= pw)
 typedef __attribute__((address_space(3))) const float lds_cf;
 typedef __attribute__((address_space(3))) const f32x2 lds_cf2;
@@ -130,6 +142,9 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
   const size_t gi = (size_t)a.n0 + (valid ? u : 0);
   const int K = a.K;
 
+#ifdef BNMTF_PHASE_TIMING
+  const unsigned long long t_start = tick(0.f);
+#endif
   float x[NX], p[NX], lam[NX];
 #pragma unroll
   for (int nx = 0; nx < NX; ++nx) {
@@ -165,6 +180,9 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
       }
   }
 
+#ifdef BNMTF_PHASE_TIMING
+  const unsigned long long t_pre = tick(__builtin_bit_cast(float, ca[kHoist - 1][0] ^ addr[EM - 1]) + x[0] + p[0] + lam[0]);
+#endif
   // ------------------------------------------------------------ pre-pass: q = U_i . V_j  (pair panels)
   {
     const int chunks2 = (2 * PW) / 256;
@@ -202,6 +220,10 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
 
   // One column.  BUF (which panel buffer holds column k) and HI (k >= 32: which register of x/p/lam/ca/cb
   // owns column k) are compile-time, so the buffer offset is a ds_read immediate.
+#ifdef BNMTF_PHASE_TIMING
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = tick(q2[0].x);
+  const unsigned long long t_main = tlast;
+#endif
   auto column = [&](auto buf_c, auto hi_c, int k) {
     constexpr int BUF = decltype(buf_c)::value;
     constexpr int HI = decltype(hi_c)::value;
@@ -212,6 +234,7 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
 #pragma unroll
     for (int h = 0; h < EH; ++h) q2[h] = pk_fma(dp2, vp2[h], q2[h]);
     __builtin_amdgcn_sched_barrier(0);
+    TICK(0, q2[0].x);
     // (B) gather v_k into those registers: address register + immediate, no VALU
 #pragma unroll
     for (int h = 0; h < EH; ++h) {
@@ -235,6 +258,7 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
       const int kk = l5 + 32 * nx;
       if (kk != k) corr_t = fmaf(-x[nx], Cs[k * KP + kk], corr_t);
     }
+    TICK(1, corr_t + asq_t);
     corr_t = half_sum(corr_t);
     asq_t = half_sum(asq_t);
     const float ckk = Cs[k * KP + k];
@@ -242,6 +266,7 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
     const float tau_p = tau * (ckk - asq_t);
     const float numer = fmaf(tau, num, -half_bcast(lam[HI], k & 31, half));
     float xnew = 0.f;
+    TICK(2, numer + tau_p);
     if (MODE == kSweepDraw) {
       const TnFast tf = tn_fast_params(numer, tau_p);
       bool done = !tf.live || !valid;
@@ -272,8 +297,10 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
       xnew = (valid && tau_p > 0.f && mu > 0.f) ? mu : 0.f;
     }
     dprev = xnew - xk;
+    TICK(3, dprev);
     if (l5 + 32 * HI == k) x[HI] = xnew;
     __syncthreads();
+    TICK(4, dprev);
   };
   using c0 = std::integral_constant<int, 0>;
   using c1 = std::integral_constant<int, 1>;
@@ -290,6 +317,11 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
     }
   }
 
+#ifdef BNMTF_PHASE_TIMING
+  if (blockIdx.x % 97 == 0 && tid == 0)
+    printf("block %d EM %d: prologue %llu prepass %llu | A %llu  BC %llu  reduce %llu  sampler %llu  barrier %llu  (cycles, %d columns)\n",
+           (int)blockIdx.x, EM, t_pre - t_start, t_main - t_pre, ph[0], ph[1], ph[2], ph[3], ph[4], K);
+#endif
   // ------------------------------------------------------------ results
 #pragma unroll
   for (int nx = 0; nx < NX; ++nx) {
