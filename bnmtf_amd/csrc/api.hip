@@ -83,16 +83,20 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
   }
   d.nslots = idx.size();
 
-  // fast layout: a unit owns a 32-lane half wave.  Lane r prefers the entries with j mod 32 == r
-  // (bank-conflict-free LDS gathers).  Residue classes are binomially unbalanced, so instead of
-  // padding every lane to the fullest class, a unit gets E = mean + ~1 sigma slots per lane and the
-  // few overflow entries are parked in lanes with room (each costs one 2-way bank conflict).
+  // fast layout: a unit owns a 32-lane half wave.  Lane r prefers the entries with j mod 32 == r (bank-conflict-free
+  // LDS gathers).  Residue classes are binomially unbalanced, so instead of padding every lane to the fullest class
+  // a unit gets E = ceil(cnt / 32) slots per lane (rounded up to even) and the entries of over-full classes are
+  // parked in lanes with room.  A parked entry shares its row's LDS read with the entry of its own residue lane (a
+  // 2-way bank conflict: one extra LDS cycle for that row); parked entries are packed into the last rows, distinct
+  // residues per row, so that few rows pay it.  BNMTF_BALANCE=0 restores the padded conflict-free layout.
   d.mz = round_up(m, 32);
   d.pw = round_up(d.mz + 32, 256);
   {
+    const bool balance = !(getenv("BNMTF_BALANCE") && atoi(getenv("BNMTF_BALANCE")) == 0);
+    const uint32_t kNone = 0xFFFFFFFFu;
     std::vector<int> Eu(d.n, 0);
-    std::vector<std::vector<uint32_t>> lanes((size_t)d.n * 32);     // per unit, per lane: slot contents
-    std::vector<uint32_t> overflow;
+    std::vector<std::vector<uint32_t>> lanes((size_t)d.n * 32);     // per unit, per lane: slot contents (kNone = empty)
+    std::vector<std::vector<uint32_t>> over(32);
     for (int ul = 0; ul < d.n; ++ul) {
       std::vector<uint32_t>* L = &lanes[(size_t)ul * 32];
       size_t cnt = 0;
@@ -100,24 +104,37 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
         const uint32_t j = idx[t];
         if (j < (uint32_t)m) { L[j & 31].push_back(j); ++cnt; }
       }
-      const double mean = (double)cnt / 32.0;
-      int E = (int)std::ceil(mean + std::sqrt(mean));
-      E = std::max(2, (E + 1) & ~1);
       int emax = 0;
       for (int r = 0; r < 32; ++r) emax = std::max(emax, (int)L[r].size());
-      if (!getenv("BNMTF_BALANCE")) E = emax;       // default: pad every lane to the fullest residue class (conflict-free; measured faster than the balanced layout, which BNMTF_BALANCE=1 selects for experiments)
-      if (emax <= E) { E = std::max(2, (emax + 1) & ~1); }
-      else {
-        overflow.clear();
-        for (int r = 0; r < 32; ++r)
-          while ((int)L[r].size() > E) { overflow.push_back(L[r].back()); L[r].pop_back(); }
-        int lane = 0;
-        for (uint32_t j : overflow) {                      // round-robin over lanes with room
-          int tries = 0;
-          while ((int)L[lane].size() >= E && tries < 32) { lane = (lane + 1) & 31; ++tries; }
-          L[lane].push_back(j);
-          lane = (lane + 1) & 31;
+      int E = std::max(2, (emax + 1) & ~1);
+      const int Eb = std::max(2, ((int)((cnt + 31) / 32) + 1) & ~1);
+      if (balance && Eb < E) {
+        E = Eb;
+        size_t nover = 0;
+        for (int r = 0; r < 32; ++r) {
+          over[r].clear();
+          while ((int)L[r].size() > E) { over[r].push_back(L[r].back()); L[r].pop_back(); ++nover; }
         }
+        std::vector<int> own(32);
+        for (int r = 0; r < 32; ++r) { own[r] = (int)L[r].size(); L[r].resize(E, kNone); }
+        // last rows first; in a row every free lane takes a parked entry of a residue not yet parked in that row
+        int rr = 0;
+        for (int row = E - 1; row >= 0 && nover > 0; --row) {
+          uint32_t used = 0;
+          for (int lane = 0; lane < 32 && nover > 0; ++lane) {
+            if (own[lane] > row) continue;
+            int pick = -1;
+            for (int t = 0; t < 32; ++t) { const int r = (rr + t) & 31; if (!over[r].empty() && !((used >> r) & 1u)) { pick = r; break; } }
+            if (pick < 0) break;
+            L[lane][row] = over[pick].back(); over[pick].pop_back(); --nover;
+            used |= 1u << pick; rr = (pick + 1) & 31;
+          }
+        }
+        for (int row = E - 1; row >= 0 && nover > 0; --row)      // leftovers (same residue twice in a row): any free slot
+          for (int lane = 0; lane < 32 && nover > 0; ++lane) {
+            if (L[lane][row] != kNone) continue;
+            for (int r = 0; r < 32; ++r) if (!over[r].empty()) { L[lane][row] = over[r].back(); over[r].pop_back(); --nover; break; }
+          }
       }
       Eu[ul] = E;
     }
@@ -125,20 +142,39 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
     std::vector<int> order(d.n);
     for (int i = 0; i < d.n; ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return Eu[x] > Eu[y]; });
-    d.f_npairs = (d.n + 1) / 2;
+    // Units pair up in descending slot-count order.  The 8-wave kernel takes the pairs in that order (homogeneous
+    // blocks, one slot class per block).  The 16-wave kernel picks the class per WAVE, so its pairs are dealt to the
+    // blocks boustrophedon (and to the four SIMDs of a block likewise): every block, and every SIMD, gets the same mix
+    // of full and light units, and one round of blocks ends together.
+    const int npairs_real = (d.n + 1) / 2;
+    const int emax_all = d.n > 0 ? Eu[order[0]] : 0;
+    const int wide_blocks = (npairs_real + 15) / 16;
+    const bool wide_can = sweep_wide_supported(d.KP, d.pw) && emax_all <= kWideMaxSlots && d.n > 0;
+    d.use_wide = wide_can && wide_blocks >= 192;
+    if (const char* e = getenv("BNMTF_WIDE")) d.use_wide = wide_can && atoi(e) != 0;      // 0: never, 1: whenever it can run
+    d.f_npairs = d.use_wide ? wide_blocks * 16 : npairs_real;
+    auto slot_of = [&](int pi) {
+      if (!d.use_wide) return pi;
+      const int r = pi / wide_blocks, c = pi % wide_blocks;
+      const int blk = (r & 1) ? wide_blocks - 1 - c : c;
+      const int t = r >> 2, sx = r & 3;
+      return blk * 16 + 4 * t + ((t & 1) ? 3 - sx : sx);
+    };
     std::vector<int> umap((size_t)d.f_npairs * 2, -1);
-    std::vector<uint32_t> pE(d.f_npairs), pB(d.f_npairs);
-    size_t rows_total = 0;
+    std::vector<uint32_t> pE(d.f_npairs, 0u), pB(d.f_npairs, 0u);
     d.f_emax = 0;
-    for (int pi = 0; pi < d.f_npairs; ++pi) {
+    for (int pi = 0; pi < npairs_real; ++pi) {
       int e = 0;
+      const int sl = slot_of(pi);
       for (int hh = 0; hh < 2; ++hh) {
         const int pos = 2 * pi + hh;
-        if (pos < d.n) { umap[pos] = order[pos]; e = std::max(e, Eu[order[pos]]); }
+        if (pos < d.n) { umap[2 * sl + hh] = order[pos]; e = std::max(e, Eu[order[pos]]); }
       }
-      pE[pi] = (uint32_t)e; pB[pi] = (uint32_t)rows_total; rows_total += e;
+      pE[sl] = (uint32_t)e;
       d.f_emax = std::max(d.f_emax, e);
     }
+    size_t rows_total = 0;
+    for (int sl = 0; sl < d.f_npairs; ++sl) { pB[sl] = (uint32_t)rows_total; rows_total += pE[sl]; }
     std::vector<uint32_t> off(std::max<size_t>(rows_total, 1) * 64);
     for (int pi = 0; pi < d.f_npairs; ++pi)
       for (int hh = 0; hh < 2; ++hh) {
@@ -146,7 +182,7 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
         for (uint32_t sidx = 0; sidx < pE[pi]; ++sidx)
           for (int r = 0; r < 32; ++r) {
             uint32_t v = (uint32_t)(d.mz + r);
-            if (ul >= 0) { const auto& lst = res(ul, r); if (sidx < lst.size()) v = lst[sidx]; }
+            if (ul >= 0) { const auto& lst = res(ul, r); if (sidx < lst.size() && lst[sidx] != kNone) v = lst[sidx]; }
             off[((size_t)pB[pi] + sidx) * 64 + hh * 32 + r] = v;
           }
       }
@@ -184,7 +220,8 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
       // waves per block: 8 when there are enough units for >= 256 blocks, else 4 or 2 (multi-GPU shards, small problems)
       d.f_nw = d.f_npairs >= 8 * 256 ? 8 : (d.f_npairs >= 4 * 256 ? 4 : (d.f_npairs >= 2 * 64 ? 2 : 8));
       if (const char* e = getenv("BNMTF_FAST_NW")) d.f_nw = atoi(e) == 2 ? 2 : (atoi(e) == 4 ? 4 : 8);
-      for (int b0 = 0; b0 < d.f_npairs; b0 += d.f_nw)
+      if (d.use_wide) d.f_nw = 16;
+      for (int b0 = 0; b0 < d.f_npairs && !d.use_wide; b0 += d.f_nw)
         if ((int)pE[b0] > kFastMaxSlots)
           for (int t = 2 * b0; t < std::min(2 * (b0 + d.f_nw), 2 * d.f_npairs); ++t) if (umap[t] >= 0) gen.push_back(umap[t]);
       d.fast_ok = true;
@@ -308,7 +345,8 @@ static void enqueue_sweep(bnmtf_model* h, Dir& d, const Dir& other, SweepArgs& s
       const bool nw16 = getenv("BNMTF_PAIR_NW8") == nullptr && d.f_npairs_hi40 < d.f_npairs;
       if (nw16) f.npairs_hi = d.f_npairs_hi40;
       launch_sweep_pair(s2, f, nw16, h->stream);
-    } else launch_sweep_fast(s2, f, h->stream);
+    } else if (d.use_wide) launch_sweep_wide(s2, f, h->stream);
+    else launch_sweep_fast(s2, f, h->stream);
     h->last_sweep_fast = true;
     if (d.f_gen_count == 0) return;
     s.unit_list = d.f_gen_units;           // the few units with more than kFastMaxSlots slots per lane

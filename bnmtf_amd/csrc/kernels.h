@@ -90,6 +90,10 @@ struct FastArgs {
 constexpr int kFastMaxSlots = 56;   // blocks whose fullest pair needs more slots per lane go to the generic kernel
 bool sweep_fast_supported(int KP, int pw);
 void launch_sweep_fast(const SweepArgs& a, const FastArgs& f, hipStream_t st);
+// 16-wave kernel (kernel_sweep_wide.hip): balanced slots, at most kWideMaxSlots per lane, 16 pairs per block
+constexpr int kWideMaxSlots = 32;
+bool sweep_wide_supported(int KP, int pw);
+void launch_sweep_wide(const SweepArgs& a, const FastArgs& f, hipStream_t st);
 // pair-step kernel (kernel_sweep_pair.hip); f.npairs_hi = leading pairs with more than 40 slots when nw16
 void launch_sweep_pair(const SweepArgs& a, const FastArgs& f, bool nw16, hipStream_t st);
 

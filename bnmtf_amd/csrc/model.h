@@ -60,6 +60,7 @@ struct Dir {
   int* f_gen_units = nullptr; int f_gen_count = 0;
   double* stats = nullptr; int stats_blocks = 0;
   bool fast_ok = false;
+  bool use_wide = false;                 // 16-wave sweep kernel (pairs dealt to blocks per wave class) instead of the 8-wave one
   double* C64 = nullptr; float* C32 = nullptr; double* colsum = nullptr;   // Gram of X
   // VB only
   float *mu = nullptr, *tauq = nullptr, *var = nullptr, *S2 = nullptr, *S2T = nullptr;

@@ -1,0 +1,89 @@
+// Shared device helpers of the register-resident sweep kernels (kernel_sweep_fast.hip, kernel_sweep_wide.hip):
+// half-wave reductions and broadcasts, the one-instruction TN candidate arithmetic, LDS-DMA panel staging.
+#pragma once
+#include "kernels.h"
+#include "device_rng.h"
+
+namespace bnmtf {
+
+__device__ __forceinline__ float dpp_xor_row_sum(float v) {   // all-reduce inside each 16-lane row
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
+__device__ __forceinline__ float half_sum(float v) {          // all-reduce inside each 32-lane half
+  v = dpp_xor_row_sum(v);
+#ifdef BNMTF_USE_PERMLANE16
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const unsigned b = __builtin_bit_cast(unsigned, v);
+  const u32x2 r = __builtin_amdgcn_permlane16_swap(b, b, false, false);   // (row0,row0,row2,row2) , (row1,row1,row3,row3)
+  return __builtin_bit_cast(float, r.x) + __builtin_bit_cast(float, r.y);
+#else
+  return v + __shfl_xor(v, 16, 64);
+#endif
+}
+__device__ __forceinline__ double half_sum_d(double v) {
+#pragma unroll
+  for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+// value held by lane (half*32 + src) for every lane of that half
+__device__ __forceinline__ float half_bcast(float v, int src, int half) {
+  const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+  const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src + 32));
+  return half ? a1 : a0;
+}
+__device__ __forceinline__ uint32_t half_bcast_u(uint32_t v, int src, int half) {
+  const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)v, src);
+  const uint32_t a1 = (uint32_t)__builtin_amdgcn_readlane((int)v, src + 32);
+  return half ? a1 : a0;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// reciprocal-based parameters (v_rcp / v_rsq, ~1 ulp): the sampler needs no correctly rounded division
+struct TnFast { float mu, irt, a, d, ilam; bool live, tail; };
+__device__ __forceinline__ TnFast tn_fast_params(float numer, float tau_p) {
+  TnFast p;
+  p.live = tau_p > 0.0f;
+  const float tp = p.live ? tau_p : 1.0f;
+  p.irt = __builtin_amdgcn_rsqf(tp);             // sigma   (v_rsq_f32 / v_rcp_f32 / v_sqrt_f32: ~1 ulp, one instruction each)
+  p.mu = numer * __builtin_amdgcn_rcpf(tp);
+  p.a = -p.mu * (tp * p.irt);                    // -mu * sqrt(tau)
+  p.live = p.live && isfinite(p.a);
+  p.d = 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(p.a, p.a, 4.0f)) + p.a);
+  p.ilam = __builtin_amdgcn_rcpf(p.a + p.d);
+  p.tail = p.a >= kTnA0;
+  return p;
+}
+__device__ __forceinline__ bool tn_eval_fast(const TnFast& p, uint32_t r0, uint32_t r1, float* x) {
+  const float u1 = u24(r0), u2 = u24(r1);
+  const float nl = -0.69314718f * __builtin_amdgcn_logf(u1);            // v_log_f32 is log2
+  const float e = nl * p.ilam;
+  const float t = e - p.d;
+  const bool acc_t = u2 <= __builtin_amdgcn_exp2f(-0.72134752f * t * t);   // exp(-t^2/2) via v_exp_f32 (2^x)
+  const float z = __builtin_amdgcn_sqrtf(2.0f * nl) * __builtin_amdgcn_cosf(u2);   // v_cos_f32 takes revolutions
+  const bool acc_n = z >= p.a;
+  *x = p.tail ? e * p.irt : fmaf(z, p.irt, p.mu);
+  return p.tail ? acc_t : acc_n;
+}
+
+// LDS-direct staging of one panel: `chunks` pieces of 1 KiB (64 lanes x 16 B), wave w takes
+// chunks w, w+8, ...  No VGPRs, no ds_write; completion is covered by the vmcnt(0) that
+// __syncthreads() carries while an LDS-DMA is in flight.
+template <int NW>
+__device__ __forceinline__ void stage_panel(const float* src, float* dst, int chunks, int wave, int lane) {
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  for (int c = wave; c < chunks; c += NW) {
+    __builtin_amdgcn_global_load_lds(src + (size_t)c * 256 + lane * 4, (lds_ptr)(dst + (size_t)c * 256), 16, 0, 0);
+  }
+}
+
+typedef __attribute__((address_space(3))) const float lds_cf;
+typedef __attribute__((address_space(3))) const f32x2 lds_cf2;
+typedef __attribute__((address_space(3))) float* lds_fp;
+
+}  // namespace bnmtf
