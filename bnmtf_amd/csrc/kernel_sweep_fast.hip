@@ -25,18 +25,6 @@
 
 namespace bnmtf {
 
-#ifdef BNMTF_PHASE_TIMING
-// debug build only (make timing): shader-clock stamps at the phase boundaries; a few blocks print their sums
-__device__ __forceinline__ unsigned long long tick(float dep) {
-  unsigned long long t;
-  asm volatile("s_waitcnt lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
-  return t;
-}
-#define TICK(i, dep) do { const unsigned long long t_ = tick(dep); ph[i] += t_ - tlast; tlast = t_; } while (0)
-#else
-#define TICK(i, dep) do { } while (0)
-#endif
-
 constexpr int kPanelStride = 9216;              // floats between the two single-column panel buffers (>= pw)
 
 template <int EM, int NX, int MODE, int NW>

@@ -51,6 +51,9 @@ __device__ __forceinline__ void sweep_wide_body(const SweepArgs& a, const FastAr
   const int K = a.K;
   const float tau = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *a.tau)));
 
+#ifdef BNMTF_PHASE_TIMING
+  const unsigned long long t_start = tick(0.f);
+#endif
   // x = the unit's row of the factor; pl = tau * P - lambda, the part of the conditional's numerator that does not
   // change during the sweep (P = the contraction slabs summed)
   float x[NX], pl[NX];
@@ -77,6 +80,9 @@ __device__ __forceinline__ void sweep_wide_body(const SweepArgs& a, const FastAr
   for (int h = 0; h < EH; ++h) { q2[h] = f32x2{0.f, 0.f}; vp2[h] = f32x2{0.f, 0.f}; }
   for (int t = tid; t < KP * KP; t += NW * 64) Cs[t] = a.C32[t];
 
+#ifdef BNMTF_PHASE_TIMING
+  const unsigned long long t_pre = tick(__builtin_bit_cast(float, addr[EM - 1]) + x[0] + pl[0]);
+#endif
   // ------------------------------------------------------------ pre-pass: q = U_i . V_j  (pair panels)
   {
     const int chunks2 = (2 * PW) / 256;
@@ -105,6 +111,9 @@ __device__ __forceinline__ void sweep_wide_body(const SweepArgs& a, const FastAr
     for (int h = 0; h < EH; ++h) { q2[h] = f32x2{q2[h].x + q2[h].y, vp2[h].x + vp2[h].y}; vp2[h] = f32x2{0.f, 0.f}; }
   }
 
+#ifdef BNMTF_PHASE_TIMING
+  const unsigned long long t_tab = tick(q2[0].x);
+#endif
   // ------------------------------------------------------------ candidate table + first panel
   const int chunks1 = PW / 256;
   stage_panel<NW>(f.XoT, pan, chunks1, wave, lane);
@@ -128,6 +137,10 @@ __device__ __forceinline__ void sweep_wide_body(const SweepArgs& a, const FastAr
 
   // One column.  BUF (which panel buffer holds column k) and HI (k >= 32: which register of x/p/lam owns column k)
   // are compile-time, so the buffer offset is a ds_read immediate.
+#ifdef BNMTF_PHASE_TIMING
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = tick(q2[0].x);
+  const unsigned long long t_main = tlast;
+#endif
   auto column = [&](auto buf_c, auto hi_c, int k) {
     constexpr int BUF = decltype(buf_c)::value;
     constexpr int HI = decltype(hi_c)::value;
@@ -138,6 +151,7 @@ __device__ __forceinline__ void sweep_wide_body(const SweepArgs& a, const FastAr
 #pragma unroll
     for (int h = 0; h < EH; ++h) q2[h] = pk_fma(dp2, vp2[h], q2[h]);
     __builtin_amdgcn_sched_barrier(0);
+    TICK(0, q2[0].x);
     // (B) gather v_k into those registers: address register + immediate, no VALU
 #pragma unroll
     for (int h = 0; h < EH; ++h) {
@@ -155,53 +169,50 @@ __device__ __forceinline__ void sweep_wide_body(const SweepArgs& a, const FastAr
     float asq_t = (vv2[0].x + vv2[0].y) + (vv2[1].x + vv2[1].y);
     float corr_t = fmaf(-xk, asq_t, (qv2[0].x + qv2[0].y) + (qv2[1].x + qv2[1].y));
 #pragma unroll
-    for (int nx = 0; nx < NX; ++nx) {
-      const int kk = l5 + 32 * nx;
-      if (kk != k) corr_t = fmaf(-x[nx], Cs[k * KP + kk], corr_t);
-    }
+    for (int nx = 0; nx < NX; ++nx) corr_t = fmaf(-x[nx], Cs[k * KP + l5 + 32 * nx], corr_t);   // all l: the l = k term is put back below
+    TICK(1, corr_t + asq_t);
     u32x2 cw = {0u, 0u};
     if (MODE == kSweepDraw) cw = *(lds_cu2*)(uintptr_t)(mytab_b + (uint32_t)(k * NC * 8));
     corr_t = half_sum(corr_t);
     asq_t = half_sum(asq_t);
     const float ckk = Cs[k * KP + k];
     const float tau_p = tau * (ckk - asq_t);
-    const float numer = fmaf(tau, corr_t, half_bcast(pl[HI], k & 31, half));
+    const float numer = fmaf(tau, fmaf(xk, ckk, corr_t), half_bcast(pl[HI], k & 31, half));
     float xnew = 0.f;
+    TICK(2, numer + tau_p);
     if (MODE == kSweepDraw) {
       const TnFast tf = tn_fast_params(numer, tau_p);
       bool done = !tf.live || !valid;
-      // lane c (< NC) of each half evaluates candidate c; the first accepted one is the draw
-      float xc;
-      const bool acc = tn_eval_fast(tf, cw.x, cw.y, &xc) && l5 < NC;
-      xc = tn_guard(xc);
-      const unsigned long long m = __ballot(acc);
-      const uint32_t m0 = (uint32_t)m, m1 = (uint32_t)(m >> 32);
-      const int f0 = m0 ? __ffs((int)m0) - 1 : 0, f1 = m1 ? __ffs((int)m1) - 1 : 0;
-      const float x0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xc), f0));
-      const float x1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xc), 32 + f1));
-      const bool found = half ? (m1 != 0u) : (m0 != 0u);
-      if (!done && found) { xnew = half ? x1 : x0; done = true; }
-      if (__ballot(!done)) {                                   // rare: fresh candidates NC.. : 32 per round
-        TnParams tp;
-        tp.mu = tf.mu; tp.rt = 1.0f / tf.irt; tp.a = tf.a; tp.d = tf.d; tp.lam = tf.a + tf.d; tp.live = tf.live; tp.tail = tf.tail;
-        for (uint32_t round = 0; round < 128u && __ballot(!done); ++round) {
-          float xr;
-          const bool ar = tn_candidate(tp, gi, (uint32_t)k, a.it, a.stream, (uint32_t)NC + round * 32u + (uint32_t)l5,
-                                       a.key0, a.key1, &xr);
-          const unsigned long long mm = __ballot(ar);
-          const uint32_t mh = half ? (uint32_t)(mm >> 32) : (uint32_t)mm;
-          const int first = mh ? __ffs((int)mh) - 1 : 0;
-          const float xf = __shfl(xr, half * 32 + first, 64);
-          if (!done && mh) { xnew = tn_guard(xf); done = true; }
-        }
+      // lane c (< NC) of each half evaluates candidate c of the batch; the first accepted one is the draw.  Batch 0
+      // comes from the table; a wave in which some unit rejected a whole batch (rare) computes the next NC candidates
+      // (numbers NC, NC+1, ... : the oracle's candidate sequence) and runs the same code again.
+      for (uint32_t cbase = 0;;) {
+        float xc;
+        const bool acc = tn_eval_fast(tf, cw.x, cw.y, &xc) && l5 < NC;
+        xc = tn_guard(xc);
+        const unsigned long long m = __ballot(acc);
+        const uint32_t m0 = (uint32_t)m, m1 = (uint32_t)(m >> 32);
+        const int f0 = m0 ? __ffs((int)m0) - 1 : 0, f1 = m1 ? __ffs((int)m1) - 1 : 0;
+        const float x0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xc), f0));
+        const float x1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xc), 32 + f1));
+        const bool found = half ? (m1 != 0u) : (m0 != 0u);
+        if (!done && found) { xnew = half ? x1 : x0; done = true; }
+        cbase += NC;
+        if (!__ballot(!done) || cbase >= 4096u) break;
+        uint32_t row = gi;
+        asm volatile("" : "+v"(row));                            // opaque: nothing of this Philox call is hoisted out of the column loop
+        const U4 r = philox4x32_10(row, (uint32_t)k, a.it, a.stream + 16u * (cbase + (uint32_t)(l5 & (NC - 1))), a.key0, a.key1);
+        cw = u32x2{r.x, r.y};
       }
     } else {
       const float mu = numer / tau_p;
       xnew = (valid && tau_p > 0.f && mu > 0.f) ? mu : 0.f;
     }
     dprev = xnew - xk;
+    TICK(3, dprev);
     if (l5 + 32 * HI == k) x[HI] = xnew;
     __syncthreads();
+    TICK(4, dprev);
   };
   using c0 = std::integral_constant<int, 0>;
   using c1 = std::integral_constant<int, 1>;
@@ -218,6 +229,11 @@ __device__ __forceinline__ void sweep_wide_body(const SweepArgs& a, const FastAr
     }
   }
 
+#ifdef BNMTF_PHASE_TIMING
+  if (blockIdx.x % 61 == 0 && (tid & 255) == 0)
+    printf("block %d wave %d EM %d: prologue %llu prepass %llu table %llu | A %llu  BC %llu  reduce %llu  sampler %llu  barrier %llu  (cycles, %d columns)\n",
+           (int)blockIdx.x, wave, EM, t_pre - t_start, t_tab - t_pre, t_main - t_tab, ph[0], ph[1], ph[2], ph[3], ph[4], K);
+#endif
   // ------------------------------------------------------------ results
 #pragma unroll
   for (int nx = 0; nx < NX; ++nx) {

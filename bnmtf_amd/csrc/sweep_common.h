@@ -82,6 +82,18 @@ __device__ __forceinline__ void stage_panel(const float* src, float* dst, int ch
   }
 }
 
+#ifdef BNMTF_PHASE_TIMING
+// debug build only (make timing): shader-clock stamps at the phase boundaries; a few blocks print their sums
+__device__ __forceinline__ unsigned long long tick(float dep) {
+  unsigned long long t;
+  asm volatile("s_waitcnt lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
+  return t;
+}
+#define TICK(i, dep) do { const unsigned long long t_ = tick(dep); ph[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define TICK(i, dep) do { } while (0)
+#endif
+
 typedef __attribute__((address_space(3))) const float lds_cf;
 typedef __attribute__((address_space(3))) const f32x2 lds_cf2;
 typedef __attribute__((address_space(3))) float* lds_fp;
