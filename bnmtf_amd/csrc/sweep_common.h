@@ -91,7 +91,10 @@ __device__ __forceinline__ unsigned long long tick(float dep) {
 }
 #define TICK(i, dep) do { const unsigned long long t_ = tick(dep); ph[i] += t_ - tlast; tlast = t_; } while (0)
 #else
-#define TICK(i, dep) do { } while (0)
+// Phase boundary: nothing is scheduled across it.  Left to itself the compiler interleaves the latency-bound reduction
+// and sampler chain with the slot work of the same wave; with several waves per SIMD that costs ~25 % (measured),
+// because a wave then holds issue slots in its slot phase that the other waves' chains could have used.
+#define TICK(i, dep) __builtin_amdgcn_sched_barrier(0)
 #endif
 
 typedef __attribute__((address_space(3))) const float lds_cf;
