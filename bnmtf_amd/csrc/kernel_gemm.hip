@@ -16,6 +16,7 @@
 // inner dimension; the four waves of a block reduce through LDS and the block writes
 // one partial slab, which the sweep kernel sums in its prologue.
 #include <cstdlib>
+#include <cstring>
 
 #include "kernels.h"
 
@@ -139,11 +140,173 @@ __global__ __launch_bounds__(256, WPS) void gemm_kernel(GemmArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// The same product on the bf16 matrix cores, exact to fp32: every fp32 operand is split into three bf16 terms
+// x = hi + mid + lo (8 significant bits each, round-to-nearest residuals) and the product is taken as
+//   hi.hi + hi.mid + mid.hi + hi.lo + lo.hi + mid.mid        (the dropped terms are below 2^-24 of the product)
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Six bf16 MFMAs (32 cycles each) replace eight f32 MFMAs (64 cycles
+// each) per 16 inner rows: the contraction stops being bound by the matrix cores (f32 MFMA peak = 157 TFLOP/s) and
+// becomes a stream of R~ from HBM.
+//   A (factor):  lane l holds A[i = l&31][k = 8*(l>>5) .. +7]  -> X[r0 + 8*(l>>5) + 0..7][mt*32 + (l&31)]
+//   B (R~):      lane l holds B[k = 8*(l>>5) .. +7][j = l&31]  -> big[r0 + 8*(l>>5) + 0..7][col0 + 4*(l&31) + t]
+//   D: as the f32 32x32 tile (reg g, lane l -> i = (g&3) + 8*(g>>2) + 4*(l>>5), j = l&31)
+// so the loads (one dwordx4 per lane per row: four interleaved column tiles), the per-wave inner slices, the LDS tree
+// reduction and the slab layout are those of gemm_kernel.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2g __attribute__((ext_vector_type(2)));
+
+// 8 fp32 -> three packed bf16x8 planes (element j of a plane = bf16 term of v[j]).  Round-to-nearest at every level
+// (v_cvt_pk_bf16_f32): the residuals are signed, so the three dropped cross terms have no systematic sign -- with
+// truncation they are all positive for positive operands and bias the sums by ~2^-25, which the SSE identity sees.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2c __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_rne(float a0, float a1) {
+  f32x2c v; v.x = a0; v.y = a1;
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ void split3(const float (&v)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float a0 = v[2 * p], a1 = v[2 * p + 1];
+    const uint32_t h = pack_rne(a0, a1);
+    hi[p] = h;
+    const float b0 = a0 - __builtin_bit_cast(float, h << 16);                 // exact
+    const float b1 = a1 - __builtin_bit_cast(float, h & 0xffff0000u);
+    const uint32_t m = pack_rne(b0, b1);
+    mid[p] = m;
+    const float c0 = b0 - __builtin_bit_cast(float, m << 16);                 // exact
+    const float c1 = b1 - __builtin_bit_cast(float, m & 0xffff0000u);
+    lo[p] = pack_rne(c0, c1);
+  }
+}
+
+template <int MT>
+__global__ __launch_bounds__(256, 1) void gemm_bf16x3_kernel(GemmArgs a) {
+  constexpr int KP = MT * 32;
+  constexpr int NACC = MT * 4 * 16;            // accumulator floats per lane
+  constexpr int NSET = 3;                      // register sets of raw operands: two 16-row steps in flight behind the one being multiplied
+  __shared__ float red[2][NACC * 64];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, c = lane & 31;
+  const int col0 = blockIdx.x * 128;
+  const int s = blockIdx.y;
+  const int ipw = a.inner_per_wave;
+  const size_t r0 = (size_t)(s * 4 + wave) * ipw + 8 * h;
+
+  const float* bp = a.big + r0 * (size_t)a.ld + col0 + 4 * c;
+  const float* xp = a.X + r0 * KP + c;
+
+  f32x16 acc[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[mt][t][g] = 0.0f;
+
+  f32x4 braw[NSET][8];
+  float araw[NSET][MT][8];
+  auto load_step = [&](f32x4 (&b)[8], float (&av)[MT][8]) {
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      b[rr] = *reinterpret_cast<const f32x4*>(bp + (size_t)rr * a.ld);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) av[mt][rr] = xp[rr * KP + mt * 32];
+    }
+    bp += 16 * (size_t)a.ld;
+    xp += 16 * KP;
+  };
+  auto mul_step = [&](const f32x4 (&b)[8], const float (&av)[MT][8]) {
+    u32x4 ah[MT], am[MT], al[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) split3(av[mt], ah[mt], am[mt], al[mt]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float bv[8];
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) bv[rr] = b[rr][t];
+      u32x4 bh, bm, bl;
+      split3(bv, bh, bm, bl);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        f32x16 d = acc[mt][t];
+        // small terms first
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[mt]), __builtin_bit_cast(bf16x8, bh), d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[mt]), __builtin_bit_cast(bf16x8, bl), d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, am[mt]), __builtin_bit_cast(bf16x8, bm), d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, am[mt]), __builtin_bit_cast(bf16x8, bh), d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[mt]), __builtin_bit_cast(bf16x8, bm), d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[mt]), __builtin_bit_cast(bf16x8, bh), d, 0, 0, 0);
+        acc[mt][t] = d;
+      }
+    }
+  };
+  const int nsteps = ipw / 16;                    // ipw is a multiple of 32 (host pads)
+  load_step(braw[0], araw[0]);
+  if (nsteps > 1) load_step(braw[1], araw[1]);
+  for (int g = 0; g < nsteps; g += 3) {
+    if (g + 2 < nsteps) load_step(braw[2], araw[2]);
+    mul_step(braw[0], araw[0]);
+    if (g + 1 < nsteps) {
+      if (g + 3 < nsteps) load_step(braw[0], araw[0]);
+      mul_step(braw[1], araw[1]);
+    }
+    if (g + 2 < nsteps) {
+      if (g + 4 < nsteps) load_step(braw[1], araw[1]);
+      mul_step(braw[2], araw[2]);
+    }
+  }
+
+  // cross-wave tree reduction through LDS: (2,3) -> (0,1), then 1 -> 0
+  auto put = [&](float* dst) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) dst[((mt * 4 + t) * 16 + g) * 64 + lane] = acc[mt][t][g];
+  };
+  auto add = [&](const float* src) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[mt][t][g] += src[((mt * 4 + t) * 16 + g) * 64 + lane];
+  };
+  if (wave >= 2) put(red[wave - 2]);
+  __syncthreads();
+  if (wave < 2) add(red[wave]);
+  __syncthreads();
+  if (wave == 1) put(red[0]);
+  __syncthreads();
+  if (wave == 0) {
+    add(red[0]);
+    float* out = a.slabs + ((size_t)s * a.n_pad + col0) * KP;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          f32x4 v = {acc[mt][t][4 * g4], acc[mt][t][4 * g4 + 1], acc[mt][t][4 * g4 + 2], acc[mt][t][4 * g4 + 3]};
+          *reinterpret_cast<f32x4*>(out + (size_t)(4 * c + t) * KP + mt * 32 + 8 * g4 + 4 * h) = v;
+        }
+  }
+}
+
 void launch_gemm(const GemmArgs& a, int KP, hipStream_t st) {
   dim3 grid(a.n_pad / 128, a.split), block(256);
-  static const bool u8 = getenv("BNMTF_GEMM_U8") != nullptr;     // experiment: 8-deep groups, two waves per SIMD
+  static const char* mode = getenv("BNMTF_GEMM");                 // "f32": the f32-MFMA kernel (kept for comparison)
+  static const bool f32 = mode && !strcmp(mode, "f32");
+  if (!f32) {
+    if (KP == 32) hipLaunchKernelGGL((gemm_bf16x3_kernel<1>), grid, block, 0, st, a);
+    else          hipLaunchKernelGGL((gemm_bf16x3_kernel<2>), grid, block, 0, st, a);
+    return;
+  }
   if (KP == 32) hipLaunchKernelGGL((gemm_kernel<1, 16, 2>), grid, block, 0, st, a);
-  else if (u8)  hipLaunchKernelGGL((gemm_kernel<2, 8, 2>), grid, block, 0, st, a);
   else          hipLaunchKernelGGL((gemm_kernel<2, 16, 1>), grid, block, 0, st, a);
 }
 

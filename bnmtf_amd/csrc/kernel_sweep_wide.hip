@@ -86,12 +86,13 @@ __device__ __forceinline__ void sweep_wide_body(const SweepArgs& a, const FastAr
   // ------------------------------------------------------------ pre-pass: q = U_i . V_j  (pair panels)
   {
     const int chunks2 = (2 * PW) / 256;
-    const size_t stride = (size_t)f.ld2_o * 2;
-    stage_panel<NW>(f.XoT2, pan, chunks2, wave, lane);
+    const uint32_t stride_b = (uint32_t)f.ld2_o * 8u;
+    const __amdgpu_buffer_rsrc_t rs2 = panel_rsrc(f.XoT2, (size_t)(KP / 2) * f.ld2_o * 8);
+    stage_panel_buf<NW>(rs2, 0u, pan, chunks2, wave, lane * 16);
     __syncthreads();
     const int npair = KP / 2;
     for (int kp = 0; kp < npair; ++kp) {
-      if (kp + 1 < npair) stage_panel<NW>(f.XoT2 + (size_t)(kp + 1) * stride, pan + (size_t)((kp + 1) & 1) * 2 * PW, chunks2, wave, lane);
+      if (kp + 1 < npair) stage_panel_buf<NW>(rs2, (uint32_t)(kp + 1) * stride_b, pan + (size_t)((kp + 1) & 1) * 2 * PW, chunks2, wave, lane * 16);
       // element j of a pair panel sits 8 j bytes in: 2 * addr - pan_b (+ the buffer's offset)
       const uint32_t boff = (uint32_t)((kp & 1) * 2 * PW) * 4u - pan_b;
       const int k0 = 2 * kp, k1 = 2 * kp + 1;
@@ -116,7 +117,8 @@ __device__ __forceinline__ void sweep_wide_body(const SweepArgs& a, const FastAr
 #endif
   // ------------------------------------------------------------ candidate table + first panel
   const int chunks1 = PW / 256;
-  stage_panel<NW>(f.XoT, pan, chunks1, wave, lane);
+  const __amdgpu_buffer_rsrc_t rs1 = panel_rsrc(f.XoT, (size_t)KP * f.ldT_o * 4);
+  stage_panel_buf<NW>(rs1, 0u, pan, chunks1, wave, lane * 16);
   if (MODE == kSweepDraw) {
     // entry ((unit * KP + col) * NC + c) = words (x, y) of Philox(row, col, it, stream | c << 4): the RNG streams of
     // oracle/rng.py, produced by whichever thread the flat index falls on
@@ -144,7 +146,7 @@ __device__ __forceinline__ void sweep_wide_body(const SweepArgs& a, const FastAr
   auto column = [&](auto buf_c, auto hi_c, int k) {
     constexpr int BUF = decltype(buf_c)::value;
     constexpr int HI = decltype(hi_c)::value;
-    if (k + 1 < K) stage_panel<NW>(f.XoT + (size_t)(k + 1) * f.ldT_o, pan + (size_t)(1 - BUF) * kWidePanelStride, chunks1, wave, lane);
+    if (k + 1 < K) stage_panel_buf<NW>(rs1, (uint32_t)(k + 1) * (uint32_t)f.ldT_o * 4u, pan + (size_t)(1 - BUF) * kWidePanelStride, chunks1, wave, lane * 16);
     const float xk = half_bcast(x[HI], k & 31, half);
     // (A) column k-1's update, from the registers that still hold v_{k-1}
     const f32x2 dp2 = {dprev, dprev};
@@ -173,8 +175,8 @@ __device__ __forceinline__ void sweep_wide_body(const SweepArgs& a, const FastAr
     TICK(1, corr_t + asq_t);
     u32x2 cw = {0u, 0u};
     if (MODE == kSweepDraw) cw = *(lds_cu2*)(uintptr_t)(mytab_b + (uint32_t)(k * NC * 8));
-    corr_t = half_sum(corr_t);
-    asq_t = half_sum(asq_t);
+    corr_t = half_sum_upper(corr_t);     // from here on the unit's scalars are right in lanes 16-31 of its half only
+    asq_t = half_sum_upper(asq_t);
     const float ckk = Cs[k * KP + k];
     const float tau_p = tau * (ckk - asq_t);
     const float numer = fmaf(tau, fmaf(xk, ckk, corr_t), half_bcast(pl[HI], k & 31, half));
@@ -182,13 +184,16 @@ __device__ __forceinline__ void sweep_wide_body(const SweepArgs& a, const FastAr
     TICK(2, numer + tau_p);
     if (MODE == kSweepDraw) {
       const TnFast tf = tn_fast_params(numer, tau_p);
-      bool done = !tf.live || !valid;
-      // lane c (< NC) of each half evaluates candidate c of the batch; the first accepted one is the draw.  Batch 0
-      // comes from the table; a wave in which some unit rejected a whole batch (rare) computes the next NC candidates
-      // (numbers NC, NC+1, ... : the oracle's candidate sequence) and runs the same code again.
+      // lanes 16 .. 16+NC-1 of each half evaluate candidates 0 .. NC-1 of the batch; the first accepted one is the draw.
+      // Batch 0 comes from the table; a wave in which some unit rejected a whole batch (rare) computes the next NC
+      // candidates (numbers NC, NC+1, ... : the oracle's candidate sequence) and runs the same code again.
+      const bool cand_lane = (l5 & ~(NC - 1)) == 16;
+      const unsigned long long mlive = __ballot(tf.live && valid);
+      const bool live_h = ((half ? (uint32_t)(mlive >> 48) : (uint32_t)(mlive >> 16)) & 1u) != 0u;      // lane 16 of the half speaks for the unit
+      bool need = live_h;
       for (uint32_t cbase = 0;;) {
         float xc;
-        const bool acc = tn_eval_fast(tf, cw.x, cw.y, &xc) && l5 < NC;
+        const bool acc = tn_eval_fast(tf, cw.x, cw.y, &xc) && cand_lane;
         xc = tn_guard(xc);
         const unsigned long long m = __ballot(acc);
         const uint32_t m0 = (uint32_t)m, m1 = (uint32_t)(m >> 32);
@@ -196,9 +201,9 @@ __device__ __forceinline__ void sweep_wide_body(const SweepArgs& a, const FastAr
         const float x0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xc), f0));
         const float x1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xc), 32 + f1));
         const bool found = half ? (m1 != 0u) : (m0 != 0u);
-        if (!done && found) { xnew = half ? x1 : x0; done = true; }
+        if (need && found) { xnew = half ? x1 : x0; need = false; }
         cbase += NC;
-        if (!__ballot(!done) || cbase >= 4096u) break;
+        if (!__ballot(need) || cbase >= 4096u) break;
         uint32_t row = gi;
         asm volatile("" : "+v"(row));                            // opaque: nothing of this Philox call is hoisted out of the column loop
         const U4 r = philox4x32_10(row, (uint32_t)k, a.it, a.stream + 16u * (cbase + (uint32_t)(l5 & (NC - 1))), a.key0, a.key1);
@@ -206,7 +211,8 @@ __device__ __forceinline__ void sweep_wide_body(const SweepArgs& a, const FastAr
       }
     } else {
       const float mu = numer / tau_p;
-      xnew = (valid && tau_p > 0.f && mu > 0.f) ? mu : 0.f;
+      const float xm = (valid && tau_p > 0.f && mu > 0.f) ? mu : 0.f;
+      xnew = half_bcast(xm, 16, half);
     }
     dprev = xnew - xk;
     TICK(3, dprev);

@@ -24,6 +24,12 @@ __device__ __forceinline__ float half_sum(float v) {          // all-reduce insi
   return v + __shfl_xor(v, 16, 64);
 #endif
 }
+// Sum over each 32-lane half, valid in the UPPER 16 lanes of the half only (lanes 16-31 and 48-63): four DPP steps
+// inside the rows, then row_bcast:15 adds row 0's total into row 1 (and row 2's into row 3).  No LDS round trip.
+__device__ __forceinline__ float half_sum_upper(float v) {
+  v = dpp_xor_row_sum(v);
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));   // row_bcast:15, rows 1 and 3
+}
 __device__ __forceinline__ double half_sum_d(double v) {
 #pragma unroll
   for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
@@ -80,6 +86,19 @@ __device__ __forceinline__ void stage_panel(const float* src, float* dst, int ch
   for (int c = wave; c < chunks; c += NW) {
     __builtin_amdgcn_global_load_lds(src + (size_t)c * 256 + lane * 4, (lds_ptr)(dst + (size_t)c * 256), 16, 0, 0);
   }
+}
+
+// The same staging through a buffer descriptor: panel base and chunk offset travel in SGPRs (descriptor + soffset), the
+// only VGPR is the lane's byte offset, so one piece costs s_mov m0 + buffer_load ... lds instead of 64-bit VGPR address
+// arithmetic per piece.  `lane16` = 16 * lane.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t panel_rsrc(const float* base, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+}
+template <int NW>
+__device__ __forceinline__ void stage_panel_buf(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, float* dst, int chunks, int wave, int lane16) {
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  for (int c = wave; c < chunks; c += NW)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(dst + (size_t)c * 256), 16, lane16, (int)(byte_off + (uint32_t)c * 1024u), 0, 0);
 }
 
 #ifdef BNMTF_PHASE_TIMING
