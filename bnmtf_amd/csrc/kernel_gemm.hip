@@ -181,11 +181,10 @@ __device__ __forceinline__ void split3(const float (&v)[8], u32x4& hi, u32x4& mi
   }
 }
 
-template <int MT>
+template <int MT, int NSET>
 __global__ __launch_bounds__(256, 1) void gemm_bf16x3_kernel(GemmArgs a) {
   constexpr int KP = MT * 32;
   constexpr int NACC = MT * 4 * 16;            // accumulator floats per lane
-  constexpr int NSET = 3;                      // register sets of raw operands: two 16-row steps in flight behind the one being multiplied
   __shared__ float red[2][NACC * 64];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -211,7 +210,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16x3_kernel(GemmArgs a) {
   auto load_step = [&](f32x4 (&b)[8], float (&av)[MT][8]) {
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
-      b[rr] = *reinterpret_cast<const f32x4*>(bp + (size_t)rr * a.ld);
+      b[rr] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(bp + (size_t)rr * a.ld));   // streamed once: keep it out of the way of X and the slabs in L2
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) av[mt][rr] = xp[rr * KP + mt * 32];
     }
@@ -244,18 +243,17 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16x3_kernel(GemmArgs a) {
     }
   };
   const int nsteps = ipw / 16;                    // ipw is a multiple of 32 (host pads)
-  load_step(braw[0], araw[0]);
-  if (nsteps > 1) load_step(braw[1], araw[1]);
-  for (int g = 0; g < nsteps; g += 3) {
-    if (g + 2 < nsteps) load_step(braw[2], araw[2]);
-    mul_step(braw[0], araw[0]);
-    if (g + 1 < nsteps) {
-      if (g + 3 < nsteps) load_step(braw[0], araw[0]);
-      mul_step(braw[1], araw[1]);
-    }
-    if (g + 2 < nsteps) {
-      if (g + 4 < nsteps) load_step(braw[1], araw[1]);
-      mul_step(braw[2], araw[2]);
+  // ring of NSET raw-operand register sets: NSET-1 steps (8 KiB of R~ each) in flight behind the one being multiplied
+#pragma unroll
+  for (int j = 0; j < NSET - 1; ++j)
+    if (j < nsteps) load_step(braw[j], araw[j]);
+  for (int g = 0; g < nsteps; g += NSET) {
+#pragma unroll
+    for (int j = 0; j < NSET; ++j) {
+      if (g + j < nsteps) {
+        if (g + j + NSET - 1 < nsteps) load_step(braw[(j + NSET - 1) % NSET], araw[(j + NSET - 1) % NSET]);
+        mul_step(braw[j], araw[j]);
+      }
     }
   }
 
@@ -302,8 +300,9 @@ void launch_gemm(const GemmArgs& a, int KP, hipStream_t st) {
   static const char* mode = getenv("BNMTF_GEMM");                 // "f32": the f32-MFMA kernel (kept for comparison)
   static const bool f32 = mode && !strcmp(mode, "f32");
   if (!f32) {
-    if (KP == 32) hipLaunchKernelGGL((gemm_bf16x3_kernel<1>), grid, block, 0, st, a);
-    else          hipLaunchKernelGGL((gemm_bf16x3_kernel<2>), grid, block, 0, st, a);
+    // three raw-operand register sets (two 8 KiB steps in flight per wave); deeper rings measured no faster
+    if (KP == 32) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 3>), grid, block, 0, st, a);
+    else          hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3>), grid, block, 0, st, a);
     return;
   }
   if (KP == 32) hipLaunchKernelGGL((gemm_kernel<1, 16, 2>), grid, block, 0, st, a);
