@@ -23,7 +23,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (the f32 kernel, BNMTF_GEMM=f32)
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (the contraction takes 6 bf16 products per fp32 product)
 PEAK_HBM_GBS = 8000.0
 
 WORKLOADS = {
@@ -168,7 +169,8 @@ def main():
         _lib.check(L.bnmf_gibbs_run(h, n, _lib.UPDATE_DRAW, None, None, None, _lib.ptr(perf), None))
 
     run(a.warmup)
-    model.set_profiling(True)
+    # timed region: HIP events bracket the roofline kernel only (two records per iteration on its own stream)
+    model.set_profiling(True, kernel=_lib.KERNEL_GEMM_COLS)
     perf = np.zeros((a.steps, 3))
     sync()
     t0 = time.perf_counter()
@@ -183,7 +185,15 @@ def main():
 
     stats = {}
     names = {0: "gemm_rows(R~.V)", 1: "gemm_cols(R~^T.U)", 2: "sweep_rows", 3: "sweep_cols"}
+    ms, n = model.kernel_stats(_lib.KERNEL_GEMM_COLS)
+    stats[names[1]] = {"avg_us": 1e3 * ms / max(n, 1), "launches": n}
+    # the other kernels of the iteration: a short untimed run with every timer on
+    model.set_profiling(True)
+    run(min(a.steps, 10))
+    sync()
     for kid, nm in names.items():
+        if kid == _lib.KERNEL_GEMM_COLS:
+            continue
         ms, n = model.kernel_stats(kid)
         stats[nm] = {"avg_us": 1e3 * ms / max(n, 1), "launches": n}
     model.set_profiling(False)
@@ -198,14 +208,16 @@ def main():
 
     if rank == 0:
         ms_step = 1e3 * dt / a.steps
-        # roofline of the dominant dense kernel, "the U^T.R step": algorithmic 2*I*J*K flop per launch
-        # (per rank: its column shard), SURVEY.md 8(d)
+        # roofline of the dense kernel of the path, "the U^T.R step" (SURVEY.md 8(d)): algorithmic 4*I*J bytes (R~ read
+        # once) and 2*I*J*K flop per launch (per rank: its column shard).  Since the contraction moved to the bf16 matrix
+        # cores (three-term operand splits, 6 MFMA products per fp32 product) it is a stream of R~ from HBM.
         g = stats["gemm_cols(R~^T.U)"]
         flops = 2.0 * I * (J / world) * K
         achieved = flops / (g["avg_us"] * 1e-6) / 1e12 if g["avg_us"] > 0 else 0.0
         bytes_alg = 4.0 * I * (J / world)
         # whole-iteration bound: max(t_MFMA, t_HBM) of the two contractions, SURVEY.md 8(d)
-        t_mfma = 4.0 * I * J * K / (PEAK_F32_MFMA_TFLOPS * 1e12) / world
+        f32_gemm = os.environ.get("BNMTF_GEMM") == "f32"
+        t_mfma = (4.0 * I * J * K / (PEAK_F32_MFMA_TFLOPS * 1e12) if f32_gemm else 6 * 4.0 * I * J * K / (PEAK_BF16_MFMA_TFLOPS * 1e12)) / world
         t_hbm = (2.0 * I * J * 4.125 + 8.0 * (I + J) * K) / (PEAK_HBM_GBS * 1e9) / world
         traffic = None
         try:     # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (profiles/traffic.json)
@@ -222,14 +234,14 @@ def main():
             "config": {"workload": "BNMF Gibbs, synthetic R %dx%d K=%d, 10%% missing mask, priors alpha=beta=1 lambda=0.1, init random" % (I, J, K),
                        "parallelism": "rows/cols split x%d, RCCL all-gather of factor blocks" % world if world > 1 else "single GPU",
                        "samples": "device-resident"},
-            "roofline": {"bound": "mfma" if K >= 64 else "hbm", "kernel": "gemm_cols: Pv = R~^T.U (f32 MFMA 32x32x2)",
-                         "achieved": achieved if K >= 64 else bytes_alg / (g["avg_us"] * 1e-6) / 1e9,
-                         "peak": PEAK_F32_MFMA_TFLOPS if K >= 64 else PEAK_HBM_GBS,
-                         "unit": "TFLOP/s" if K >= 64 else "GB/s",
-                         "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if K >= 64 else bytes_alg / (g["avg_us"] * 1e-6) / 1e9 / PEAK_HBM_GBS,
-                         "traffic": traffic,
-                         "algorithmic_per_launch": {"flop": flops, "bytes": bytes_alg},
-                         "avg_launch_us": g["avg_us"]},
+            "roofline": ({"bound": "mfma", "kernel": "gemm_cols: Pv = R~^T.U (f32 MFMA 32x32x2)", "achieved": achieved,
+                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                          "algorithmic_per_launch": {"flop": flops, "bytes": bytes_alg}, "avg_launch_us": g["avg_us"]}
+                         if f32_gemm else
+                         {"bound": "hbm", "kernel": "gemm_cols: Pv = R~^T.U (bf16x3 MFMA 32x32x16, fp32-exact products)",
+                          "achieved": bytes_alg / (g["avg_us"] * 1e-6) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                          "frac": bytes_alg / (g["avg_us"] * 1e-6) / 1e9 / PEAK_HBM_GBS, "traffic": traffic,
+                          "algorithmic_per_launch": {"flop": flops, "bytes": bytes_alg}, "avg_launch_us": g["avg_us"]}),
             "iteration_bound": {"t_mfma_us": 1e6 * t_mfma, "t_hbm_us": 1e6 * t_hbm,
                                 "frac_of_bound": max(t_mfma, t_hbm) / (dt / a.steps)},
             "kernels": stats,

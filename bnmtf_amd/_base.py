@@ -125,8 +125,10 @@ class DeviceModel(object):
         _lib.check(_lib.lib().bnmtf_describe(self._handle(), buf, 1024))
         return buf.value.decode()
 
-    def set_profiling(self, enable=True):
-        _lib.check(_lib.lib().bnmtf_set_profiling(self._handle(), int(bool(enable))))
+    def set_profiling(self, enable=True, kernel=None):
+        """Bracket kernel launches with HIP events (all listed kernels, or only `kernel`)."""
+        code = 0 if not enable else (1 if kernel is None else 2 + int(kernel))
+        _lib.check(_lib.lib().bnmtf_set_profiling(self._handle(), code))
 
     def set_sweep_path(self, fast=True):
         """fast=False forces the generic sweep kernel (test hook; results are the same)."""

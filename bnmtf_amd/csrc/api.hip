@@ -280,8 +280,9 @@ static void free_dir(Dir& d) {
 // ---------------------------------------------------------------- profiling
 struct ScopedKernelTimer {
   bnmtf_model* h; int id; hipEvent_t a = nullptr, b = nullptr;
-  ScopedKernelTimer(bnmtf_model* h_, int id_) : h(h_), id(id_) {
-    if (!h->profiling) return;
+  bool on;
+  ScopedKernelTimer(bnmtf_model* h_, int id_) : h(h_), id(id_), on((h_->profiling >> id_) & 1u) {
+    if (!on) return;
     auto get = [&]() {
       hipEvent_t e;
       if (!h->event_pool.empty()) { e = h->event_pool.back(); h->event_pool.pop_back(); }
@@ -292,7 +293,7 @@ struct ScopedKernelTimer {
     (void)hipEventRecord(a, h->stream);
   }
   ~ScopedKernelTimer() {
-    if (!h->profiling) return;
+    if (!on) return;
     (void)hipEventRecord(b, h->stream);
     h->pending_events.push_back({id, {a, b}});
   }
@@ -547,7 +548,8 @@ int bnmtf_set_iteration(bnmtf_handle h, uint64_t it) { h->iteration = it; return
 int bnmtf_get_iteration(bnmtf_handle h, uint64_t* it) { *it = h->iteration; return BNMTF_OK; }
 
 int bnmtf_set_profiling(bnmtf_handle h, int enable) {
-  h->profiling = enable != 0;
+  // 0: off; 1: every kernel; 2 + k: kernel k only (so that a timed region carries two event records, not eight)
+  h->profiling = enable == 0 ? 0u : (enable == 1 ? 0xFFFFFFFFu : 1u << (unsigned)((enable - 2) & 31));
   for (int i = 0; i < BNMTF_KERNEL_COUNT; ++i) { h->kernel_ms[i] = 0; h->kernel_launches[i] = 0; }
   return BNMTF_OK;
 }

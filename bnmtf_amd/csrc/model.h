@@ -100,7 +100,7 @@ struct bnmtf_model {
   double *s_numer = nullptr, *s_taup = nullptr;
   int s_blocks = 0;
   // profiling
-  bool profiling = false;
+  uint32_t profiling = 0;                // bit k: bracket the launches of kernel k with events
   double kernel_ms[BNMTF_KERNEL_COUNT] = {0};
   uint64_t kernel_launches[BNMTF_KERNEL_COUNT] = {0};
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending_events;

@@ -169,8 +169,9 @@ int bnmtf_gamma_sample(double alpha, double beta, uint64_t seed, uint64_t it, in
 #define BNMTF_KERNEL_SWEEP_COLS 3
 #define BNMTF_KERNEL_SWEEP_S 4      /* BNMTF: the K*L sequential S entries */
 #define BNMTF_KERNEL_COUNT 8
-/* when enabled, run() brackets each launch of the listed kernels with hipEvents
- * on the handle's stream; totals are read back with bnmtf_kernel_stats. */
+/* enable = 1: run() brackets each launch of the listed kernels with hipEvents on the handle's
+ * stream; enable = 2 + k: only kernel k (BNMTF_KERNEL_*); 0: off.  Totals are read back with
+ * bnmtf_kernel_stats. */
 int bnmtf_set_profiling(bnmtf_handle h, int enable);
 /* sweep kernel selection: 1 (default) = register/LDS-resident fast path when the shape
  * fits, 0 = always the generic kernel (any mask, q in global memory).  Same results. */
