@@ -11,6 +11,7 @@
 
 #include "model.h"
 #include "comm.h"
+#include "device_rng.h"
 
 namespace bnmtf {
 
@@ -401,9 +402,20 @@ static int bnmtf_alloc_extras(bnmtf_model* h, const double* lambdaS);
 
 static int ensure_rec(bnmtf_model* h, size_t n) {
   if (h->rec_cap >= n) return BNMTF_OK;
-  dfree(h->rec);
+  dfree(h->rec); dfree(h->gunit);
   CHK(dalloc(&h->rec, n * 5));
+  CHK(dalloc(&h->gunit, n));
   h->rec_cap = n;
+  return BNMTF_OK;
+}
+// Gamma(alpha_s, 1) variates of the next n iterations (tau = variate / beta_s): they depend on the seed and the iteration
+// number only, so the fp64 Marsaglia-Tsang loop runs on the host, off the device's critical path.
+static int stage_gamma_variates(bnmtf_model* h, int n) {
+  h->gunit_host.resize((size_t)n);
+  const double shape = h->alpha + 0.5 * h->n_obs;
+  for (int it = 0; it < n; ++it)
+    h->gunit_host[it] = gamma_unit_draw(shape, (uint32_t)(h->iteration + it), kStreamTau, (uint32_t)h->seed, (uint32_t)(h->seed >> 32));
+  HIPCHK(hipMemcpyAsync(h->gunit, h->gunit_host.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
   return BNMTF_OK;
 }
 
@@ -523,7 +535,7 @@ int bnmtf_destroy(bnmtf_handle h) {
   dfree(h->slabsS); dfree(h->CfS); dfree(h->deltaS); dfree(h->s_partial); dfree(h->s_reduced); dfree(h->lambdaS); dfree(h->s_numer); dfree(h->s_taup);
   dfree(h->Rfull); dfree(h->Mtrain); dfree(h->Mscratch); dfree(h->Ad); dfree(h->Bd); dfree(h->out6);
   dfree(h->A2d); dfree(h->B2d); dfree(h->vb_rec);
-  dfree(h->tau_d); dfree(h->tau_f); dfree(h->acc); dfree(h->rec); dfree(h->S);
+  dfree(h->tau_d); dfree(h->tau_f); dfree(h->acc); dfree(h->rec); dfree(h->gunit); dfree(h->S);
   for (auto& pe : h->pending_events) { (void)hipEventDestroy(pe.second.first); (void)hipEventDestroy(pe.second.second); }
   for (auto e : h->event_pool) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -617,6 +629,10 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
   CHK(ensure_rec(h, (size_t)n_iter));
   const int mode = update == BNMTF_UPDATE_MODE ? kSweepMode : kSweepDraw;
   Dir& r = h->rows; Dir& c = h->cols;
+  if (mode == kSweepDraw) CHK(stage_gamma_variates(h, n_iter));
+  // the [3] accumulator is only written by the generic sweep kernel (and summed across ranks): zero once, reset when used
+  const bool acc_used = h->comm != nullptr || !h->use_fast || !c.fast_ok || c.f_gen_count > 0 || !sweep_fast_supported(c.KP, c.pw);
+  HIPCHK(hipMemsetAsync(h->acc, 0, 4 * sizeof(double), h->stream));
   std::vector<hipEvent_t> ev(times_out ? n_iter + 1 : 0);
   for (auto& e : ev) HIPCHK(hipEventCreate(&e));
   if (times_out) HIPCHK(hipEventRecord(ev[0], h->stream));
@@ -633,7 +649,7 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
     enqueue_post(h, r);
     // ---- V columns: Pv = R~^T . U
     enqueue_gemm(h, c, r, BNMTF_KERNEL_GEMM_COLS);
-    HIPCHK(hipMemsetAsync(h->acc, 0, 4 * sizeof(double), h->stream));
+    if (acc_used && it > 0) HIPCHK(hipMemsetAsync(h->acc, 0, 4 * sizeof(double), h->stream));
     {
       ScopedKernelTimer t(h, BNMTF_KERNEL_SWEEP_COLS);
       SweepArgs s = sweep_args(h, c, r, mode, kStreamCols);
@@ -654,6 +670,7 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
     f.n_obs = h->n_obs; f.sumR = h->sumR; f.sumR2 = h->sumR2;
     f.alpha = h->alpha; f.beta = h->beta; f.update = update;
     f.key0 = (uint32_t)h->seed; f.key1 = (uint32_t)(h->seed >> 32); f.it = (uint32_t)h->iteration;
+    f.gunit = mode == kSweepDraw ? h->gunit + it : nullptr;
     f.tau_d = h->tau_d; f.tau_f = h->tau_f; f.rec = h->rec + (size_t)it * 5;
     launch_finish(f, h->stream);
     // ---- sample hand-off (all_U[it], all_V[it])

@@ -12,12 +12,13 @@ constexpr float kTwoPi = 6.283185307179586f;
 
 struct U4 { uint32_t x, y, z, w; };
 
-__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+__host__ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
+__host__ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                              uint32_t k0, uint32_t k1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
     c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
@@ -26,7 +27,7 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
 
 // uint32 -> (0,1), 24 significant bits: identical value in fp32 and fp64
 __device__ __forceinline__ float u24(uint32_t r) { return ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f); }
-__device__ __forceinline__ double u32d(uint32_t r) { return ((double)r + 0.5) * (1.0 / 4294967296.0); }
+__host__ __device__ __forceinline__ double u32d(uint32_t r) { return ((double)r + 0.5) * (1.0 / 4294967296.0); }
 
 // Per-draw constants of TN(mu, tau_p) on [0,inf): a = -mu*sqrt(tau_p).
 struct TnParams {
@@ -96,9 +97,9 @@ __device__ __forceinline__ float tn_draw_serial(float mu, float tau_p, uint32_t 
   return 0.0f;
 }
 
-// Gamma(shape, rate) by Marsaglia-Tsang in fp64 (one thread).
-__device__ inline double gamma_draw_serial(double shape, double rate, uint32_t it, uint32_t stream,
-                                           uint32_t k0, uint32_t k1) {
+// Gamma(shape, 1) by Marsaglia-Tsang in fp64 (one thread).  The variate depends on (shape, seed, iteration) only --
+// not on the rate -- so run() computes it on the host ahead of the iteration and the device divides by the rate.
+__host__ __device__ inline double gamma_unit_draw(double shape, uint32_t it, uint32_t stream, uint32_t k0, uint32_t k1) {
   const bool boost = shape < 1.0;
   const double a = boost ? shape + 1.0 : shape;
   const double d = a - 1.0 / 3.0;
@@ -113,10 +114,14 @@ __device__ inline double gamma_draw_serial(double shape, double rate, uint32_t i
     if (log(u3) < 0.5 * x * x + d - d * v + d * log(v)) {
       double g = d * v;
       if (boost) g *= pow(u4, 1.0 / shape);
-      return g / rate;
+      return g;
     }
   }
-  return shape / rate;
+  return shape;
+}
+__host__ __device__ inline double gamma_draw_serial(double shape, double rate, uint32_t it, uint32_t stream,
+                                                    uint32_t k0, uint32_t k1) {
+  return gamma_unit_draw(shape, it, stream, k0, k1) / rate;
 }
 
 // TN moments in fp64, as truncated_normal_vector.py:53-73 (incl. the exponential

@@ -55,43 +55,40 @@ void launch_gram(const GramArgs& a, hipStream_t st) {
 //   sum_Omega R Rp = sum (Pv o V)   (Pv = R~^T U only holds observed entries)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
-  __shared__ double red[256];
-  const int KP = a.KP;
-  double s = 0.0;
-  for (int t = threadIdx.x; t < KP * KP; t += 256) s = fma(a.Cr64[t], a.Cc64[t], s);
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int w = 128; w >= 1; w >>= 1) {
-    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-    __syncthreads();
-  }
-  const double dot = red[0];
-  __syncthreads();
-  // per-block sweep statistics: 3 columns, strided over the threads, tree-summed
-  double st3[3] = {0.0, 0.0, 0.0};
+  __shared__ double red[4][4];
+  const int KP = a.KP, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // four sums at once: <Cr, Cc>, and the three columns of the per-block sweep statistics
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int t = threadIdx.x; t < KP * KP; t += 256) v[0] = fma(a.Cr64[t], a.Cc64[t], v[0]);
   for (int b = threadIdx.x; b < a.nstats; b += 256)
-    for (int t = 0; t < 3; ++t) st3[t] += a.stats[(size_t)b * 4 + t];
-  for (int t = 0; t < 3; ++t) {
-    red[threadIdx.x] = st3[t];
-    __syncthreads();
-    for (int w = 128; w >= 1; w >>= 1) {
-      if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-      __syncthreads();
-    }
-    st3[t] = red[0];
-    __syncthreads();
+    for (int t = 0; t < 3; ++t) v[1 + t] += a.stats[(size_t)b * 4 + t];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v[t] += __shfl_xor(v[t], m, 64);
+    if (lane == 0) red[wave][t] = v[t];
   }
+  // column-sum product (KP terms) on wave 0 meanwhile
+  double sp1 = 0.0;
+  if (wave == 0) {
+    sp1 = lane < KP ? a.sr[lane] * a.sc[lane] : 0.0;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) sp1 += __shfl_xor(sp1, m, 64);
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    double sp1 = 0.0;
-    for (int t = 0; t < KP; ++t) sp1 = fma(a.sr[t], a.sc[t], sp1);
-    double acc[3] = {a.acc[0] + st3[0], a.acc[1] + st3[1], a.acc[2] + st3[2]};
+    double tot[4];
+    for (int t = 0; t < 4; ++t) tot[t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    const double dot = tot[0];
+    double acc[3] = {a.acc[0] + tot[1], a.acc[1] + tot[2], a.acc[2] + tot[3]};
     const double srp = acc[0], sp = sp1 - acc[1], spp = dot - acc[2];
     const double n = a.n_obs;
     const double sse = a.sumR2 - 2.0 * srp + spp;
     const double alpha_s = a.alpha + 0.5 * n, beta_s = a.beta + 0.5 * sse;
     double tau;
-    if (a.update == 0) tau = gamma_draw_serial(alpha_s, beta_s, a.it, kStreamTau, a.key0, a.key1);
-    else tau = alpha_s / beta_s;
+    if (a.update != 0) tau = alpha_s / beta_s;
+    else if (a.gunit) tau = *a.gunit / beta_s;
+    else tau = gamma_draw_serial(alpha_s, beta_s, a.it, kStreamTau, a.key0, a.key1);
     *a.tau_d = tau;
     *a.tau_f = (float)tau;
     const double ss_tot = a.sumR2 - a.sumR * a.sumR / n;

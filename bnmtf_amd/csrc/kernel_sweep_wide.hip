@@ -217,7 +217,11 @@ __device__ __forceinline__ void sweep_wide_body(const SweepArgs& a, const FastAr
     dprev = xnew - xk;
     TICK(3, dprev);
     if (l5 + 32 * HI == k) x[HI] = xnew;
+#ifdef BNMTF_EXPERIMENT_NO_BARRIER
+    __builtin_amdgcn_s_waitcnt(0);    // experiment only (wrong results): how fast would the column loop run without the per-column barrier?
+#else
     __syncthreads();
+#endif
     TICK(4, dprev);
   };
   using c0 = std::integral_constant<int, 0>;

@@ -121,6 +121,7 @@ struct FinishArgs {
   double alpha, beta;
   int update;                 // 0 draw, 1 mode (tau = alpha_s/beta_s)
   uint32_t key0, key1, it;
+  const double* gunit;        // Gamma(alpha_s, 1) variate of this iteration computed ahead on the host, or null (draw here)
   double* tau_d; float* tau_f;
   double* rec;                // [5]: tau, MSE, R2, Rp, SSE  (slot of this iteration)
 };

@@ -100,6 +100,8 @@ struct bnmtf_model {
   double *s_numer = nullptr, *s_taup = nullptr;
   int s_blocks = 0;
   // profiling
+  double* gunit = nullptr;               // [rec_cap] Gamma(alpha_s, 1) variates staged by run()
+  std::vector<double> gunit_host;
   uint32_t profiling = 0;                // bit k: bracket the launches of kernel k with events
   double kernel_ms[BNMTF_KERNEL_COUNT] = {0};
   uint64_t kernel_launches[BNMTF_KERNEL_COUNT] = {0};
