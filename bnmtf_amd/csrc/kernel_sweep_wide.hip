@@ -47,6 +47,7 @@ __device__ __forceinline__ void sweep_wide_body(const SweepArgs& a, const FastAr
   const int E = wave_on ? (int)f.pair_E[pair] : 0;
   const int u = wave_on ? f.unit_map[2 * pair + half] : -1;
   const bool valid = u >= 0;
+  const bool valid0 = wave_on && f.unit_map[2 * pair] >= 0, valid1 = wave_on && f.unit_map[2 * pair + 1] >= 0;   // per half, scalar
   const uint32_t gi = (uint32_t)a.n0 + (uint32_t)(valid ? u : 0);
   const int K = a.K;
   const float tau = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *a.tau)));
@@ -187,28 +188,30 @@ __device__ __forceinline__ void sweep_wide_body(const SweepArgs& a, const FastAr
       // lanes 16 .. 16+NC-1 of each half evaluate candidates 0 .. NC-1 of the batch; the first accepted one is the draw.
       // Batch 0 comes from the table; a wave in which some unit rejected a whole batch (rare) computes the next NC
       // candidates (numbers NC, NC+1, ... : the oracle's candidate sequence) and runs the same code again.
-      const bool cand_lane = (l5 & ~(NC - 1)) == 16;
-      const unsigned long long mlive = __ballot(tf.live && valid);
-      const bool live_h = ((half ? (uint32_t)(mlive >> 48) : (uint32_t)(mlive >> 16)) & 1u) != 0u;      // lane 16 of the half speaks for the unit
-      bool need = live_h;
+      // Everything that is one value per unit is kept per HALF in scalar registers (ballots, s_ff1, v_readlane), not as
+      // per-lane booleans: the selection costs scalar instructions instead of vector issue slots.
+      constexpr unsigned long long kCandMask = (unsigned long long)((1u << NC) - 1u) << 16 | (unsigned long long)((1u << NC) - 1u) << 48;
+      const unsigned long long mlive = __ballot(tf.live);                 // lanes 16 / 48 speak for the two units
+      bool need0 = valid0 && ((mlive >> 16) & 1ull), need1 = valid1 && ((mlive >> 48) & 1ull);
+      float xs0 = 0.f, xs1 = 0.f;
       for (uint32_t cbase = 0;;) {
         float xc;
-        const bool acc = tn_eval_fast(tf, cw.x, cw.y, &xc) && cand_lane;
+        const bool acc = tn_eval_fast(tf, cw.x, cw.y, &xc);
         xc = tn_guard(xc);
-        const unsigned long long m = __ballot(acc);
+        const unsigned long long m = __ballot(acc) & kCandMask;
         const uint32_t m0 = (uint32_t)m, m1 = (uint32_t)(m >> 32);
-        const int f0 = m0 ? __ffs((int)m0) - 1 : 0, f1 = m1 ? __ffs((int)m1) - 1 : 0;
-        const float x0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xc), f0));
-        const float x1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xc), 32 + f1));
-        const bool found = half ? (m1 != 0u) : (m0 != 0u);
-        if (need && found) { xnew = half ? x1 : x0; need = false; }
+        const float c0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xc), m0 ? __ffs((int)m0) - 1 : 0));
+        const float c1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xc), 32 + (m1 ? __ffs((int)m1) - 1 : 0)));
+        if (need0 && m0) { xs0 = c0; need0 = false; }
+        if (need1 && m1) { xs1 = c1; need1 = false; }
         cbase += NC;
-        if (!__ballot(need) || cbase >= 4096u) break;
+        if (!(need0 || need1) || cbase >= 4096u) break;
         uint32_t row = gi;
         asm volatile("" : "+v"(row));                            // opaque: nothing of this Philox call is hoisted out of the column loop
         const U4 r = philox4x32_10(row, (uint32_t)k, a.it, a.stream + 16u * (cbase + (uint32_t)(l5 & (NC - 1))), a.key0, a.key1);
         cw = u32x2{r.x, r.y};
       }
+      xnew = half ? xs1 : xs0;
     } else {
       const float mu = numer / tau_p;
       const float xm = (valid && tau_p > 0.f && mu > 0.f) ? mu : 0.f;
