@@ -181,48 +181,49 @@ __device__ __forceinline__ void split3(const float (&v)[8], u32x4& hi, u32x4& mi
   }
 }
 
-template <int MT, int NSET>
-__global__ __launch_bounds__(256, 1) void gemm_bf16x3_kernel(GemmArgs a) {
+template <int MT, int NSET, int TW>
+__global__ __launch_bounds__(256, (TW == 4 ? 1 : 2)) void gemm_bf16x3_kernel(GemmArgs a) {
+  typedef float f32xT __attribute__((ext_vector_type(TW)));   // TW column tiles per wave: one TW-dword load per lane per row
   constexpr int KP = MT * 32;
-  constexpr int NACC = MT * 4 * 16;            // accumulator floats per lane
+  constexpr int NACC = MT * TW * 16;            // accumulator floats per lane
   __shared__ float red[2][NACC * 64];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, c = lane & 31;
-  const int col0 = blockIdx.x * 128;
+  const int col0 = blockIdx.x * (32 * TW);
   const int s = blockIdx.y;
   const int ipw = a.inner_per_wave;
   const size_t r0 = (size_t)(s * 4 + wave) * ipw + 8 * h;
 
-  const float* bp = a.big + r0 * (size_t)a.ld + col0 + 4 * c;
+  const float* bp = a.big + r0 * (size_t)a.ld + col0 + TW * c;
   const float* xp = a.X + r0 * KP + c;
 
-  f32x16 acc[MT][4];
+  f32x16 acc[MT][TW];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < TW; ++t)
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[mt][t][g] = 0.0f;
 
-  f32x4 braw[NSET][8];
+  f32xT braw[NSET][8];
   float araw[NSET][MT][8];
-  auto load_step = [&](f32x4 (&b)[8], float (&av)[MT][8]) {
+  auto load_step = [&](f32xT (&b)[8], float (&av)[MT][8]) {
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
-      b[rr] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(bp + (size_t)rr * a.ld));   // streamed once: keep it out of the way of X and the slabs in L2
+      b[rr] = __builtin_nontemporal_load(reinterpret_cast<const f32xT*>(bp + (size_t)rr * a.ld));   // streamed once: keep it out of the way of X and the slabs in L2
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) av[mt][rr] = xp[rr * KP + mt * 32];
     }
     bp += 16 * (size_t)a.ld;
     xp += 16 * KP;
   };
-  auto mul_step = [&](const f32x4 (&b)[8], const float (&av)[MT][8]) {
+  auto mul_step = [&](const f32xT (&b)[8], const float (&av)[MT][8]) {
     u32x4 ah[MT], am[MT], al[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) split3(av[mt], ah[mt], am[mt], al[mt]);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < TW; ++t) {
       float bv[8];
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) bv[rr] = b[rr][t];
@@ -262,17 +263,17 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16x3_kernel(GemmArgs a) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < TW; ++t)
 #pragma unroll
-        for (int g = 0; g < 16; ++g) dst[((mt * 4 + t) * 16 + g) * 64 + lane] = acc[mt][t][g];
+        for (int g = 0; g < 16; ++g) dst[((mt * TW + t) * 16 + g) * 64 + lane] = acc[mt][t][g];
   };
   auto add = [&](const float* src) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < TW; ++t)
 #pragma unroll
-        for (int g = 0; g < 16; ++g) acc[mt][t][g] += src[((mt * 4 + t) * 16 + g) * 64 + lane];
+        for (int g = 0; g < 16; ++g) acc[mt][t][g] += src[((mt * TW + t) * 16 + g) * 64 + lane];
   };
   if (wave >= 2) put(red[wave - 2]);
   __syncthreads();
@@ -286,11 +287,11 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16x3_kernel(GemmArgs a) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < TW; ++t)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           f32x4 v = {acc[mt][t][4 * g4], acc[mt][t][4 * g4 + 1], acc[mt][t][4 * g4 + 2], acc[mt][t][4 * g4 + 3]};
-          *reinterpret_cast<f32x4*>(out + (size_t)(4 * c + t) * KP + mt * 32 + 8 * g4 + 4 * h) = v;
+          *reinterpret_cast<f32x4*>(out + (size_t)(TW * c + t) * KP + mt * 32 + 8 * g4 + 4 * h) = v;
         }
   }
 }
@@ -301,8 +302,10 @@ void launch_gemm(const GemmArgs& a, int KP, hipStream_t st) {
   static const bool f32 = mode && !strcmp(mode, "f32");
   if (!f32) {
     // three raw-operand register sets (two 8 KiB steps in flight per wave); deeper rings measured no faster
-    if (KP == 32) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 3>), grid, block, 0, st, a);
-    else          hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3>), grid, block, 0, st, a);
+    // TW = 4 column tiles (128 columns) per wave, one wave per SIMD.  TW = 2 with two waves per SIMD (grid n_pad/64) was
+    // measured slower: 68-70 us against 60-62 us (the factor operand is split twice as often per MFMA).
+    if (KP == 32) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 3, 4>), grid, block, 0, st, a);
+    else          hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, 4>), grid, block, 0, st, a);
     return;
   }
   if (KP == 32) hipLaunchKernelGGL((gemm_kernel<1, 16, 2>), grid, block, 0, st, a);
