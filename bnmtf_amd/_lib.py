@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libbnmtf_hip.so")
 
 KERNEL_GEMM_ROWS, KERNEL_GEMM_COLS, KERNEL_SWEEP_ROWS, KERNEL_SWEEP_COLS = 0, 1, 2, 3
-UPDATE_DRAW, UPDATE_MODE = 0, 1
+UPDATE_DRAW, UPDATE_MODE, UPDATE_ICM = 0, 1, 2
 
 
 class BnmtfError(RuntimeError):
@@ -57,6 +57,7 @@ _SIGS = {
     "bnmtf_tn_moments": ([_P, _P, C.c_size_t, C.c_int, _P, _P], C.c_int),
     "bnmtf_gamma_sample": ([C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_double)], C.c_int),
     "bnmtf_set_profiling": ([_P, C.c_int], C.c_int),
+    "bnmtf_set_minimum_tn": ([_P, C.c_double], C.c_int),
     "bnmtf_set_sweep_path": ([_P, C.c_int], C.c_int),
     "bnmtf_kernel_stats": ([_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)], C.c_int),
     "bnmtf_describe": ([_P, C.c_char_p, C.c_size_t], C.c_int),

@@ -359,6 +359,7 @@ static void enqueue_sweep(bnmtf_model* h, Dir& d, const Dir& other, SweepArgs& s
 static SweepArgs sweep_args(bnmtf_model* h, Dir& d, const Dir& other, int mode, uint32_t stream_id) {
   SweepArgs s;
   memset(&s, 0, sizeof(s));
+  s.min_x = mode == kSweepMode ? h->cur_min_x : 0.f;
   s.n = d.n; s.n0 = d.n0; s.K = d.W; s.KP = d.KP; s.mode = mode; s.cond_k = -1; s.qinit_only = 0; s.only_k = -1; s.vb_moments = 1; s.vb_stats = nullptr;
   s.slabs = d.slabs; s.split = d.split; s.n_pad = d.n_pad; s.lambda = d.lambda;
   s.Xself = d.X; s.XselfT = nullptr; s.ldT_self = d.ldT;
@@ -559,6 +560,11 @@ int bnmtf_omega_counts(bnmtf_handle h, uint64_t* total, uint32_t* row, uint32_t*
 int bnmtf_set_iteration(bnmtf_handle h, uint64_t it) { h->iteration = it; return BNMTF_OK; }
 int bnmtf_get_iteration(bnmtf_handle h, uint64_t* it) { *it = h->iteration; return BNMTF_OK; }
 
+int bnmtf_set_minimum_tn(bnmtf_handle h, double minimum_TN) {
+  if (!(minimum_TN >= 0.0)) { set_error("minimum_TN must be >= 0"); return BNMTF_EINVAL; }
+  h->min_tn = minimum_TN;
+  return BNMTF_OK;
+}
 int bnmtf_set_profiling(bnmtf_handle h, int enable) {
   // 0: off; 1: every kernel; 2 + k: kernel k only (so that a timed region carries two event records, not eight)
   h->profiling = enable == 0 ? 0u : (enable == 1 ? 0xFFFFFFFFu : 1u << (unsigned)((enable - 2) & 31));
@@ -627,7 +633,9 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
   if (n_iter == 0) return BNMTF_OK;
   HIPCHK(hipSetDevice(h->device));
   CHK(ensure_rec(h, (size_t)n_iter));
-  const int mode = update == BNMTF_UPDATE_MODE ? kSweepMode : kSweepDraw;
+  if (update < 0 || update > BNMTF_UPDATE_ICM) { set_error("unknown update rule"); return BNMTF_EINVAL; }
+  const int mode = update == BNMTF_UPDATE_DRAW ? kSweepDraw : kSweepMode;
+  h->cur_min_x = update == BNMTF_UPDATE_ICM ? (float)h->min_tn : 0.f;
   Dir& r = h->rows; Dir& c = h->cols;
   if (mode == kSweepDraw) CHK(stage_gamma_variates(h, n_iter));
   // the [3] accumulator is only written by the generic sweep kernel (and summed across ranks): zero once, reset when used

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(1024) void srow_draw_kernel(SDrawArgs a) {
           }
         }
       } else {
-        snew = (tau_p > 0.f && mu > 0.f) ? mu : 0.f;
+        snew = fmaxf((tau_p > 0.f && mu > 0.f) ? mu : 0.f, a.min_x);
       }
       if (tid == 0) { delta[l] = snew - sold; srow[l] = snew; }
       __builtin_amdgcn_s_waitcnt(0);

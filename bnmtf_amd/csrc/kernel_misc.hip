@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
     const double sse = a.sumR2 - 2.0 * srp + spp;
     const double alpha_s = a.alpha + 0.5 * n, beta_s = a.beta + 0.5 * sse;
     double tau;
-    if (a.update != 0) tau = alpha_s / beta_s;
+    if (a.update == 2) tau = (alpha_s - 1.0) / beta_s;            // gamma_mode (distributions/gamma.py:27-29)
+    else if (a.update != 0) tau = alpha_s / beta_s;
     else if (a.gunit) tau = *a.gunit / beta_s;
     else tau = gamma_draw_serial(alpha_s, beta_s, a.it, kStreamTau, a.key0, a.key1);
     *a.tau_d = tau;

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void sweep_generic_kernel(SweepArgs a) {
         }
       }
     } else if (MODE == kSweepMode) {
-      xnew = (tau_p > 0.f && mu > 0.f) ? mu : 0.f;
+      xnew = fmaxf((tau_p > 0.f && mu > 0.f) ? mu : 0.f, a.min_x);
     } else {
       double e_, v_;
       if (a.vb_moments) tn_moments((double)mu, (double)tau_p, &e_, &v_);

@@ -202,7 +202,7 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
       }
     } else {
       const float mu = numer / tau_p;
-      xnew = (valid && tau_p > 0.f && mu > 0.f) ? mu : 0.f;
+      xnew = fmaxf((valid && tau_p > 0.f && mu > 0.f) ? mu : 0.f, a.min_x);
     }
     dprev = xnew - xk;
     TICK(3, dprev);

@@ -136,7 +136,7 @@ __device__ __forceinline__ float draw_column(const SweepArgs& a, int k, float nu
     }
   } else {
     const float mu = numer / tau_p;
-    xnew = (valid && tau_p > 0.f && mu > 0.f) ? mu : 0.f;
+    xnew = fmaxf((valid && tau_p > 0.f && mu > 0.f) ? mu : 0.f, a.min_x);
   }
   return xnew;
 }

@@ -214,7 +214,7 @@ __device__ __forceinline__ void sweep_wide_body(const SweepArgs& a, const FastAr
       xnew = half ? xs1 : xs0;
     } else {
       const float mu = numer / tau_p;
-      const float xm = (valid && tau_p > 0.f && mu > 0.f) ? mu : 0.f;
+      const float xm = fmaxf((valid && tau_p > 0.f && mu > 0.f) ? mu : 0.f, a.min_x);
       xnew = half_bcast(xm, 16, half);
     }
     dprev = xnew - xk;

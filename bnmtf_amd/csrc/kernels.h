@@ -46,6 +46,7 @@ struct SweepArgs {
   int cond_k;                // >= 0: only evaluate column cond_k, write numer/tau, change nothing
   int qinit_only;            // generic kernel: compute q = X_i . Xo_j on the missing entries and stop
   int only_k;                // >= 0 (VB hooks): update only this column (update_U(k) / update_V(k))
+  float min_x;               // mode updates: lower clamp of the new value (ICM minimum_TN; 0 otherwise)
   int vb_moments;            // VB: also refresh exp/var from the new mu/tau (update_exp_U(k))
   double* vb_stats;          // VB: [n][8] per-unit ELBO / exp_square_diff partial sums (may be null)
   // numerators
@@ -119,7 +120,7 @@ struct FinishArgs {
   const double* stats; int nstats;   // [nstats][4] per-block partial sums (fast sweep), may be null
   double n_obs, sumR, sumR2;  // over the training mask
   double alpha, beta;
-  int update;                 // 0 draw, 1 mode (tau = alpha_s/beta_s)
+  int update;                 // 0 draw, 1 mode (tau = alpha_s/beta_s), 2 ICM (tau = (alpha_s - 1)/beta_s, gamma_mode)
   uint32_t key0, key1, it;
   const double* gunit;        // Gamma(alpha_s, 1) variate of this iteration computed ahead on the host, or null (draw here)
   double* tau_d; float* tau_f;
@@ -170,6 +171,7 @@ struct SRowArgs {           // one row k of S: J-vectors h_k, w_k and per-block 
 void launch_srow_gather(const SRowArgs& a, int blocks, hipStream_t st);
 struct SDrawArgs {
   int k, K, L, KPk, nblocks, update, cond_l;
+  float min_x;                         // mode updates: lower clamp (ICM minimum_TN)
   const float* partial; float* reduced; float* S; const float* lambdaS; const float* tau;
   const double* Cf64; float* CfS; float* delta_out;
   uint32_t key0, key1, it;

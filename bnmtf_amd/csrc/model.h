@@ -102,6 +102,8 @@ struct bnmtf_model {
   // profiling
   double* gunit = nullptr;               // [rec_cap] Gamma(alpha_s, 1) variates staged by run()
   std::vector<double> gunit_host;
+  double min_tn = 0.0;                   // ICM: lower clamp of every mode update (run(iterations, minimum_TN))
+  float cur_min_x = 0.f;                 // clamp in force for the sweeps being enqueued
   uint32_t profiling = 0;                // bit k: bracket the launches of kernel k with events
   double kernel_ms[BNMTF_KERNEL_COUNT] = {0};
   uint64_t kernel_launches[BNMTF_KERNEL_COUNT] = {0};

@@ -48,6 +48,7 @@ typedef struct bnmtf_model* bnmtf_handle;
  * shares all tau/mu kernels and serves as an exact end-to-end parity harness. */
 #define BNMTF_UPDATE_DRAW 0
 #define BNMTF_UPDATE_MODE 1
+#define BNMTF_UPDATE_ICM 2        /* nmf_icm / nmtf_icm: TN mode max(0, mu), clamped from below by minimum_TN; tau = gamma_mode */
 
 typedef struct bnmtf_problem {
   int32_t I, J;              /* shape of R */
@@ -173,6 +174,9 @@ int bnmtf_gamma_sample(double alpha, double beta, uint64_t seed, uint64_t it, in
  * stream; enable = 2 + k: only kernel k (BNMTF_KERNEL_*); 0: off.  Totals are read back with
  * bnmtf_kernel_stats. */
 int bnmtf_set_profiling(bnmtf_handle h, int enable);
+/* ICM: the lower clamp run(iterations, minimum_TN) applies to every updated entry (nmf_icm.py:129,135;
+ * nmtf_icm.py:147,153,159).  Used by *_gibbs_run with update = BNMTF_UPDATE_ICM.  Default 0. */
+int bnmtf_set_minimum_tn(bnmtf_handle h, double minimum_TN);
 /* sweep kernel selection: 1 (default) = register/LDS-resident fast path when the shape
  * fits, 0 = always the generic kernel (any mask, q in global memory).  Same results. */
 int bnmtf_set_sweep_path(bnmtf_handle h, int fast);

@@ -282,6 +282,50 @@ def make_trajectories():
     np.savez_compressed(os.path.join(HERE, "gibbs_trajectories.npz"), **out)
 
 
+def make_icm():
+    """nmf_icm / nmtf_icm are deterministic given the initial state: whole trajectories of the reference
+    (a converging run, a run with the minimum_TN clamp, and the collapse to zero from init='exp')."""
+    from BNMTF.code.models.nmf_icm import nmf_icm
+    from BNMTF.code.models.nmtf_icm import nmtf_icm
+    out = {}
+    R = np.loadtxt(REF + "/data_toy/bnmf/R.txt"); M = np.loadtxt(REF + "/data_toy/bnmf/M.txt")
+    I, J = R.shape
+    for name, K, lam, init, mtn, seed, iters in [("nmf_conv", 10, 1.0, "random", 0.0, 3, 12), ("nmf_min", 10, 0.1, "random", 0.1, 7, 12),
+                                                 ("nmf_collapse", 10, 0.1, "exp", 0.0, None, 3)]:
+        pri = dict(alpha=1.0, beta=1.0, lambdaU=lam * np.ones((I, K)), lambdaV=lam * np.ones((J, K)))
+        if seed is not None:
+            np.random.seed(seed)
+        b = nmf_icm(R, M, K, pri)
+        b.initialise(init)
+        out[name + "/U0"], out[name + "/V0"], out[name + "/tau0"] = b.U.copy(), b.V.copy(), np.array(b.tau)
+        with quiet(), np.errstate(all="ignore"):
+            b.run(iters, minimum_TN=mtn)
+            out[name + "/quality"] = np.array([b.quality(m) for m in ["loglikelihood", "BIC", "AIC", "MSE", "ELBO"]])
+            Mp = rand_mask(np.random.RandomState(3), I, J, 0.5)
+            pr = b.predict(Mp)
+        out[name + "/U"], out[name + "/V"], out[name + "/all_tau"] = b.U.copy(), b.V.copy(), b.all_tau.copy()
+        out[name + "/mse"] = np.array(b.all_performances["MSE"]); out[name + "/r2"] = np.array(b.all_performances["R^2"])
+        out[name + "/rp"] = np.array(b.all_performances["Rp"])
+        out[name + "/cfg"] = np.array([K, lam, mtn, iters])
+        out[name + "/Mpred"], out[name + "/pred"] = Mp, np.array([pr["MSE"], pr["R^2"], pr["Rp"]])
+    R = np.loadtxt(REF + "/data_toy/bnmtf/R.txt"); M = np.loadtxt(REF + "/data_toy/bnmtf/M.txt")
+    I, J = R.shape; K = L = 5
+    for name, lam, mtn, seed, iters in [("nmtf_conv", 1.0, 0.0, 11, 10), ("nmtf_min", 0.1, 0.05, 12, 10)]:
+        pri = dict(alpha=1.0, beta=1.0, lambdaF=lam * np.ones((I, K)), lambdaS=lam * np.ones((K, L)), lambdaG=lam * np.ones((J, L)))
+        np.random.seed(seed)
+        b = nmtf_icm(R, M, K, L, pri)
+        b.initialise("random", "random")
+        out[name + "/F0"], out[name + "/S0"], out[name + "/G0"], out[name + "/tau0"] = b.F.copy(), b.S.copy(), b.G.copy(), np.array(b.tau)
+        with quiet(), np.errstate(all="ignore"):
+            b.run(iters, minimum_TN=mtn)
+            out[name + "/quality"] = np.array([b.quality(m) for m in ["loglikelihood", "BIC", "AIC", "MSE", "ELBO"]])
+        out[name + "/F"], out[name + "/S"], out[name + "/G"], out[name + "/all_tau"] = b.F.copy(), b.S.copy(), b.G.copy(), b.all_tau.copy()
+        out[name + "/mse"] = np.array(b.all_performances["MSE"]); out[name + "/r2"] = np.array(b.all_performances["R^2"])
+        out[name + "/rp"] = np.array(b.all_performances["Rp"])
+        out[name + "/cfg"] = np.array([K, lam, mtn, iters])
+    np.savez_compressed(os.path.join(HERE, "icm.npz"), **out)
+
+
 def make_toy_data():
     """The reference's toy inputs (data files its own tests/experiments hold) as one fixture."""
     out = {}
@@ -294,13 +338,14 @@ def make_toy_data():
 
 if __name__ == "__main__":
     import_reference()
-    which = sys.argv[1:] or ["toy", "bnmf", "bnmtf", "vb", "tn", "traj"]
+    which = sys.argv[1:] or ["toy", "bnmf", "bnmtf", "vb", "tn", "traj", "icm"]
     if "toy" in which: make_toy_data()
     if "bnmf" in which: make_bnmf_cond()
     if "bnmtf" in which: make_bnmtf_cond()
     if "vb" in which: make_vb()
     if "tn" in which: make_tn()
     if "traj" in which: make_trajectories()
+    if "icm" in which: make_icm()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))
