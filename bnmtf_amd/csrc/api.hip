@@ -341,7 +341,7 @@ static void enqueue_sweep(bnmtf_model* h, Dir& d, const Dir& other, SweepArgs& s
     { const char* e = getenv("BNMTF_SWEEP_DBG"); f.dbg = e ? atoi(e) : 0; }
     SweepArgs s2 = s;
     s2.acc = nullptr;
-    f.off16 = d.f_off16;
+    f.off16 = d.pair_ok ? d.f_off16 : nullptr;
     const char* kern = getenv("BNMTF_SWEEP_KERNEL");           // "fast" (default) | "pair" (two columns per barrier; same speed at 8 waves, kept for experiments)
     if (d.pair_ok && kern && !strcmp(kern, "pair")) {
       const bool nw16 = getenv("BNMTF_PAIR_NW8") == nullptr && d.f_npairs_hi40 < d.f_npairs;

@@ -72,10 +72,20 @@ __device__ __forceinline__ void sweep_wide_body(const SweepArgs& a, const FastAr
   // slot addresses as LDS BYTE addresses inside panel buffer 0 (sentinel: a zero word on bank l5)
   uint32_t addr[EM];
   f32x2 q2[EH], vp2[EH];                   // slots (2h, 2h+1) share a register pair: packed f32 FMAs
+  if (f.off16) {                            // two 16-bit inner indices per word: half the bytes of the slot table
 #pragma unroll
-  for (int s = 0; s < EM; ++s) {
-    const uint32_t j = (s < E) ? f.off[((size_t)base + s) * 64 + lane] : (uint32_t)(f.mz + l5);
-    addr[s] = pan_b + 4u * j;
+    for (int h = 0; h < EH; ++h) {
+      const uint32_t sent = (uint32_t)(f.mz + l5);
+      const uint32_t w = (2 * h < E) ? f.off16[((size_t)(base >> 1) + h) * 64 + lane] : (sent | (sent << 16));
+      addr[2 * h] = pan_b + 4u * (w & 0xFFFFu);
+      addr[2 * h + 1] = pan_b + 4u * (w >> 16);
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < EM; ++s) {
+      const uint32_t j = (s < E) ? f.off[((size_t)base + s) * 64 + lane] : (uint32_t)(f.mz + l5);
+      addr[s] = pan_b + 4u * j;
+    }
   }
 #pragma unroll
   for (int h = 0; h < EH; ++h) { q2[h] = f32x2{0.f, 0.f}; vp2[h] = f32x2{0.f, 0.f}; }
