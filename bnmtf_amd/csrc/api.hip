@@ -151,6 +151,7 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
     const int emax_all = d.n > 0 ? Eu[order[0]] : 0;
     const int wide_blocks = (npairs_real + 15) / 16;
     const bool wide_can = sweep_wide_supported(d.KP, d.pw) && emax_all <= kWideMaxSlots && d.n > 0;
+    d.wide_can = wide_can;
     d.use_wide = wide_can && wide_blocks >= 192;
     if (const char* e = getenv("BNMTF_WIDE")) d.use_wide = wide_can && atoi(e) != 0;      // 0: never, 1: whenever it can run
     d.f_npairs = d.use_wide ? wide_blocks * 16 : npairs_real;
@@ -275,7 +276,7 @@ static void free_dir(Dir& d) {
   dfree(d.XT2); dfree(d.Cpart); dfree(d.spart); dfree(d.s2part); dfree(d.f_unit_map); dfree(d.f_pair_E);
   dfree(d.f_pair_base); dfree(d.f_off); dfree(d.f_off16); dfree(d.stats); dfree(d.f_gen_units);
   dfree(d.vb_stats);
-  dfree(d.mu); dfree(d.tauq); dfree(d.var); dfree(d.S2); dfree(d.S2T); dfree(d.numer); dfree(d.taup);
+  dfree(d.mu); dfree(d.tauq); dfree(d.var); dfree(d.S2); dfree(d.S2T); dfree(d.XS); dfree(d.vb_asq); dfree(d.vb_vsq); dfree(d.numer); dfree(d.taup);
 }
 
 // ---------------------------------------------------------------- profiling
@@ -326,7 +327,7 @@ static void enqueue_post(bnmtf_model* h, Dir& d, bool vb = false) {
   memset(&g, 0, sizeof(g));
   g.X = d.X; g.rows = d.nglob; g.KP = d.KP; g.XT = d.XT; g.ldT = d.ldT; g.XT2 = d.XT2; g.ld2 = d.ldT;
   g.Cpart = d.Cpart; g.spart = d.spart; g.C64 = d.C64; g.C32 = d.C32; g.colsum = d.colsum;
-  if (vb) { g.S2 = d.S2; g.S2T = d.S2T; g.s2part = d.s2part; g.colsum2 = d.colsum2; }
+  if (vb) { g.S2 = d.S2; g.S2T = d.S2T; g.s2part = d.s2part; g.colsum2 = d.colsum2; g.XS = d.XS; }
   launch_post(g, h->stream);
 }
 static void enqueue_sweep(bnmtf_model* h, Dir& d, const Dir& other, SweepArgs& s, bool want_stats) {

@@ -11,14 +11,15 @@ namespace bnmtf {
 
 __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
   constexpr int RB = kPostRows;
-  __shared__ float tile[RB * 68];
+  __shared__ float tile0[RB * 68], tile1[RB * 68];     // X rows ; VB: S2 rows
   constexpr int LD = 68;
   const int KP = a.KP, tid = threadIdx.x;
   const int r0 = blockIdx.x * RB;
   const int nr = min(RB, a.rows - r0);
   const float* src = a.X;
   for (int pass = 0; pass < (a.S2 ? 2 : 1); ++pass) {
-    if (pass == 1) { __syncthreads(); src = a.S2; }
+    float* tile = pass == 0 ? tile0 : tile1;
+    if (pass == 1) src = a.S2;
     for (int t = tid; t < RB * KP; t += 256) {
       const int r = t / KP, k = t % KP;
       tile[r * LD + k] = (r < nr) ? src[(size_t)(r0 + r) * KP + k] : 0.f;
@@ -64,6 +65,11 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
       for (int r = 0; r < nr; ++r) s += (double)tile[r * LD + tid];
       (pass == 0 ? a.spart : a.s2part)[(size_t)blockIdx.x * KP + tid] = s;
     }
+    if (pass == 1 && a.XS)        // VB: the (E, S2) pair panels of the fast VB sweep, [KP][ldT][2]
+      for (int t = tid; t < RB * KP; t += 256) {
+        const int k = t / RB, r = t % RB;
+        if (r < nr) *reinterpret_cast<float2*>(a.XS + ((size_t)k * a.ldT + r0 + r) * 2) = float2{tile0[r * LD + k], tile1[r * LD + k]};
+      }
   }
 }
 

@@ -1,0 +1,265 @@
+// K3-VB: the variational half sweep (bnmf_vb_optimised.py:189-211, update_U(k) + update_exp_U(k) for k = 0..K-1)
+// in the register/LDS-resident shape of kernel_sweep_wide.hip: 16 units per block, 8 waves (the fp64 moments need the 256-VGPR budget).
+//
+// Per unit i and column k (E = expectations, S2 = var + E^2 of the OTHER factor):
+//   tau_ik = exptau * sum_j M_ij S2_jk                = exptau * (colsum2_k - sum_{j in miss(i)} S2_jk)
+//   mu_ik  = (-lambda_ik + exptau * num_ik) / tau_ik ,  num as in the Gibbs sweep with U, V -> E[U], E[V]
+//   E[U_ik], Var[U_ik] = moments of TN(mu_ik, tau_ik)  (fp64: exp, erfc)
+// Differences from the Gibbs kernels:
+//  * the panel of column k is the PAIR (E_jk, S2_jk) interleaved per j (PostArgs::XS, written by post_kernel), one
+//    ds_read_b64 per slot, so the main loop shares the pre-pass's 8-byte slot addressing and its two 66 KiB buffers;
+//  * the fp64 moments are NOT evaluated by every wave (8 waves x ~300 fp64 instructions per column would swamp the
+//    SIMDs): each wave posts (mu, tau) of its two units to LDS, wave 0 evaluates the units of the block one per
+//    lane, writes mu/tau/E/Var/S2 of column k to global memory and posts E back.  Two block barriers per column;
+//  * the ELBO / exp_square_diff pieces (more fp64 erfc/log) do not feed the recurrence: the sweep stores
+//    sum_miss S2 and sum_miss E^2 per (unit, column) and vb_pieces_kernel evaluates them afterwards, all units in parallel.
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+#include "sweep_common.h"
+
+namespace bnmtf {
+
+constexpr int kVbNW = 8;     // 8 waves x 256 VGPRs: the fp64 exp/erfc of the moments do not fit beside 28 slots at 128
+
+template <int EM, int NX>
+__device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs& f, float* lds) {
+  constexpr int NW = kVbNW;
+  constexpr int KP = NX * 32;
+  constexpr int EH = EM / 2;
+  static_assert(EM % 2 == 0, "slots are processed in pairs");
+  const int PW = f.pw;
+  float* Cs = lds;                          // [KP][KP]
+  float* c2s = lds + KP * KP;               // [KP] colsum2 of the other factor
+  float* xch = c2s + KP;                    // [2*NW][4] (mu, tau, sum_miss S2, sum_miss E^2) posted by the owners
+  float* ret = xch + 2 * NW * 4;            // [2*NW] E back from wave 0
+  float* pan = ret + 2 * NW;                // two pair-panel buffers of 2*PW floats
+  const uint32_t pan_b = (uint32_t)(uintptr_t)(lds_fp)pan;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l5 = lane & 31;
+  const int pair = blockIdx.x * NW + wave;
+  const bool wave_on = pair < f.npairs;
+  const uint32_t base = wave_on ? f.pair_base[pair] : 0u;
+  const int E = wave_on ? (int)f.pair_E[pair] : 0;
+  const int u = wave_on ? f.unit_map[2 * pair + half] : -1;
+  const bool valid = u >= 0;
+  const uint32_t gi = (uint32_t)a.n0 + (uint32_t)(valid ? u : 0);
+  const int K = a.K;
+  const float tau = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *a.tau)));
+
+  float x[NX], pl[NX];
+  auto slab_sum = [&](int nx) {
+    float s = 0.f;
+    if (valid) for (int sl = 0; sl < a.split; ++sl) s += a.slabs[((size_t)sl * a.n_pad + u) * KP + l5 + 32 * nx];
+    return s;
+  };
+#pragma unroll
+  for (int nx = 0; nx < NX; ++nx) {
+    const int kk = l5 + 32 * nx;
+    x[nx] = valid ? a.Xself[(size_t)gi * KP + kk] : 0.f;
+    pl[nx] = valid ? fmaf(tau, slab_sum(nx), -a.lambda[(size_t)u * KP + kk]) : 0.f;
+  }
+  // slot addresses as LDS byte addresses of the 8-byte element j in pair-panel buffer 0 (sentinel: zeros on bank pair l5)
+  uint32_t addr[EM];
+  f32x2 q2[EH], vp2[EH];
+#pragma unroll
+  for (int h = 0; h < EH; ++h) {
+    const uint32_t sent = (uint32_t)(f.mz + l5);
+    const uint32_t w = (2 * h < E) ? f.off16[((size_t)(base >> 1) + h) * 64 + lane] : (sent | (sent << 16));
+    addr[2 * h] = pan_b + 8u * (w & 0xFFFFu);
+    addr[2 * h + 1] = pan_b + 8u * (w >> 16);
+    q2[h] = f32x2{0.f, 0.f}; vp2[h] = f32x2{0.f, 0.f};
+  }
+  for (int t = tid; t < KP * KP; t += NW * 64) Cs[t] = a.C32[t];
+  if (tid < KP) c2s[tid] = (float)a.colsum2_o[tid];
+  // wave 0, lane un: the unit it evaluates the moments for
+  int mgi = -1;
+  if (wave == 0 && lane < 2 * NW) {
+    const int pr = blockIdx.x * NW + (lane >> 1);
+    const int uu = pr < f.npairs ? f.unit_map[2 * pr + (lane & 1)] : -1;
+    mgi = uu >= 0 ? a.n0 + uu : -1;
+  }
+
+  const int chunks2 = (2 * PW) / 256;
+  const uint32_t buf_b = (uint32_t)(2 * PW) * 4u;           // bytes between the two buffers
+  // ------------------------------------------------------------ pre-pass: q = E[U_i] . E[V_j]  (pair panels of E)
+  {
+    const uint32_t stride_b = (uint32_t)f.ld2_o * 8u;
+    const __amdgpu_buffer_rsrc_t rs2 = panel_rsrc(f.XoT2, (size_t)(KP / 2) * f.ld2_o * 8);
+    stage_panel_buf<NW>(rs2, 0u, pan, chunks2, wave, lane * 16);
+    __syncthreads();
+    const int npair = KP / 2;
+    for (int kp = 0; kp < npair; ++kp) {
+      if (kp + 1 < npair) stage_panel_buf<NW>(rs2, (uint32_t)(kp + 1) * stride_b, pan + (size_t)((kp + 1) & 1) * 2 * PW, chunks2, wave, lane * 16);
+      const uint32_t boff = (uint32_t)(kp & 1) * buf_b;
+      const int k0 = 2 * kp, k1 = 2 * kp + 1;
+      const float xs0 = (NX == 2 && k0 >= 32) ? x[NX - 1] : x[0];
+      const float x0 = half_bcast(xs0, k0 & 31, half), x1 = half_bcast(xs0, k1 & 31, half);
+      const f32x2 x01 = {x0, x1};
+#pragma unroll
+      for (int h = 0; h < EH; ++h) {
+        const f32x2 va = *(lds_cf2*)(uintptr_t)(addr[2 * h] + boff);
+        const f32x2 vb = *(lds_cf2*)(uintptr_t)(addr[2 * h + 1] + boff);
+        q2[h] = pk_fma(va, x01, q2[h]);
+        vp2[h] = pk_fma(vb, x01, vp2[h]);
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int h = 0; h < EH; ++h) { q2[h] = f32x2{q2[h].x + q2[h].y, vp2[h].x + vp2[h].y}; vp2[h] = f32x2{0.f, 0.f}; }
+  }
+
+  // ------------------------------------------------------------ the K sequential columns, panels of (E_k, S2_k)
+  const __amdgpu_buffer_rsrc_t rsx = panel_rsrc(f.XoS, (size_t)KP * f.ld2_o * 8);
+  const uint32_t cstride_b = (uint32_t)f.ld2_o * 8u;
+  stage_panel_buf<NW>(rsx, 0u, pan, chunks2, wave, lane * 16);
+  __syncthreads();
+  float dprev = 0.f;
+  for (int k = 0; k < K; ++k) {
+    if (k + 1 < K) stage_panel_buf<NW>(rsx, (uint32_t)(k + 1) * cstride_b, pan + (size_t)((k + 1) & 1) * 2 * PW, chunks2, wave, lane * 16);
+    const uint32_t boff = (uint32_t)(k & 1) * buf_b;
+    const float xsel = (NX == 2 && k >= 32) ? x[NX - 1] : x[0];
+    const float xk = half_bcast(xsel, k & 31, half);
+    // (A) column k-1's update of q
+    const f32x2 dp2 = {dprev, dprev};
+#pragma unroll
+    for (int h = 0; h < EH; ++h) q2[h] = pk_fma(dp2, vp2[h], q2[h]);
+    __builtin_amdgcn_sched_barrier(0);
+    // (B, C) gather (E_jk, S2_jk); sum q E, sum E^2, sum S2
+    f32x2 qv2 = {0.f, 0.f}, vv2 = {0.f, 0.f}, ss2 = {0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < EH; ++h) {
+      const f32x2 ta = *(lds_cf2*)(uintptr_t)(addr[2 * h] + boff);
+      const f32x2 tb = *(lds_cf2*)(uintptr_t)(addr[2 * h + 1] + boff);
+      vp2[h] = f32x2{ta.x, tb.x};
+      qv2 = pk_fma(q2[h], vp2[h], qv2);
+      vv2 = pk_fma(vp2[h], vp2[h], vv2);
+      ss2.x += ta.y; ss2.y += tb.y;
+    }
+    float vv_t = vv2.x + vv2.y, ss_t = ss2.x + ss2.y;
+    float corr_t = fmaf(-xk, vv_t, qv2.x + qv2.y);
+#pragma unroll
+    for (int nx = 0; nx < NX; ++nx) corr_t = fmaf(-x[nx], Cs[k * KP + l5 + 32 * nx], corr_t);   // all l: the l = k term is put back below
+    __builtin_amdgcn_sched_barrier(0);
+    corr_t = half_sum_upper(corr_t);     // right in lanes 16-31 of the half
+    vv_t = half_sum_upper(vv_t);
+    ss_t = half_sum_upper(ss_t);
+    const float ckk = Cs[k * KP + k];
+    const float psel = (NX == 2 && k >= 32) ? pl[NX - 1] : pl[0];
+    const float tau_p = tau * (c2s[k] - ss_t);
+    const float numer = fmaf(tau, fmaf(xk, ckk, corr_t), half_bcast(psel, k & 31, half));
+    if (l5 == 16) {
+      float4 o; o.x = numer / tau_p; o.y = tau_p; o.z = ss_t; o.w = vv_t;
+      *reinterpret_cast<float4*>(&xch[(2 * wave + half) * 4]) = o;
+    }
+    __syncthreads();
+    if (wave == 0 && lane < 2 * NW) {
+      const float4 o = *reinterpret_cast<const float4*>(&xch[lane * 4]);
+      double e_ = 0.0, v_ = 0.0;
+      if (mgi >= 0) {
+        tn_moments((double)o.x, (double)o.y, &e_, &v_);
+        const size_t p = (size_t)mgi * KP + k;
+        const float ef = (float)e_, vf = (float)v_;
+        a.Xself[p] = ef; a.mu_self[p] = o.x; a.tau_self[p] = o.y; a.var_self[p] = vf; a.S2self[p] = vf + ef * ef;
+        f.vb_asq[p] = o.z; f.vb_vsq[p] = o.w;
+      }
+      ret[lane] = (float)e_;
+    }
+    __syncthreads();                     // also lands the next panel (vmcnt) and retires this one
+    const float xnew = ret[2 * wave + half];
+    dprev = xnew - xk;
+#pragma unroll
+    for (int nx = 0; nx < NX; ++nx)
+      if (l5 + 32 * nx == k) x[nx] = xnew;
+  }
+
+  // ------------------------------------------------------------ the three sums of the SSE identity (cols sweep)
+  if (f.stats) {
+    double px = 0.0, sq = 0.0, sq2 = 0.0;
+#pragma unroll
+    for (int nx = 0; nx < NX; ++nx) px += (double)slab_sum(nx) * (double)x[nx];
+#pragma unroll
+    for (int h = 0; h < EH; ++h) {
+      const double qa = (double)fmaf(dprev, vp2[h].x, q2[h].x), qb = (double)fmaf(dprev, vp2[h].y, q2[h].y);
+      sq += qa + qb; sq2 += qa * qa + qb * qb;
+    }
+    px = half_sum_d(px); sq = half_sum_d(sq); sq2 = half_sum_d(sq2);
+    double* red = reinterpret_cast<double*>(pan);      // panels are dead: reuse
+    if (l5 == 0) { red[(wave * 2 + half) * 3 + 0] = valid ? px : 0.0; red[(wave * 2 + half) * 3 + 1] = sq; red[(wave * 2 + half) * 3 + 2] = sq2; }
+    __syncthreads();
+    if (tid < 3) {
+      double s = 0.0;
+      for (int w = 0; w < 2 * NW; ++w) s += red[w * 3 + tid];
+      f.stats[(size_t)blockIdx.x * 4 + tid] = s;
+    }
+  }
+}
+
+template <int NX>
+__global__ __launch_bounds__(kVbNW * 64, 1) void sweep_vb_kernel(SweepArgs a, FastArgs f) {
+  extern __shared__ float lds[];
+  const int pr = blockIdx.x * kVbNW + (int)(threadIdx.x >> 6);
+  const int e0 = __builtin_amdgcn_readfirstlane(pr < f.npairs ? (int)f.pair_E[pr] : 0);
+  if (e0 <= 8) sweep_vb_body<8, NX>(a, f, lds);
+  else if (e0 <= 16) sweep_vb_body<16, NX>(a, f, lds);
+  else if (e0 <= 24) sweep_vb_body<24, NX>(a, f, lds);
+  else if (e0 <= 28) sweep_vb_body<28, NX>(a, f, lds);
+  else sweep_vb_body<kWideMaxSlots, NX>(a, f, lds);      // host guarantees e0 <= kWideMaxSlots
+}
+
+size_t sweep_vb_lds_bytes(int KP, int pw) { return sizeof(float) * ((size_t)KP * KP + KP + 2 * kVbNW * 5 + 4 * (size_t)pw); }
+
+bool sweep_vb_supported(int KP, int pw) { return sweep_vb_lds_bytes(KP, pw) <= 160 * 1024; }
+
+void launch_sweep_vb(const SweepArgs& a, const FastArgs& f, hipStream_t st) {
+  const size_t lds_bytes = sweep_vb_lds_bytes(a.KP, f.pw);
+  const int nblocks = (f.npairs + kVbNW - 1) / kVbNW;
+  static bool once[2] = {false, false};
+  const int nx = a.KP / 32;
+  if (!once[nx - 1]) {
+    if (nx == 1) (void)hipFuncSetAttribute((const void*)sweep_vb_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    else         (void)hipFuncSetAttribute((const void*)sweep_vb_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    once[nx - 1] = true;
+  }
+  if (nblocks <= 0) return;
+  if (nx == 1) hipLaunchKernelGGL((sweep_vb_kernel<1>), dim3(nblocks), dim3(kVbNW * 64), lds_bytes, st, a, f);
+  else         hipLaunchKernelGGL((sweep_vb_kernel<2>), dim3(nblocks), dim3(kVbNW * 64), lds_bytes, st, a, f);
+}
+
+// ELBO / exp_square_diff pieces of one sweep (bnmf_vb_optimised.py:163-177, 185-187), one wave per unit, lane = column:
+//   [0] sum_k tau/2 (Var + (E - mu)^2)   [1] sum_k log(1/2 erfc(-mu sqrt(tau/2)))   [2] sum_k log tau   [3] sum_k lambda E
+//   [4] sum_k S2self sum_miss S2other    [5] sum_k E^2 sum_miss Eother^2
+__global__ __launch_bounds__(256) void vb_pieces_kernel(int n, int n0, int KP, int K, const float* mu, const float* tauq, const float* ex,
+                                                         const float* var, const float* lambda, const float* asq, const float* vsq, double* out) {
+  const int lane = threadIdx.x & 63, u = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (u >= n) return;
+  double p[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (lane < K) {
+    const size_t q = (size_t)(n0 + u) * KP + lane;
+    const double m = (double)mu[q], t = (double)tauq[q], e = (double)ex[q], v = (double)var[q];
+    const double dm = e - m;
+    p[0] = 0.5 * t * (v + dm * dm);
+    p[1] = log(0.5 * erfc(-m * sqrt(t) * 0.7071067811865476));
+    p[2] = log(t);
+    p[3] = (double)lambda[(size_t)u * KP + lane] * e;
+    p[4] = (v + e * e) * (double)asq[q];
+    p[5] = e * e * (double)vsq[q];
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) p[c] += __shfl_xor(p[c], s, 64);
+  }
+  if (lane == 0) for (int c = 0; c < 6; ++c) out[(size_t)u * 8 + c] = p[c];
+}
+
+void launch_vb_pieces(int n, int n0, int KP, int K, const float* mu, const float* tauq, const float* ex, const float* var,
+                      const float* lambda, const float* asq, const float* vsq, double* out, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(vb_pieces_kernel, dim3((n + 3) / 4), dim3(256), 0, st, n, n0, KP, K, mu, tauq, ex, var, lambda, asq, vsq, out);
+}
+
+}  // namespace bnmtf

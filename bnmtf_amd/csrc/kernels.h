@@ -87,6 +87,9 @@ struct FastArgs {
   const float* XoT2; int ld2_o;  // other factor, column pairs interleaved [KP/2][ld2_o][2]
   int dbg;                     // timing experiments only (BNMTF_SWEEP_DBG): 1 no restaging, 2 no slot loops, 4 no sampler
   double* stats;               // [blocks][4] partial (sum P.X', sum_miss q, sum_miss q^2) or null
+  // VB sweep (kernel_sweep_vb.hip)
+  const float* XoS;            // other factor's (E, S2) pair panels [KP][ld2_o][2]
+  float* vb_asq; float* vb_vsq;  // [rows][KP] per (unit, column): sum_miss S2other, sum_miss Eother^2 (for vb_pieces_kernel)
 };
 constexpr int kFastMaxSlots = 56;   // blocks whose fullest pair needs more slots per lane go to the generic kernel
 bool sweep_fast_supported(int KP, int pw);
@@ -95,6 +98,11 @@ void launch_sweep_fast(const SweepArgs& a, const FastArgs& f, hipStream_t st);
 constexpr int kWideMaxSlots = 32;
 bool sweep_wide_supported(int KP, int pw);
 void launch_sweep_wide(const SweepArgs& a, const FastArgs& f, hipStream_t st);
+// VB sweep in the 16-wave shape (kernel_sweep_vb.hip) and the ELBO pieces it leaves to a second pass
+bool sweep_vb_supported(int KP, int pw);
+void launch_sweep_vb(const SweepArgs& a, const FastArgs& f, hipStream_t st);
+void launch_vb_pieces(int n, int n0, int KP, int K, const float* mu, const float* tauq, const float* ex, const float* var,
+                      const float* lambda, const float* asq, const float* vsq, double* out, hipStream_t st);
 // pair-step kernel (kernel_sweep_pair.hip); f.npairs_hi = leading pairs with more than 40 slots when nw16
 void launch_sweep_pair(const SweepArgs& a, const FastArgs& f, bool nw16, hipStream_t st);
 
@@ -106,6 +114,7 @@ struct PostArgs {
   double* C64; float* C32; double* colsum;
   // VB: second moment matrix S2 = var + exp^2
   const float* S2; float* S2T; double* s2part; double* colsum2;
+  float* XS;                             // VB: [KP][ldT][2] (E, S2) interleaved per row: pair panels of the fast VB sweep, or null
 };
 void launch_post(const PostArgs& a, hipStream_t st);
 constexpr int kPostRows = 32;

@@ -64,6 +64,8 @@ struct Dir {
   double* C64 = nullptr; float* C32 = nullptr; double* colsum = nullptr;   // Gram of X
   // VB only
   float *mu = nullptr, *tauq = nullptr, *var = nullptr, *S2 = nullptr, *S2T = nullptr;
+  float *XS = nullptr, *vb_asq = nullptr, *vb_vsq = nullptr;   // fast VB sweep: (E, S2) pair panels; per (unit, column) sums for the ELBO pieces
+  bool wide_can = false;                 // the 16-wave kernels can run on this direction (<= kWideMaxSlots slots per lane, LDS fits)
   double* colsum2 = nullptr;
   double* vb_stats = nullptr;           // VB: [n][8] per-unit partial sums
   // cond-params scratch
