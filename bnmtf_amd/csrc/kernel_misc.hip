@@ -105,29 +105,32 @@ __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
 // VB end of iteration (bnmf_vb_optimised.py:181-187, 213-215): exp_square_diff from Gram identities,
 // exptau = alpha_s / beta_s, training-mask metrics, and the O((I+J)K) sums elbo() needs.
 __global__ __launch_bounds__(256) void vb_finish_kernel(VbFinishArgs a) {
-  __shared__ double red[256];
-  const int KP = a.KP;
-  auto block_sum = [&](double v) {
-    red[threadIdx.x] = v;
-    __syncthreads();
-    for (int w = 128; w >= 1; w >>= 1) { if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w]; __syncthreads(); }
-    const double r = red[0];
-    __syncthreads();
-    return r;
-  };
-  double s = 0.0;
-  for (int t = threadIdx.x; t < KP * KP; t += 256) s = fma(a.Cr64[t], a.Cc64[t], s);
-  const double dot = block_sum(s);
-  double su[6], sv[6];
-  for (int c = 0; c < 6; ++c) {
-    double v = 0.0;
-    for (int b = threadIdx.x; b < a.nr; b += 256) v += a.stats_r[(size_t)b * 8 + c];
-    su[c] = block_sum(v);
-    v = 0.0;
-    for (int b = threadIdx.x; b < a.nc; b += 256) v += a.stats_c[(size_t)b * 8 + c];
-    sv[c] = block_sum(v);
+  __shared__ double red[4][13];
+  const int KP = a.KP, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // 13 sums at once: <Cr, Cc>, six columns of the rows-sweep pieces, six of the cols-sweep pieces
+  double v[13];
+#pragma unroll
+  for (int t = 0; t < 13; ++t) v[t] = 0.0;
+  for (int t = threadIdx.x; t < KP * KP; t += 256) v[0] = fma(a.Cr64[t], a.Cc64[t], v[0]);
+  for (int b = threadIdx.x; b < a.nr; b += 256)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) v[1 + c] += a.stats_r[(size_t)b * 8 + c];
+  for (int b = threadIdx.x; b < a.nc; b += 256)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) v[7 + c] += a.stats_c[(size_t)b * 8 + c];
+#pragma unroll
+  for (int t = 0; t < 13; ++t) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v[t] += __shfl_xor(v[t], m, 64);
+    if (lane == 0) red[wave][t] = v[t];
   }
+  __syncthreads();
   if (threadIdx.x == 0) {
+    double tot[13];
+    for (int t = 0; t < 13; ++t) tot[t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    const double dot = tot[0];
+    const double* su = &tot[1];
+    const double* sv = &tot[7];
     double sp1 = 0.0, s22 = 0.0, sdd = 0.0;
     for (int t = 0; t < KP; ++t) {
       sp1 = fma(a.sr[t], a.sc[t], sp1);
@@ -220,16 +223,23 @@ void launch_metric_sums(const MetricArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(metric_kernel, grid, block, 0, st, a);
 }
 
-__global__ void sum_stats_kernel(const double* stats, int nblocks, double* acc) {
-  const int t = threadIdx.x;
-  if (t < 3) {
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += stats[(size_t)b * 4 + t];
-    acc[t] += s;
+__global__ __launch_bounds__(256) void sum_stats_kernel(const double* stats, int nblocks, double* acc) {
+  __shared__ double red[4][3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double v[3] = {0.0, 0.0, 0.0};
+  for (int b = threadIdx.x; b < nblocks; b += 256)
+    for (int t = 0; t < 3; ++t) v[t] += stats[(size_t)b * 4 + t];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v[t] += __shfl_xor(v[t], m, 64);
+    if (lane == 0) red[wave][t] = v[t];
   }
+  __syncthreads();
+  if (threadIdx.x < 3) acc[threadIdx.x] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 void launch_sum_stats(const double* stats, int nblocks, double* acc, hipStream_t st) {
-  hipLaunchKernelGGL(sum_stats_kernel, dim3(1), dim3(64), 0, st, stats, nblocks, acc);
+  hipLaunchKernelGGL(sum_stats_kernel, dim3(1), dim3(256), 0, st, stats, nblocks, acc);
 }
 
 // ---------------------------------------------------------------------------

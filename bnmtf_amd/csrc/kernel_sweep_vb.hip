@@ -232,12 +232,12 @@ void launch_sweep_vb(const SweepArgs& a, const FastArgs& f, hipStream_t st) {
 // ELBO / exp_square_diff pieces of one sweep (bnmf_vb_optimised.py:163-177, 185-187), one wave per unit, lane = column:
 //   [0] sum_k tau/2 (Var + (E - mu)^2)   [1] sum_k log(1/2 erfc(-mu sqrt(tau/2)))   [2] sum_k log tau   [3] sum_k lambda E
 //   [4] sum_k S2self sum_miss S2other    [5] sum_k E^2 sum_miss Eother^2
+// out: one row of 8 per BLOCK of four units (vb_finish_kernel only needs the totals).
 __global__ __launch_bounds__(256) void vb_pieces_kernel(int n, int n0, int KP, int K, const float* mu, const float* tauq, const float* ex,
                                                          const float* var, const float* lambda, const float* asq, const float* vsq, double* out) {
   const int lane = threadIdx.x & 63, u = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (u >= n) return;
   double p[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  if (lane < K) {
+  if (u < n && lane < K) {
     const size_t q = (size_t)(n0 + u) * KP + lane;
     const double m = (double)mu[q], t = (double)tauq[q], e = (double)ex[q], v = (double)var[q];
     const double dm = e - m;
@@ -253,7 +253,11 @@ __global__ __launch_bounds__(256) void vb_pieces_kernel(int n, int n0, int KP, i
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) p[c] += __shfl_xor(p[c], s, 64);
   }
-  if (lane == 0) for (int c = 0; c < 6; ++c) out[(size_t)u * 8 + c] = p[c];
+  // one row of partial sums per block (4 units), in unit order
+  __shared__ double red[4][6];
+  if (lane == 0) for (int c = 0; c < 6; ++c) red[threadIdx.x >> 6][c] = p[c];
+  __syncthreads();
+  if (threadIdx.x < 6) out[(size_t)blockIdx.x * 8 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 void launch_vb_pieces(int n, int n0, int KP, int K, const float* mu, const float* tauq, const float* ex, const float* var,

@@ -67,7 +67,8 @@ struct Dir {
   float *XS = nullptr, *vb_asq = nullptr, *vb_vsq = nullptr;   // fast VB sweep: (E, S2) pair panels; per (unit, column) sums for the ELBO pieces
   bool wide_can = false;                 // the 16-wave kernels can run on this direction (<= kWideMaxSlots slots per lane, LDS fits)
   double* colsum2 = nullptr;
-  double* vb_stats = nullptr;           // VB: [n][8] per-unit partial sums
+  double* vb_stats = nullptr;           // VB: [n][8] per-unit partial sums (generic sweep) or [ceil(n/4)][8] per-block (fast sweep)
+  int vb_stat_rows = 0;                 // rows of vb_stats the last sweep wrote
   // cond-params scratch
   double *numer = nullptr, *taup = nullptr;
   std::vector<uint32_t> obs_count;      // host, all nglob units
