@@ -15,8 +15,7 @@
 // srow_draw_kernel reduces them, runs the L sequential draws and propagates delta.
 #include <algorithm>
 
-#include "kernels.h"
-#include "device_rng.h"
+#include "sweep_common.h"
 
 namespace bnmtf {
 
@@ -179,19 +178,20 @@ __global__ __launch_bounds__(1024) void srow_draw_kernel(SDrawArgs a) {
       const float mu = numer / tau_p;
       float snew = 0.f;
       if (a.update == 0) {
-        const TnParams tp = tn_params(mu, tau_p);
+        const TnFast tp = tn_fast_params(numer, tau_p);           // the one-instruction forms the factor sweeps use
         if (tp.live) {
           // candidates 0, 1 from the hoisted words (lane l), then 64 fresh candidates per round
           const uint32_t w0a = (uint32_t)__builtin_amdgcn_readlane((int)c0a, l), w0b = (uint32_t)__builtin_amdgcn_readlane((int)c0b, l);
           const uint32_t w1a = (uint32_t)__builtin_amdgcn_readlane((int)c1a, l), w1b = (uint32_t)__builtin_amdgcn_readlane((int)c1b, l);
           float x0, x1;
-          const bool a0 = tn_eval_words(tp, w0a, w0b, &x0), a1 = tn_eval_words(tp, w1a, w1b, &x1);
+          const bool a0 = tn_eval_fast(tp, w0a, w0b, &x0), a1 = tn_eval_fast(tp, w1a, w1b, &x1);
           if (a0) snew = tn_guard(x0);
           else if (a1) snew = tn_guard(x1);
           else {
             for (uint32_t round = 0; round < 64u; ++round) {
+              const U4 r = philox4x32_10(0u, (uint32_t)(k * L + l), a.it, kStreamS + 16u * (2u + round * 64u + tid), a.key0, a.key1);
               float xc;
-              const bool acc = tn_candidate(tp, 0u, (uint32_t)(k * L + l), a.it, kStreamS, 2u + round * 64u + tid, a.key0, a.key1, &xc);
+              const bool acc = tn_eval_fast(tp, r.x, r.y, &xc);
               const unsigned long long m = __ballot(acc);
               if (m) { snew = tn_guard(__shfl(xc, __ffsll((long long)m) - 1, 64)); break; }
             }
