@@ -197,7 +197,7 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
     HIPCHK(hipMemcpy(d.f_pair_base, pB.data(), pB.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     CHK(dalloc(&d.f_off, off.size(), false));
     HIPCHK(hipMemcpy(d.f_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    {   // 16-bit packed slot pairs for the pair-step kernel
+    {   // 16-bit packed slot pairs (two inner indices per word): the slot table the 16-wave kernels load
       d.pair_ok = d.mz + 32 < 65536;
       std::vector<uint32_t> off16(std::max<size_t>(rows_total / 2, 1) * 64, 0);
       if (d.pair_ok)
@@ -205,19 +205,9 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
           for (int l = 0; l < 64; ++l) off16[r2 * 64 + l] = (off[(2 * r2) * 64 + l] & 0xFFFFu) | (off[(2 * r2 + 1) * 64 + l] << 16);
       CHK(dalloc(&d.f_off16, off16.size(), false));
       HIPCHK(hipMemcpy(d.f_off16, off16.data(), off16.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-      int nhi = 0;
-      while (nhi < d.f_npairs && (int)pE[nhi] > 40) ++nhi;
-      d.f_npairs_hi40 = std::min(d.f_npairs, (nhi + 15) / 16 * 16);
-      if (d.f_npairs_hi40 % 8) d.f_npairs_hi40 = 0;
     }
-    // leading pairs with more than 32 slots form 8-wave blocks (padded to a multiple of 16 pairs so the
-    // two launches tile the pair list); 8-pair blocks whose fullest pair exceeds kFastMaxSlots are left
-    // to the generic kernel
+    // 8-wave kernel: blocks whose fullest pair exceeds kFastMaxSlots are left to the generic kernel
     {
-      int nhi = 0;
-      while (nhi < d.f_npairs && (int)pE[nhi] > 32) ++nhi;
-      d.f_npairs_hi = std::min(d.f_npairs, (nhi + 15) / 16 * 16);
-      if (d.f_npairs_hi % 8) d.f_npairs_hi = 0 * (nhi = 0);   // tiny problems: everything in the 16-wave launch
       std::vector<int> gen;
       // waves per block: 8 when there are enough units for >= 256 blocks, else 4 or 2 (multi-GPU shards, small problems)
       d.f_nw = d.f_npairs >= 8 * 256 ? 8 : (d.f_npairs >= 4 * 256 ? 4 : (d.f_npairs >= 2 * 64 ? 2 : 8));
@@ -336,19 +326,13 @@ static void enqueue_sweep(bnmtf_model* h, Dir& d, const Dir& other, SweepArgs& s
   if (h->use_fast && d.fast_ok && s.cond_k < 0 && s.mode != kSweepVB && sweep_fast_supported(d.KP, d.pw)) {
     FastArgs f;
     f.unit_map = d.f_unit_map; f.pair_E = d.f_pair_E; f.pair_base = d.f_pair_base; f.off = d.f_off;
-    f.npairs = d.f_npairs; f.npairs_hi = d.f_npairs_hi; f.mz = d.mz; f.pw = d.pw; f.nw = d.f_nw;
+    f.npairs = d.f_npairs; f.mz = d.mz; f.pw = d.pw; f.nw = d.f_nw;
     f.XoT = other.XT; f.ldT_o = other.ldT; f.XoT2 = other.XT2; f.ld2_o = other.ldT;
     f.stats = want_stats ? d.stats : nullptr;
-    { const char* e = getenv("BNMTF_SWEEP_DBG"); f.dbg = e ? atoi(e) : 0; }
     SweepArgs s2 = s;
     s2.acc = nullptr;
     f.off16 = d.pair_ok ? d.f_off16 : nullptr;
-    const char* kern = getenv("BNMTF_SWEEP_KERNEL");           // "fast" (default) | "pair" (two columns per barrier; same speed at 8 waves, kept for experiments)
-    if (d.pair_ok && kern && !strcmp(kern, "pair")) {
-      const bool nw16 = getenv("BNMTF_PAIR_NW8") == nullptr && d.f_npairs_hi40 < d.f_npairs;
-      if (nw16) f.npairs_hi = d.f_npairs_hi40;
-      launch_sweep_pair(s2, f, nw16, h->stream);
-    } else if (d.use_wide) launch_sweep_wide(s2, f, h->stream);
+    if (d.use_wide) launch_sweep_wide(s2, f, h->stream);
     else launch_sweep_fast(s2, f, h->stream);
     h->last_sweep_fast = true;
     if (d.f_gen_count == 0) return;

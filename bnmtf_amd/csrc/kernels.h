@@ -78,14 +78,12 @@ struct FastArgs {
   const uint32_t* pair_E;      // [npairs] slots of the pair (max of its two units)
   const uint32_t* pair_base;   // [npairs] first slot row of the pair
   const uint32_t* off;         // [(base+s)*64 + lane] inner index j (j mod 32 == lane mod 32) or mz + lane%32
-  const uint32_t* off16;       // [(base/2+h)*64 + lane] slots 2h (low 16 bits) and 2h+1 (high) packed, for the pair-step kernel
+  const uint32_t* off16;       // [(base/2+h)*64 + lane] slots 2h (low 16 bits) and 2h+1 (high) packed (16-wave kernels), or null
   int nw;                      // waves per block of the fast sweep (2, 4 or 8)
   int npairs;                  // pairs in descending slot-count order
-  int npairs_hi;               // leading pairs with more than 32 slots (padded to a multiple of 16): 8-wave blocks; the rest 16-wave blocks
   int mz, pw;                  // inner extent rounded up to 32 (sentinel zero words at mz..mz+31); panel floats pw = round_up(mz+32, 256)
   const float* XoT; int ldT_o;   // other factor transposed [KP][ldT_o]
   const float* XoT2; int ld2_o;  // other factor, column pairs interleaved [KP/2][ld2_o][2]
-  int dbg;                     // timing experiments only (BNMTF_SWEEP_DBG): 1 no restaging, 2 no slot loops, 4 no sampler
   double* stats;               // [blocks][4] partial (sum P.X', sum_miss q, sum_miss q^2) or null
   // VB sweep (kernel_sweep_vb.hip)
   const float* XoS;            // other factor's (E, S2) pair panels [KP][ld2_o][2]
@@ -103,8 +101,6 @@ bool sweep_vb_supported(int KP, int pw);
 void launch_sweep_vb(const SweepArgs& a, const FastArgs& f, hipStream_t st);
 void launch_vb_pieces(int n, int n0, int KP, int K, const float* mu, const float* tauq, const float* ex, const float* var,
                       const float* lambda, const float* asq, const float* vsq, double* out, hipStream_t st);
-// pair-step kernel (kernel_sweep_pair.hip); f.npairs_hi = leading pairs with more than 40 slots when nw16
-void launch_sweep_pair(const SweepArgs& a, const FastArgs& f, bool nw16, hipStream_t st);
 
 // relayout + Gram after a sweep / state upload: X -> XT, XT2, partial Gram slabs; then the reduction
 struct PostArgs {

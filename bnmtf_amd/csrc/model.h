@@ -54,7 +54,6 @@ struct Dir {
   int* f_unit_map = nullptr; uint32_t* f_pair_E = nullptr; uint32_t* f_pair_base = nullptr; uint32_t* f_off = nullptr;
   int f_npairs = 0, f_emax = 0, mz = 0; size_t f_slots = 0;
   int f_nw = 8;                          // waves per fast-sweep block
-  int f_npairs_hi = 0, f_npairs_hi40 = 0;   // leading pairs with more than 32 / 40 slots (padded to 16)
   uint32_t* f_off16 = nullptr; bool pair_ok = false;
   int pw = 0;                                     // LDS panel floats = round_up(mz + 32, 256)
   int* f_gen_units = nullptr; int f_gen_count = 0;

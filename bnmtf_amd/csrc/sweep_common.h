@@ -15,14 +15,7 @@ __device__ __forceinline__ float dpp_xor_row_sum(float v) {   // all-reduce insi
 }
 __device__ __forceinline__ float half_sum(float v) {          // all-reduce inside each 32-lane half
   v = dpp_xor_row_sum(v);
-#ifdef BNMTF_USE_PERMLANE16
-  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-  const unsigned b = __builtin_bit_cast(unsigned, v);
-  const u32x2 r = __builtin_amdgcn_permlane16_swap(b, b, false, false);   // (row0,row0,row2,row2) , (row1,row1,row3,row3)
-  return __builtin_bit_cast(float, r.x) + __builtin_bit_cast(float, r.y);
-#else
   return v + __shfl_xor(v, 16, 64);
-#endif
 }
 // Sum over each 32-lane half, valid in the UPPER 16 lanes of the half only (lanes 16-31 and 48-63): four DPP steps
 // inside the rows, then row_bcast:15 adds row 0's total into row 1 (and row 2's into row 3).  No LDS round trip.
