@@ -73,25 +73,13 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
   }
 }
 
-// 32 entries per block, 32 partial-slab strides per entry (thread = entry e + 32*g), tree-summed in LDS:
-// KP*KP/32 blocks of 1024 threads, every slab read is a coalesced 256 B row segment, <= nblk/32 serial loads.
+// 32 entries per block, 32 partial-slab strides per entry (thread = entry e + 32*g), summed through LDS in a fixed order:
+// KP*KP/32 blocks of 1024 threads (+ one for the column sums), every slab read is a coalesced 256 B row segment.
 __global__ __launch_bounds__(1024) void gram_reduce_kernel(PostArgs a, int nblk) {
   __shared__ double red[1024];
   const int KP = a.KP;
-  const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int t = blockIdx.x * 32 + e;
-  double s = 0.0;
-  for (int b = g; b < nblk; b += 32) s += a.Cpart[(size_t)b * KP * KP + t];
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int w = 16; w >= 1; w >>= 1) {
-    if (g < w) red[threadIdx.x] += red[threadIdx.x + 32 * w];
-    __syncthreads();
-  }
-  if (g == 0) { a.C64[t] = red[e]; a.C32[t] = (float)red[e]; }
-  if (blockIdx.x == 0) {
-    __syncthreads();
-    // column sums: 16 partial strides per column (KP <= 64 columns)
+  if ((int)blockIdx.x == KP * KP / 32) {
+    // the extra block: column sums, 16 partial strides per column (KP <= 64 columns), in parallel with the Gram blocks
     const int col = threadIdx.x >> 4, gq = threadIdx.x & 15;
     double v = 0.0, v2 = 0.0;
     if (col < KP)
@@ -99,13 +87,26 @@ __global__ __launch_bounds__(1024) void gram_reduce_kernel(PostArgs a, int nblk)
 #pragma unroll
     for (int m = 1; m < 16; m <<= 1) { v += __shfl_xor(v, m, 64); v2 += __shfl_xor(v2, m, 64); }
     if (col < KP && gq == 0) { a.colsum[col] = v; if (a.S2) a.colsum2[col] = v2; }
+    return;
+  }
+  const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int t = blockIdx.x * 32 + e;
+  double s = 0.0;
+  for (int b = g; b < nblk; b += 32) s += a.Cpart[(size_t)b * KP * KP + t];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (g == 0) {                          // one barrier, then 32 threads add the 32 strides in a fixed order
+    double tot = 0.0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) tot += red[e + 32 * j];
+    a.C64[t] = tot; a.C32[t] = (float)tot;
   }
 }
 
 void launch_post(const PostArgs& a, hipStream_t st) {
   const int nblk = post_blocks(a.rows);
   hipLaunchKernelGGL(post_kernel, dim3(nblk), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3(a.KP * a.KP / 32), dim3(1024), 0, st, a, nblk);
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3(a.KP * a.KP / 32 + 1), dim3(1024), 0, st, a, nblk);
 }
 
 }  // namespace bnmtf
