@@ -53,15 +53,17 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
 #ifdef BNMTF_PHASE_TIMING
   const unsigned long long t_start = tick(0.f);
 #endif
-  float x[NX], p[NX], lam[NX];
+  const float tau = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *a.tau)));
+  // x = the unit's row of the factor; p = the contraction slabs summed; pl = tau * p - lambda (constant during the sweep)
+  float x[NX], p[NX], pl[NX];
 #pragma unroll
   for (int nx = 0; nx < NX; ++nx) {
     const int kk = l5 + 32 * nx;
-    x[nx] = 0.f; p[nx] = 0.f; lam[nx] = 0.f;
+    x[nx] = 0.f; p[nx] = 0.f; pl[nx] = 0.f;
     if (valid) {
       x[nx] = a.Xself[gi * KP + kk];
       for (int s = 0; s < a.split; ++s) p[nx] += a.slabs[((size_t)s * a.n_pad + u) * KP + kk];
-      lam[nx] = a.lambda[(size_t)u * KP + kk];
+      pl[nx] = fmaf(tau, p[nx], -a.lambda[(size_t)u * KP + kk]);
     }
   }
   // slot addresses as LDS BYTE addresses inside panel buffer 0 (sentinel: a zero word on bank l5)
@@ -89,17 +91,18 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
   }
 
 #ifdef BNMTF_PHASE_TIMING
-  const unsigned long long t_pre = tick(__builtin_bit_cast(float, ca[kHoist - 1][0] ^ addr[EM - 1]) + x[0] + p[0] + lam[0]);
+  const unsigned long long t_pre = tick(__builtin_bit_cast(float, ca[kHoist - 1][0] ^ addr[EM - 1]) + x[0] + p[0] + pl[0]);
 #endif
   // ------------------------------------------------------------ pre-pass: q = U_i . V_j  (pair panels)
   {
     const int chunks2 = (2 * PW) / 256;
-    const size_t stride = (size_t)f.ld2_o * 2;
-    stage_panel<NW>(f.XoT2, pan, chunks2, wave, lane);
+    const uint32_t stride_b = (uint32_t)f.ld2_o * 8u;
+    const __amdgpu_buffer_rsrc_t rs2 = panel_rsrc(f.XoT2, (size_t)(KP / 2) * f.ld2_o * 8);
+    stage_panel_buf<NW>(rs2, 0u, pan, chunks2, wave, lane * 16);
     __syncthreads();
     const int npair = KP / 2;
     for (int kp = 0; kp < npair; ++kp) {
-      if (kp + 1 < npair) stage_panel<NW>(f.XoT2 + (size_t)(kp + 1) * stride, pan + (size_t)((kp + 1) & 1) * 2 * PW, chunks2, wave, lane);
+      if (kp + 1 < npair) stage_panel_buf<NW>(rs2, (uint32_t)(kp + 1) * stride_b, pan + (size_t)((kp + 1) & 1) * 2 * PW, chunks2, wave, lane * 16);
       // element j of a pair panel sits 8 j bytes in: 2 * addr - pan_b (+ the buffer's offset)
       const uint32_t boff = (uint32_t)((kp & 1) * 2 * PW) * 4u - pan_b;
       const int k0 = 2 * kp, k1 = 2 * kp + 1;
@@ -121,9 +124,9 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
 
   // ------------------------------------------------------------ the K sequential columns
   const int chunks1 = PW / 256;
-  stage_panel<NW>(f.XoT, pan, chunks1, wave, lane);
+  const __amdgpu_buffer_rsrc_t rs1 = panel_rsrc(f.XoT, (size_t)KP * f.ldT_o * 4);
+  stage_panel_buf<NW>(rs1, 0u, pan, chunks1, wave, lane * 16);
   __syncthreads();
-  const float tau = *a.tau;
   float dprev = 0.f;
 
   // One column.  BUF (which panel buffer holds column k) and HI (k >= 32: which register of x/p/lam/ca/cb
@@ -135,7 +138,7 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
   auto column = [&](auto buf_c, auto hi_c, int k) {
     constexpr int BUF = decltype(buf_c)::value;
     constexpr int HI = decltype(hi_c)::value;
-    if (k + 1 < K) stage_panel<NW>(f.XoT + (size_t)(k + 1) * f.ldT_o, pan + (size_t)(1 - BUF) * kPanelStride, chunks1, wave, lane);
+    if (k + 1 < K) stage_panel_buf<NW>(rs1, (uint32_t)(k + 1) * (uint32_t)f.ldT_o * 4u, pan + (size_t)(1 - BUF) * kPanelStride, chunks1, wave, lane * 16);
     const float xk = half_bcast(x[HI], k & 31, half);
     // (A) column k-1's update, from the registers that still hold v_{k-1}
     const f32x2 dp2 = {dprev, dprev};
@@ -150,29 +153,24 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
       vp2[h].x = *(lds_cf*)(uintptr_t)(addr[2 * h] + (uint32_t)(BUF * kPanelStride * 4));
       vp2[h].y = *(lds_cf*)(uintptr_t)(addr[2 * h + 1] + (uint32_t)(BUF * kPanelStride * 4));
     }
-    // (C) sum (q - x_k v) v  and  sum v^2
-    f32x2 corr2[2] = {{0.f, 0.f}, {0.f, 0.f}}, asq2[2] = {{0.f, 0.f}, {0.f, 0.f}};
-    const f32x2 nxk2 = {-xk, -xk};
+    // (C) sum q v  and  sum v^2 ;  sum (q - x_k v) v = sum q v - x_k sum v^2.  Same operation order as the 16-wave
+    // kernel (kernel_sweep_wide.hip), so a shard of a multi-GPU run draws exactly what the single-GPU run draws.
+    f32x2 qv2[2] = {{0.f, 0.f}, {0.f, 0.f}}, vv2[2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
     for (int h = 0; h < EH; ++h) {
-      const f32x2 t = pk_fma(nxk2, vp2[h], q2[h]);
-      corr2[h & 1] = pk_fma(t, vp2[h], corr2[h & 1]);
-      asq2[h & 1] = pk_fma(vp2[h], vp2[h], asq2[h & 1]);
+      qv2[h & 1] = pk_fma(q2[h], vp2[h], qv2[h & 1]);
+      vv2[h & 1] = pk_fma(vp2[h], vp2[h], vv2[h & 1]);
     }
-    float corr_t = (corr2[0].x + corr2[0].y) + (corr2[1].x + corr2[1].y);
-    float asq_t = (asq2[0].x + asq2[0].y) + (asq2[1].x + asq2[1].y);
+    float asq_t = (vv2[0].x + vv2[0].y) + (vv2[1].x + vv2[1].y);
+    float corr_t = fmaf(-xk, asq_t, (qv2[0].x + qv2[0].y) + (qv2[1].x + qv2[1].y));
 #pragma unroll
-    for (int nx = 0; nx < NX; ++nx) {
-      const int kk = l5 + 32 * nx;
-      if (kk != k) corr_t = fmaf(-x[nx], Cs[k * KP + kk], corr_t);
-    }
+    for (int nx = 0; nx < NX; ++nx) corr_t = fmaf(-x[nx], Cs[k * KP + l5 + 32 * nx], corr_t);   // all l: the l = k term is put back below
     TICK(1, corr_t + asq_t);
     corr_t = half_sum(corr_t);
     asq_t = half_sum(asq_t);
     const float ckk = Cs[k * KP + k];
-    const float num = half_bcast(p[HI], k & 31, half) + corr_t;
     const float tau_p = tau * (ckk - asq_t);
-    const float numer = fmaf(tau, num, -half_bcast(lam[HI], k & 31, half));
+    const float numer = fmaf(tau, fmaf(xk, ckk, corr_t), half_bcast(pl[HI], k & 31, half));
     float xnew = 0.f;
     TICK(2, numer + tau_p);
     if (MODE == kSweepDraw) {
@@ -186,19 +184,17 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
           if (!done && acc) { xnew = tn_guard(xc); done = true; }
         }
       }
-      if (__ballot(!done)) {                                   // rare: fresh candidates kHoist.. : 32 per round
-        TnParams tp;
-        tp.mu = tf.mu; tp.rt = 1.0f / tf.irt; tp.a = tf.a; tp.d = tf.d; tp.lam = tf.a + tf.d; tp.live = tf.live; tp.tail = tf.tail;
-        for (uint32_t round = 0; round < 128u && __ballot(!done); ++round) {
-          float xr;
-          const bool ar = tn_candidate(tp, (uint32_t)gi, (uint32_t)k, a.it, a.stream, (uint32_t)kHoist + round * 32u + (uint32_t)l5,
-                                       a.key0, a.key1, &xr);
-          const unsigned long long m = __ballot(ar);
-          const uint32_t mh = half ? (uint32_t)(m >> 32) : (uint32_t)m;
-          const int first = mh ? __ffs((int)mh) - 1 : 0;
-          const float xf = __shfl(xr, half * 32 + first, 64);
-          if (!done && mh) { xnew = tn_guard(xf); done = true; }
-        }
+      for (uint32_t round = 0; round < 128u && __ballot(!done); ++round) {   // rare: fresh candidates kHoist.. : 32 per round
+        uint32_t row = (uint32_t)gi;
+        asm volatile("" : "+v"(row));                            // opaque: nothing of this Philox call is hoisted out of the column loop
+        const U4 r = philox4x32_10(row, (uint32_t)k, a.it, a.stream + 16u * ((uint32_t)kHoist + round * 32u + (uint32_t)l5), a.key0, a.key1);
+        float xr;
+        const bool ar = tn_eval_fast(tf, r.x, r.y, &xr);
+        const unsigned long long m = __ballot(ar);
+        const uint32_t mh = half ? (uint32_t)(m >> 32) : (uint32_t)m;
+        const int first = mh ? __ffs((int)mh) - 1 : 0;
+        const float xf = __shfl(xr, half * 32 + first, 64);
+        if (!done && mh) { xnew = tn_guard(xf); done = true; }
       }
     } else {
       const float mu = numer / tau_p;

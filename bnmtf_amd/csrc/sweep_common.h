@@ -46,6 +46,7 @@ __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __bu
 // reciprocal-based parameters (v_rcp / v_rsq, ~1 ulp): the sampler needs no correctly rounded division
 struct TnFast { float mu, irt, a, d, ilam; bool live, tail; };
 __device__ __forceinline__ TnFast tn_fast_params(float numer, float tau_p) {
+#pragma clang fp contract(off)      // explicit fmaf only: every kernel that inlines this rounds identically (same chain on 1 and N GPUs)
   TnFast p;
   p.live = tau_p > 0.0f;
   const float tp = p.live ? tau_p : 1.0f;
@@ -59,6 +60,7 @@ __device__ __forceinline__ TnFast tn_fast_params(float numer, float tau_p) {
   return p;
 }
 __device__ __forceinline__ bool tn_eval_fast(const TnFast& p, uint32_t r0, uint32_t r1, float* x) {
+#pragma clang fp contract(off)
   const float u1 = u24(r0), u2 = u24(r1);
   const float nl = -0.69314718f * __builtin_amdgcn_logf(u1);            // v_log_f32 is log2
   const float e = nl * p.ilam;
