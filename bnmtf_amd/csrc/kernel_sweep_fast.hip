@@ -166,8 +166,6 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
 #pragma unroll
     for (int nx = 0; nx < NX; ++nx) corr_t = fmaf(-x[nx], Cs[k * KP + l5 + 32 * nx], corr_t);   // all l: the l = k term is put back below
     TICK(1, corr_t + asq_t);
-    TnPre pre0 = TnPre{0.f, 0.f, 0.f};    // candidate 0's log / sqrt / cos: no parameters needed, overlaps the reductions
-    if (MODE == kSweepDraw) pre0 = tn_pre(half_bcast_u(ca[0][HI], k & 31, half), half_bcast_u(cb[0][HI], k & 31, half));
     corr_t = half_sum(corr_t);
     asq_t = half_sum(asq_t);
     const float ckk = Cs[k * KP + k];
@@ -182,8 +180,7 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
       for (int c = 0; c < kHoist; ++c) {
         if (c == 0 || __ballot(!done)) {                      // wave-uniform: later candidates only when someone still needs one
           float xc;
-          const bool acc = c == 0 ? tn_post(tf, pre0, &xc)
-                                  : tn_eval_fast(tf, half_bcast_u(ca[c][HI], k & 31, half), half_bcast_u(cb[c][HI], k & 31, half), &xc);
+          const bool acc = tn_eval_fast(tf, half_bcast_u(ca[c][HI], k & 31, half), half_bcast_u(cb[c][HI], k & 31, half), &xc);
           if (!done && acc) { xnew = tn_guard(xc); done = true; }
         }
       }

@@ -186,7 +186,6 @@ __device__ __forceinline__ void sweep_wide_body(const SweepArgs& a, const FastAr
     TICK(1, corr_t + asq_t);
     u32x2 cw = {0u, 0u};
     if (MODE == kSweepDraw) cw = *(lds_cu2*)(uintptr_t)(mytab_b + (uint32_t)(k * NC * 8));
-    TnPre pre = tn_pre(cw.x, cw.y);      // log / sqrt / cos of the uniforms: no parameters needed, overlaps the reductions
     corr_t = half_sum_upper(corr_t);     // from here on the unit's scalars are right in lanes 16-31 of its half only
     asq_t = half_sum_upper(asq_t);
     const float ckk = Cs[k * KP + k];
@@ -207,7 +206,7 @@ __device__ __forceinline__ void sweep_wide_body(const SweepArgs& a, const FastAr
       float xs0 = 0.f, xs1 = 0.f;
       for (uint32_t cbase = 0;;) {
         float xc;
-        const bool acc = tn_post(tf, pre, &xc);
+        const bool acc = tn_eval_fast(tf, cw.x, cw.y, &xc);
         xc = tn_guard(xc);
         const unsigned long long m = __ballot(acc) & kCandMask;
         const uint32_t m0 = (uint32_t)m, m1 = (uint32_t)(m >> 32);
@@ -220,7 +219,7 @@ __device__ __forceinline__ void sweep_wide_body(const SweepArgs& a, const FastAr
         uint32_t row = gi;
         asm volatile("" : "+v"(row));                            // opaque: nothing of this Philox call is hoisted out of the column loop
         const U4 r = philox4x32_10(row, (uint32_t)k, a.it, a.stream + 16u * (cbase + (uint32_t)(l5 & (NC - 1))), a.key0, a.key1);
-        pre = tn_pre(r.x, r.y);
+        cw = u32x2{r.x, r.y};
       }
       xnew = half ? xs1 : xs0;
     } else {

@@ -59,30 +59,17 @@ __device__ __forceinline__ TnFast tn_fast_params(float numer, float tau_p) {
   p.tail = p.a >= kTnA0;
   return p;
 }
-// A candidate in two halves: what depends on the random words only (issued early, in the shadow of the reductions that
-// produce the parameters) and what needs the parameters.
-struct TnPre { float nl, z, u2; };
-__device__ __forceinline__ TnPre tn_pre(uint32_t r0, uint32_t r1) {
-#pragma clang fp contract(off)
-  TnPre q;
-  const float u1 = u24(r0);
-  q.u2 = u24(r1);
-  q.nl = -0.69314718f * __builtin_amdgcn_logf(u1);                        // v_log_f32 is log2
-  q.z = __builtin_amdgcn_sqrtf(2.0f * q.nl) * __builtin_amdgcn_cosf(q.u2);   // v_cos_f32 takes revolutions
-  return q;
-}
-__device__ __forceinline__ bool tn_post(const TnFast& p, const TnPre& q, float* x) {
-#pragma clang fp contract(off)
-  const float e = q.nl * p.ilam;
-  const float t = e - p.d;
-  const bool acc_t = q.u2 <= __builtin_amdgcn_exp2f(-0.72134752f * t * t);  // exp(-t^2/2) via v_exp_f32 (2^x)
-  const bool acc_n = q.z >= p.a;
-  *x = p.tail ? e * p.irt : fmaf(q.z, p.irt, p.mu);
-  return p.tail ? acc_t : acc_n;
-}
 __device__ __forceinline__ bool tn_eval_fast(const TnFast& p, uint32_t r0, uint32_t r1, float* x) {
-  const TnPre q = tn_pre(r0, r1);
-  return tn_post(p, q, x);
+#pragma clang fp contract(off)
+  const float u1 = u24(r0), u2 = u24(r1);
+  const float nl = -0.69314718f * __builtin_amdgcn_logf(u1);            // v_log_f32 is log2
+  const float e = nl * p.ilam;
+  const float t = e - p.d;
+  const bool acc_t = u2 <= __builtin_amdgcn_exp2f(-0.72134752f * t * t);   // exp(-t^2/2) via v_exp_f32 (2^x)
+  const float z = __builtin_amdgcn_sqrtf(2.0f * nl) * __builtin_amdgcn_cosf(u2);   // v_cos_f32 takes revolutions
+  const bool acc_n = z >= p.a;
+  *x = p.tail ? e * p.irt : fmaf(z, p.irt, p.mu);
+  return p.tail ? acc_t : acc_n;
 }
 
 // LDS-direct staging of one panel: `chunks` pieces of 1 KiB (64 lanes x 16 B), wave w takes
