@@ -1,20 +1,21 @@
 // K1/K2: the masked contractions  P = R~ . V  and  Pv = R~^T . U  ("the U^T.R step").
 //
-// Both are the same skinny product  out[n][KP] = sum_r big[r][n] * X[r][KP]  with
-// n, r ~ 8192 and KP = 32/64: every element of `big` (the 256 MiB operand) is used
-// by exactly one wave, so it is streamed HBM -> VGPR directly in MFMA B-fragment
-// shape (no LDS round trip; see cdna_hip_programming.md "GEMV / operand streamed once"),
-// while the small factor X is the A operand.
+// Both are the same skinny product  out[n][KP] = sum_r big[r][n] * X[r][KP]  with n, r ~ 8192 and KP = 32/64: every
+// element of `big` (the 256 MiB operand) is used by exactly one wave, so it is streamed HBM -> VGPR directly in MFMA
+// B-fragment shape (no LDS round trip; see cdna_hip_programming.md "GEMV / operand streamed once"), while the small
+// factor X is the A operand.  A wave owns 128 output columns x KP and a private slice of the inner dimension; the four
+// waves of a block reduce through LDS and the block writes one partial slab, which the sweep kernel sums in its prologue.
 //
-// v_mfma_f32_32x32x2_f32:  D[i][j] += sum_{k<2} A[i][k] B[k][j]
-//   A: lane l holds A[i = l&31][k = l>>5]   -> X[r + (l>>5)][mt*32 + (l&31)]      (coalesced 128 B)
-//   B: lane l holds B[k = l>>5][j = l&31]   -> big[r + (l>>5)][col0 + 4*(l&31) + t] (one dwordx4 = 4 tiles)
-//   D: reg g, lane l -> i = (g&3) + 8*(g>>2) + 4*(l>>5), j = l&31
-// One dwordx4 per lane per r-pair gives the B fragments of four 32-column tiles whose
-// columns interleave with stride 4, so each wave-instruction reads two fully used
-// 512 B row segments.  A wave owns 128 output columns x KP and a private slice of the
-// inner dimension; the four waves of a block reduce through LDS and the block writes
-// one partial slab, which the sweep kernel sums in its prologue.
+// Two kernels:
+//  * gemm_bf16x3_kernel (default, further down): fp32-exact products on the bf16 matrix cores from three-term operand
+//    splits -- the contraction becomes a stream of R~ from HBM;
+//  * gemm_kernel (BNMTF_GEMM=f32, kept for comparison): v_mfma_f32_32x32x2_f32, bound by the f32 matrix-core rate:
+//      D[i][j] += sum_{k<2} A[i][k] B[k][j]
+//      A: lane l holds A[i = l&31][k = l>>5]   -> X[r + (l>>5)][mt*32 + (l&31)]      (coalesced 128 B)
+//      B: lane l holds B[k = l>>5][j = l&31]   -> big[r + (l>>5)][col0 + 4*(l&31) + t] (one dwordx4 = 4 tiles)
+//      D: reg g, lane l -> i = (g&3) + 8*(g>>2) + 4*(l>>5), j = l&31
+//    One dwordx4 per lane per r-pair gives the B fragments of four 32-column tiles whose columns interleave with
+//    stride 4, so each wave-instruction reads two fully used 512 B row segments.
 #include <cstdlib>
 #include <cstring>
 

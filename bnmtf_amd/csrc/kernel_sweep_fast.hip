@@ -1,22 +1,20 @@
-// K3 fast path: the half sweep of kernel_sweep.hip with everything that is touched
-// K times per row kept on chip.
+// K3, 2/4/8-wave blocks: the half sweep of kernel_sweep.hip with everything that is touched K times per row kept on
+// chip.  This is the shape for shards of a multi-GPU run, small problems and masks with more than 32 slots per lane (up
+// to 56: two waves per SIMD, 256 VGPRs); large single-GPU problems take the 16-wave kernel (kernel_sweep_wide.hip), whose
+// operation order this kernel follows so that the two draw exactly the same chain.
 //
-//  * a unit (row of the factor being updated) owns one 32-lane half wave; its missing
-//    entries sit in "slots": slot s of lane l holds an entry whose inner index j has
-//    j mod 32 == l, so a ds_read_b32 gather of the other factor's column k from LDS is
-//    bank-conflict free by construction (each half wave hits 32 distinct banks;
-//    sentinel slots read a per-lane zero word).  The price is padding to the fullest
-//    residue class (max_r cnt_r slots instead of cnt/32).
-//  * q_ij (= U_i . V_j on the missing entries), the slot addresses and the previous
-//    column's gathered values live in registers (EM slots per lane, template).
-//  * the other factor's column k ("panel", m floats) is staged in LDS once per block and
-//    k, double buffered; 16 units (8 waves) share it.  C = V^T V sits in LDS too.
-//  * q is rebuilt each sweep by a pre-pass over pair panels (ds_read_b64: two columns per
-//    gather, same conflict-free slots), which is what makes the kernel independent of
-//    how the other direction ordered its entries (and of the GPU count).
-//  * the K draws per unit are sequential, so the Philox work is hoisted: lane l
-//    pre-computes the first two candidates of columns l and l+32; step k broadcasts them.
-//    Only a double rejection (rare) falls back to 32 fresh candidates per round.
+//  * a unit (row of the factor being updated) owns one 32-lane half wave; its missing entries sit in "slots": slot s of
+//    lane l holds an entry whose inner index j has j mod 32 == l (bank-conflict-free ds_read_b32 gathers; the host parks
+//    the entries of over-full residue classes in free lanes, api.hip build_dir); sentinel slots read a per-lane zero word.
+//  * q_ij (= U_i . V_j on the missing entries), the slot byte addresses and the previous column's gathered values live
+//    in registers (EM slots per lane, template), two slots per register pair for packed-f32 FMAs.
+//  * the other factor's column k ("panel", m floats) is staged in LDS once per block and k by LDS-DMA through a buffer
+//    descriptor, double buffered at a compile-time stride (a gather is one ds_read_b32 offset:imm); C = V^T V sits in LDS.
+//  * q is rebuilt each sweep by a pre-pass over pair panels (ds_read_b64: two columns per gather, same slots), which is
+//    what makes the kernel independent of how the other direction ordered its entries (and of the GPU count).
+//  * the K draws per unit are sequential, so the Philox work is hoisted: lane l pre-computes the first four candidates
+//    of columns l and l+32; step k broadcasts them.  Four rejections in a row (rare) fall back to 32 fresh candidates
+//    per round, evaluated with the same one-instruction transcendental forms.
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
