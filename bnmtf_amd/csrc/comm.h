@@ -1,4 +1,5 @@
-// RCCL exchange for the row/column-sharded sweep (one process per GPU).
+// RCCL exchange for the row/column-sharded sweep (one process per GPU), plus an in-process transport for tests (a
+// communicator id starting with "BNMTFLOC": ranks are host threads of one process, see comm.hip).
 // librccl is resolved at run time (dlopen) so that the single-GPU path has no
 // link-time dependency on it and a process that already loaded RCCL (e.g. through
 // torch.distributed in bench.py) shares that copy.

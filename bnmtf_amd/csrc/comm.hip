@@ -3,7 +3,14 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
 
 #include "model.h"
 
@@ -63,8 +70,33 @@ int load_api() {
     }                                                                              \
   } while (0)
 
+// In-process transport (test hook): a communicator id that starts with "BNMTFLOC" joins the ranks of ONE process (one
+// host thread per rank, any devices) through a rendezvous in host memory and device-to-device copies.  It lets a single
+// GPU exercise everything of the sharded path except RCCL itself: shard ranges, the kernels' row offsets, the placement
+// of the gathered blocks, the order of the reduced sums.
+struct LocalGroup {
+  std::mutex m;
+  std::condition_variable cv;
+  int world = 0, arrived = 0;
+  uint64_t generation = 0;
+  std::vector<void*> ptrs;
+  std::vector<double> vals;
+  bool barrier() {                               // false on timeout (a peer died): the caller reports an error instead of hanging
+    std::unique_lock<std::mutex> lk(m);
+    const uint64_t gen = generation;
+    if (++arrived == world) { arrived = 0; ++generation; cv.notify_all(); return true; }
+    return cv.wait_for(lk, std::chrono::seconds(120), [&] { return generation != gen; });
+  }
+};
+namespace {
+std::mutex g_groups_m;
+std::map<std::string, std::shared_ptr<LocalGroup>> g_groups;
+}
+
 struct Comm {
   ncclComm_t comm = nullptr;
+  std::shared_ptr<LocalGroup> local;
+  std::string local_key;
   int rank = 0, world = 1;
 };
 
@@ -78,6 +110,18 @@ int comm_unique_id(uint8_t out[128]) {
 }
 
 int comm_create(Comm** out, const uint8_t idb[128], int rank, int world, hipStream_t) {
+  if (!memcmp(idb, "BNMTFLOC", 8)) {
+    Comm* c = new Comm();
+    c->rank = rank; c->world = world;
+    c->local_key.assign(reinterpret_cast<const char*>(idb), 128);
+    std::lock_guard<std::mutex> lk(g_groups_m);
+    auto& g = g_groups[c->local_key];
+    if (!g) { g = std::make_shared<LocalGroup>(); g->world = world; g->ptrs.assign(world, nullptr); }
+    if (g->world != world) { set_error("local communicator: world size mismatch"); delete c; return BNMTF_ECOMM; }
+    c->local = g;
+    *out = c;
+    return BNMTF_OK;
+  }
   CHK(load_api());
   ncclUniqueId id;
   memcpy(&id, idb, 128);
@@ -95,12 +139,34 @@ int comm_create(Comm** out, const uint8_t idb[128], int rank, int world, hipStre
 
 void comm_destroy(Comm* c) {
   if (!c) return;
+  if (c->local) {
+    std::lock_guard<std::mutex> lk(g_groups_m);
+    c->local.reset();
+    auto it = g_groups.find(c->local_key);
+    if (it != g_groups.end() && it->second.use_count() == 1) g_groups.erase(it);
+    delete c;
+    return;
+  }
   if (c->comm) g_api.CommDestroy(c->comm);
   delete c;
 }
 
 int comm_allgather_factor(Comm* c, float* X, int KP, int nglob, int world, hipStream_t st) {
   auto first = [&](int r) { return (int)(((int64_t)nglob * r) / world); };
+  if (c->local) {
+    LocalGroup& g = *c->local;
+    HIPCHK(hipStreamSynchronize(st));                     // own block written
+    g.ptrs[c->rank] = X;
+    if (!g.barrier()) { set_error("local communicator: peer did not arrive"); return BNMTF_ECOMM; }
+    for (int r = 0; r < world; ++r) {
+      if (r == c->rank) continue;
+      const size_t off = (size_t)first(r) * KP, cnt = (size_t)(first(r + 1) - first(r)) * KP;
+      HIPCHK(hipMemcpyAsync(X + off, static_cast<const float*>(g.ptrs[r]) + off, cnt * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    if (!g.barrier()) { set_error("local communicator: peer did not arrive"); return BNMTF_ECOMM; }   // peers have copied my block
+    return BNMTF_OK;
+  }
   if (nglob % world == 0) {
     const size_t cnt = (size_t)(nglob / world) * KP;
     NCHK(g_api.AllGather(X + (size_t)first(c->rank) * KP, X, cnt, ncclFloat, c->comm, st));
@@ -117,6 +183,24 @@ int comm_allgather_factor(Comm* c, float* X, int KP, int nglob, int world, hipSt
 }
 
 int comm_allreduce_sum(Comm* c, double* buf, int count, hipStream_t st) {
+  if (c->local) {
+    LocalGroup& g = *c->local;
+    {
+      std::lock_guard<std::mutex> lk(g.m);
+      if (g.vals.size() < (size_t)c->world * count) g.vals.assign((size_t)c->world * count, 0.0);
+    }
+    if (!g.barrier()) { set_error("local communicator: peer did not arrive"); return BNMTF_ECOMM; }
+    HIPCHK(hipMemcpyAsync(g.vals.data() + (size_t)c->rank * count, buf, count * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (!g.barrier()) { set_error("local communicator: peer did not arrive"); return BNMTF_ECOMM; }
+    std::vector<double> sum(count, 0.0);
+    for (int r = 0; r < c->world; ++r)                     // rank order: every rank forms the same sum
+      for (int t = 0; t < count; ++t) sum[t] += g.vals[(size_t)r * count + t];
+    HIPCHK(hipMemcpyAsync(buf, sum.data(), count * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (!g.barrier()) { set_error("local communicator: peer did not arrive"); return BNMTF_ECOMM; }
+    return BNMTF_OK;
+  }
   NCHK(g_api.AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, c->comm, st));
   return BNMTF_OK;
 }

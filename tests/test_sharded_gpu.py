@@ -1,0 +1,62 @@
+"""The row/column-sharded path on ONE GPU: two (or three) ranks of one process, one host thread each, joined by the
+library's in-process transport (communicator id "BNMTFLOC...": device-to-device copies and a host rendezvous in place of
+RCCL's all-gather / all-reduce).  Everything else is the multi-GPU code path as it runs on a node: shard ranges, the
+kernels' row offsets, the placement of the gathered factor blocks, the reduction of the three SSE sums, the Philox
+counters keyed by global indices.  Expected: every rank ends with the same replicated chain, and it is the chain of the
+single-rank run (sweeps are bit-identical; tau can differ in its last fp64 bits through the order of the partial sums)."""
+import threading
+
+import numpy as np
+import pytest
+
+from bnmtf_amd import bnmf_gibbs_optimised
+from bnmtf_amd.synthetic import generate_bnmf
+
+pytestmark = pytest.mark.gpu
+
+PRI = dict(alpha=1., beta=1., lambdaU=0.1, lambdaV=0.1)
+
+
+def _run_ranks(R, M, K, U0, V0, tau0, world, iters, update, token):
+    cid = (b"BNMTFLOC" + token).ljust(128, b"\0")
+    out, err = [None] * world, [None] * world
+
+    def work(rank):
+        try:
+            b = bnmf_gibbs_optimised(R, M, K, PRI, verbose=False, seed=7, rank=rank, world=world, comm_id=cid)
+            b.U, b.V, b.tau = U0.copy(), V0.copy(), tau0
+            b.run(iters, update=update)
+            out[rank] = (b.all_U.copy(), b.all_V.copy(), b.all_tau.copy(), np.array(b.all_performances["MSE"]))
+            b.close()
+        except Exception as e:      # noqa: BLE001 -- reported by the main thread
+            err[rank] = e
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in ts), "a rank hung"
+    assert all(e is None for e in err), err
+    return out
+
+
+@pytest.mark.parametrize("I,J,K,world", [(640, 512, 24, 2), (515, 389, 40, 3)])
+def test_sharded_run_equals_single_rank_run(I, J, K, world):
+    R, M, _, _ = generate_bnmf(I, J, K, 0.12, seed_data=5, seed_mask=6)
+    rs = np.random.RandomState(3)
+    U0 = rs.exponential(1.0, (I, K)); V0 = rs.exponential(1.0, (J, K)); tau0 = 0.7
+    for update in ("mode", "draw"):
+        single = bnmf_gibbs_optimised(R, M, K, PRI, verbose=False, seed=7)      # fresh handle: iteration counter (Philox word) 0
+        single.U, single.V, single.tau = U0.copy(), V0.copy(), tau0
+        single.run(5, update=update)
+        ranks = _run_ranks(R, M, K, U0, V0, tau0, world, 5, update, ("%d%s" % (world, update)).encode())
+        for r in range(1, world):                      # replicated state: identical on every rank
+            for a, b in zip(ranks[0], ranks[r]):
+                assert np.array_equal(a, b)
+        sU, sV, stau, smse = single.all_U, single.all_V, single.all_tau, np.array(single.all_performances["MSE"])
+        # first sweep: same operation order in every kernel -> bit-identical rows and columns
+        assert np.array_equal(ranks[0][0][0], sU[0]) and np.array_equal(ranks[0][1][0], sV[0])
+        np.testing.assert_allclose(ranks[0][2], stau, rtol=1e-9)
+        np.testing.assert_allclose(ranks[0][3], smse, rtol=1e-6)
+        assert np.abs(ranks[0][0][-1] - sU[-1]).max() <= 1e-4 * np.abs(sU[-1]).max()
