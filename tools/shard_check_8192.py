@@ -1,0 +1,31 @@
+"""One-off check at the headline shape: 8 ranks of one process on one GPU (in-process transport) against the single-rank run."""
+import sys, os, threading, time, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bnmtf_amd import bnmf_gibbs_optimised
+from bnmtf_amd.synthetic import generate_bnmf
+PRI = dict(alpha=1., beta=1., lambdaU=0.1, lambdaV=0.1)
+I = J = 8192; K = 64; world = int(sys.argv[1]) if len(sys.argv) > 1 else 8; iters = 6
+R, M, _, _ = generate_bnmf(I, J, K, 0.1, tau=1.0, seed_data=0, seed_mask=1)
+rs = np.random.RandomState(3)
+U0 = rs.exponential(10.0, (I, K)); V0 = rs.exponential(10.0, (J, K)); tau0 = 1.0
+s = bnmf_gibbs_optimised(R, M, K, PRI, verbose=False, seed=7)
+s.U, s.V, s.tau = U0.copy(), V0.copy(), tau0
+s.run(iters)
+sm = np.array(s.all_performances["MSE"]); sU = s.all_U[-1].copy(); s.close()
+cid = b"BNMTFLOC8192".ljust(128, b"\0")
+out = [None] * world; err = [None] * world
+def work(rank):
+    try:
+        b = bnmf_gibbs_optimised(R, M, K, PRI, verbose=False, seed=7, rank=rank, world=world, comm_id=cid)
+        b.U, b.V, b.tau = U0.copy(), V0.copy(), tau0
+        t0 = time.time(); b.run(iters, store_samples=(rank == 0)); dt = time.time() - t0
+        out[rank] = (np.array(b.all_performances["MSE"]), b.U.copy(), dt)
+        b.close()
+    except Exception as e:
+        err[rank] = e
+ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+[t.start() for t in ts]; [t.join() for t in ts]
+print("errors", [e for e in err if e is not None])
+print("single MSE", sm)
+print("rank0  MSE", out[0][0])
+print("max rel MSE diff", np.abs(out[0][0] - sm).max() / sm.max(), " final U max diff", np.abs(out[0][1] - sU).max(), "ranks agree", all(np.array_equal(out[0][1], out[r][1]) for r in range(1, world)))
