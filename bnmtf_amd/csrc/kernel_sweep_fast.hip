@@ -25,7 +25,7 @@ namespace bnmtf {
 
 constexpr int kPanelStride = 9216;              // floats between the two single-column panel buffers (>= pw)
 
-template <int EM, int NX, int MODE, int NW>
+template <int EM, int NX, int MODE, int NW, int DW>
 __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastArgs& f, float* lds) {
   constexpr int KP = NX * 32;
   constexpr int EH = EM / 2;
@@ -39,6 +39,30 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l5 = lane & 31;
+  if (DW && wave == NW) {
+    // The staging wave of a small block (DW = 1: 2- or 4-wave blocks, i.e. few units per CU: shards of a multi-GPU run).
+    // It owns no units and issues every LDS-DMA piece of every panel; the unit waves never stall on VMEM issue (the
+    // texture path takes 1 KiB per ~16 cycles, and with one unit wave per SIMD nothing hides that stall).  Same barrier
+    // sequence as the unit waves.
+    const int chunks2 = (2 * PW) / 256, chunks1 = PW / 256;
+    const uint32_t stride_b = (uint32_t)f.ld2_o * 8u;
+    const __amdgpu_buffer_rsrc_t rs2 = panel_rsrc(f.XoT2, (size_t)(KP / 2) * f.ld2_o * 8);
+    const __amdgpu_buffer_rsrc_t rs1 = panel_rsrc(f.XoT, (size_t)KP * f.ldT_o * 4);
+    stage_panel_buf<1>(rs2, 0u, pan, chunks2, 0, lane * 16);
+    __syncthreads();
+    for (int kp = 0; kp < KP / 2; ++kp) {
+      if (kp + 1 < KP / 2) stage_panel_buf<1>(rs2, (uint32_t)(kp + 1) * stride_b, pan + (size_t)((kp + 1) & 1) * 2 * PW, chunks2, 0, lane * 16);
+      __syncthreads();
+    }
+    stage_panel_buf<1>(rs1, 0u, pan, chunks1, 0, lane * 16);
+    __syncthreads();
+    for (int k = 0; k < a.K; ++k) {
+      if (k + 1 < a.K) stage_panel_buf<1>(rs1, (uint32_t)(k + 1) * (uint32_t)f.ldT_o * 4u, pan + (size_t)((k + 1) & 1) * kPanelStride, chunks1, 0, lane * 16);
+      __syncthreads();
+    }
+    if (f.stats) __syncthreads();
+    return;
+  }
   const int pair = blockIdx.x * NW + wave;
   const bool wave_on = pair < f.npairs;
   const uint32_t base = wave_on ? f.pair_base[pair] : 0u;
@@ -60,7 +84,7 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
     x[nx] = 0.f; p[nx] = 0.f; pl[nx] = 0.f;
     if (valid) {
       x[nx] = a.Xself[gi * KP + kk];
-      for (int s = 0; s < a.split; ++s) p[nx] += a.slabs[((size_t)s * a.n_pad + u) * KP + kk];
+      p[nx] = slab_sum_ordered(a.slabs, a.split, (size_t)a.n_pad * KP, (size_t)u * KP + kk);
       pl[nx] = fmaf(tau, p[nx], -a.lambda[(size_t)u * KP + kk]);
     }
   }
@@ -96,11 +120,11 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
     const int chunks2 = (2 * PW) / 256;
     const uint32_t stride_b = (uint32_t)f.ld2_o * 8u;
     const __amdgpu_buffer_rsrc_t rs2 = panel_rsrc(f.XoT2, (size_t)(KP / 2) * f.ld2_o * 8);
-    stage_panel_buf<NW>(rs2, 0u, pan, chunks2, wave, lane * 16);
+    if (!DW) stage_panel_buf<NW>(rs2, 0u, pan, chunks2, wave, lane * 16);
     __syncthreads();
     const int npair = KP / 2;
     for (int kp = 0; kp < npair; ++kp) {
-      if (kp + 1 < npair) stage_panel_buf<NW>(rs2, (uint32_t)(kp + 1) * stride_b, pan + (size_t)((kp + 1) & 1) * 2 * PW, chunks2, wave, lane * 16);
+      if (!DW && kp + 1 < npair) stage_panel_buf<NW>(rs2, (uint32_t)(kp + 1) * stride_b, pan + (size_t)((kp + 1) & 1) * 2 * PW, chunks2, wave, lane * 16);
       // element j of a pair panel sits 8 j bytes in: 2 * addr - pan_b (+ the buffer's offset)
       const uint32_t boff = (uint32_t)((kp & 1) * 2 * PW) * 4u - pan_b;
       const int k0 = 2 * kp, k1 = 2 * kp + 1;
@@ -123,7 +147,7 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
   // ------------------------------------------------------------ the K sequential columns
   const int chunks1 = PW / 256;
   const __amdgpu_buffer_rsrc_t rs1 = panel_rsrc(f.XoT, (size_t)KP * f.ldT_o * 4);
-  stage_panel_buf<NW>(rs1, 0u, pan, chunks1, wave, lane * 16);
+  if (!DW) stage_panel_buf<NW>(rs1, 0u, pan, chunks1, wave, lane * 16);
   __syncthreads();
   float dprev = 0.f;
 
@@ -136,7 +160,7 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
   auto column = [&](auto buf_c, auto hi_c, int k) {
     constexpr int BUF = decltype(buf_c)::value;
     constexpr int HI = decltype(hi_c)::value;
-    if (k + 1 < K) stage_panel_buf<NW>(rs1, (uint32_t)(k + 1) * (uint32_t)f.ldT_o * 4u, pan + (size_t)(1 - BUF) * kPanelStride, chunks1, wave, lane * 16);
+    if (!DW && k + 1 < K) stage_panel_buf<NW>(rs1, (uint32_t)(k + 1) * (uint32_t)f.ldT_o * 4u, pan + (size_t)(1 - BUF) * kPanelStride, chunks1, wave, lane * 16);
     const float xk = half_bcast(x[HI], k & 31, half);
     // (A) column k-1's update, from the registers that still hold v_{k-1}
     const f32x2 dp2 = {dprev, dprev};
@@ -253,17 +277,17 @@ __device__ __forceinline__ void sweep_fast_body(const SweepArgs& a, const FastAr
 
 // One launch covers every block; a block's slot class (template EM) is the smallest class that
 // holds its fullest pair (units are sorted by slot count, so blocks are homogeneous).
-template <int NX, int MODE, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void sweep_fast_kernel(SweepArgs a, FastArgs f) {
+template <int NX, int MODE, int NW, int DW>
+__global__ __launch_bounds__((NW + DW) * 64, (DW ? 1 : 2)) void sweep_fast_kernel(SweepArgs a, FastArgs f) {
   extern __shared__ float lds[];
   const int e0 = (int)f.pair_E[blockIdx.x * NW];      // descending order: first pair of the block is its fullest
-  if (e0 <= 8) sweep_fast_body<8, NX, MODE, NW>(a, f, lds);
-  else if (e0 <= 16) sweep_fast_body<16, NX, MODE, NW>(a, f, lds);
-  else if (e0 <= 24) sweep_fast_body<24, NX, MODE, NW>(a, f, lds);
-  else if (e0 <= 32) sweep_fast_body<32, NX, MODE, NW>(a, f, lds);
-  else if (e0 <= 40) sweep_fast_body<40, NX, MODE, NW>(a, f, lds);
-  else if (e0 <= 48) sweep_fast_body<48, NX, MODE, NW>(a, f, lds);
-  else if (e0 <= kFastMaxSlots) sweep_fast_body<kFastMaxSlots, NX, MODE, NW>(a, f, lds);
+  if (e0 <= 8) sweep_fast_body<8, NX, MODE, NW, DW>(a, f, lds);
+  else if (e0 <= 16) sweep_fast_body<16, NX, MODE, NW, DW>(a, f, lds);
+  else if (e0 <= 24) sweep_fast_body<24, NX, MODE, NW, DW>(a, f, lds);
+  else if (e0 <= 32) sweep_fast_body<32, NX, MODE, NW, DW>(a, f, lds);
+  else if (e0 <= 40) sweep_fast_body<40, NX, MODE, NW, DW>(a, f, lds);
+  else if (e0 <= 48) sweep_fast_body<48, NX, MODE, NW, DW>(a, f, lds);
+  else if (e0 <= kFastMaxSlots) sweep_fast_body<kFastMaxSlots, NX, MODE, NW, DW>(a, f, lds);
   else if (f.stats && threadIdx.x < 3) f.stats[(size_t)blockIdx.x * 4 + threadIdx.x] = 0.0;   // generic kernel owns these units
 }
 
@@ -275,11 +299,11 @@ size_t sweep_fast_lds_bytes(int KP, int pw) {
 
 bool sweep_fast_supported(int KP, int pw) { return pw <= kPanelStride && sweep_fast_lds_bytes(KP, pw) <= 160 * 1024; }
 
-template <int NX, int MODE, int NW>
+template <int NX, int MODE, int NW, int DW>
 static void launch_inst(const SweepArgs& a, const FastArgs& f, int nblocks, size_t lds_bytes, hipStream_t st) {
   static bool once = false;
-  if (!once) { (void)hipFuncSetAttribute((const void*)sweep_fast_kernel<NX, MODE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
-  if (nblocks > 0) hipLaunchKernelGGL((sweep_fast_kernel<NX, MODE, NW>), dim3(nblocks), dim3(NW * 64), lds_bytes, st, a, f);
+  if (!once) { (void)hipFuncSetAttribute((const void*)sweep_fast_kernel<NX, MODE, NW, DW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+  if (nblocks > 0) hipLaunchKernelGGL((sweep_fast_kernel<NX, MODE, NW, DW>), dim3(nblocks), dim3((NW + DW) * 64), lds_bytes, st, a, f);
 }
 
 // Blocks of NW waves (2*NW units).  8 waves is the throughput shape; when a rank owns few units (row/column
@@ -288,11 +312,14 @@ void launch_sweep_fast(const SweepArgs& a, const FastArgs& f, hipStream_t st) {
   const size_t lds_bytes = sweep_fast_lds_bytes(a.KP, f.pw);
   const int nx = a.KP / 32;
   const int nw = f.nw;
+  static const bool dw = getenv("BNMTF_NO_STAGING_WAVE") == nullptr;    // small blocks get a staging wave (see sweep_fast_body)
 #define BNMTF_L(NXV, MODEV)                                                                       \
   do {                                                                                            \
-    if (nw == 2) launch_inst<NXV, MODEV, 2>(a, f, (f.npairs + 1) / 2, lds_bytes, st);             \
-    else if (nw == 4) launch_inst<NXV, MODEV, 4>(a, f, (f.npairs + 3) / 4, lds_bytes, st);        \
-    else launch_inst<NXV, MODEV, 8>(a, f, (f.npairs + 7) / 8, lds_bytes, st);                     \
+    if (nw == 2 && dw) launch_inst<NXV, MODEV, 2, 1>(a, f, (f.npairs + 1) / 2, lds_bytes, st);     \
+    else if (nw == 2) launch_inst<NXV, MODEV, 2, 0>(a, f, (f.npairs + 1) / 2, lds_bytes, st);      \
+    else if (nw == 4 && dw) launch_inst<NXV, MODEV, 4, 1>(a, f, (f.npairs + 3) / 4, lds_bytes, st); \
+    else if (nw == 4) launch_inst<NXV, MODEV, 4, 0>(a, f, (f.npairs + 3) / 4, lds_bytes, st);      \
+    else launch_inst<NXV, MODEV, 8, 0>(a, f, (f.npairs + 7) / 8, lds_bytes, st);                   \
   } while (0)
   if (a.mode == kSweepDraw) { if (nx == 1) BNMTF_L(1, kSweepDraw); else BNMTF_L(2, kSweepDraw); }
   else                      { if (nx == 1) BNMTF_L(1, kSweepMode); else BNMTF_L(2, kSweepMode); }

@@ -60,7 +60,7 @@ __device__ __forceinline__ void sweep_wide_body(const SweepArgs& a, const FastAr
   float x[NX], pl[NX];
   auto slab_sum = [&](int nx) {
     float s = 0.f;
-    if (valid) for (int sl = 0; sl < a.split; ++sl) s += a.slabs[((size_t)sl * a.n_pad + u) * KP + l5 + 32 * nx];
+    if (valid) s = slab_sum_ordered(a.slabs, a.split, (size_t)a.n_pad * KP, (size_t)u * KP + l5 + 32 * nx);
     return s;
   };
 #pragma unroll

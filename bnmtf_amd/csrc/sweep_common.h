@@ -111,6 +111,22 @@ __device__ __forceinline__ unsigned long long tick(float dep) {
 #define TICK(i, dep) __builtin_amdgcn_sched_barrier(0)
 #endif
 
+// Sum of the contraction's partial slabs for one (unit, column): P = sum_s slabs[s][u][kk], added in slab order (so every
+// kernel rounds alike), with the loads of eight slabs issued together -- a shard of a multi-GPU run has 32 or more slabs
+// and a load-wait-add loop serialises their L2 latency (measured: 19 us of a 100 us sweep).
+__device__ __forceinline__ float slab_sum_ordered(const float* slabs, int split, size_t slab_stride, size_t elem) {
+  float p = 0.f;
+  const float* q = slabs + elem;
+  for (int s0 = 0; s0 < split; s0 += 8) {
+    float t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = s0 + j < split ? q[(size_t)(s0 + j) * slab_stride] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (s0 + j < split) p += t[j];
+  }
+  return p;
+}
+
 typedef __attribute__((address_space(3))) const float lds_cf;
 typedef __attribute__((address_space(3))) const f32x2 lds_cf2;
 typedef __attribute__((address_space(3))) float* lds_fp;
