@@ -54,7 +54,11 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
   }
   d.n_pad = round_up(std::max(d.n, 1), 128);
   // split of the inner dimension: aim at >= 2 blocks per CU, >= 64 inner rows per wave
-  const int tiles = d.n_pad / 128;
+  // a wave covers 128 output columns (four 32-column tiles); when the output side is short (a shard of a multi-GPU run)
+  // 64 columns, so that the chip is filled with half as many inner slices, each twice as long (BNMTF_GEMM_TW=2/4 forces)
+  d.gemm_tw = (d.KP == 64 && d.n_pad <= 2048) ? 2 : 4;
+  if (const char* e = getenv("BNMTF_GEMM_TW")) d.gemm_tw = atoi(e) == 2 && d.KP == 64 ? 2 : 4;
+  const int tiles = d.n_pad / (32 * d.gemm_tw);
   // one resident block per CU at KP = 64 (the GEMM holds 332 registers per lane), two at KP = 32
   int split = std::max(1, (d.KP == 64 ? 256 : 512) / tiles);
   if (const char* e = getenv("BNMTF_GEMM_SPLIT")) split = std::max(1, atoi(e));
@@ -308,7 +312,7 @@ static void enqueue_gemm(bnmtf_model* h, Dir& d, const Dir& other, int kid) {
   ScopedKernelTimer t(h, kid);
   GemmArgs g;
   g.big = d.big; g.ld = d.n_pad; g.X = other.X; g.slabs = d.slabs;
-  g.n_pad = d.n_pad; g.split = d.split; g.inner_per_wave = d.ipw;
+  g.n_pad = d.n_pad; g.split = d.split; g.inner_per_wave = d.ipw; g.tw = d.gemm_tw;
   launch_gemm(g, d.KP, h->stream);
 }
 // relayout (XT, XT2) + Gram of a factor that was just written

@@ -306,6 +306,7 @@ void launch_gemm(const GemmArgs& a, int KP, hipStream_t st) {
     // TW = 4 column tiles (128 columns) per wave, one wave per SIMD.  TW = 2 with two waves per SIMD (grid n_pad/64) was
     // measured slower: 68-70 us against 60-62 us (the factor operand is split twice as often per MFMA).
     if (KP == 32) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 3, 4>), grid, block, 0, st, a);
+    else if (a.tw == 2) hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, 2>), dim3(a.n_pad / 64, a.split), block, 0, st, a);
     else          hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, 4>), grid, block, 0, st, a);
     return;
   }

@@ -20,6 +20,7 @@ struct GemmArgs {
   const float* X;                    // [inner_pad][KP]
   float* slabs;                      // [split][n_pad][KP]
   int n_pad, split, inner_per_wave;  // inner range of wave w in split s: [(s*4+w)*ipw, +ipw)
+  int tw;                            // 32-column tiles per wave: 4 (128 columns) or 2 (64 columns, short output sides)
 };
 void launch_gemm(const GemmArgs& a, int KP, hipStream_t st);
 

@@ -59,6 +59,7 @@ struct Dir {
   int* f_gen_units = nullptr; int f_gen_count = 0;
   double* stats = nullptr; int stats_blocks = 0;
   bool fast_ok = false;
+  int gemm_tw = 4;                       // contraction: 32-column tiles per wave
   bool use_wide = false;                 // 16-wave sweep kernel (pairs dealt to blocks per wave class) instead of the 8-wave one
   double* C64 = nullptr; float* C32 = nullptr; double* colsum = nullptr;   // Gram of X
   // VB only
