@@ -210,16 +210,17 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
       CHK(dalloc(&d.f_off16, off16.size(), false));
       HIPCHK(hipMemcpy(d.f_off16, off16.data(), off16.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
-    // 8-wave kernel: blocks whose fullest pair exceeds kFastMaxSlots are left to the generic kernel
+    // pairs with more slots per lane than the block shape holds (kFastMaxSlots; the 16-wave shape is only chosen when
+    // every pair fits) are left to the generic kernel: their waves idle in the on-chip kernel
     {
       std::vector<int> gen;
       // waves per block: 8 when there are enough units for >= 256 blocks, else 4 or 2 (multi-GPU shards, small problems)
       d.f_nw = d.f_npairs >= 8 * 256 ? 8 : (d.f_npairs >= 4 * 256 ? 4 : (d.f_npairs >= 2 * 64 ? 2 : 8));
       if (const char* e = getenv("BNMTF_FAST_NW")) d.f_nw = atoi(e) == 2 ? 2 : (atoi(e) == 4 ? 4 : 8);
       if (d.use_wide) d.f_nw = 16;
-      for (int b0 = 0; b0 < d.f_npairs && !d.use_wide; b0 += d.f_nw)
-        if ((int)pE[b0] > kFastMaxSlots)
-          for (int t = 2 * b0; t < std::min(2 * (b0 + d.f_nw), 2 * d.f_npairs); ++t) if (umap[t] >= 0) gen.push_back(umap[t]);
+      for (int pi = 0; pi < d.f_npairs && !d.use_wide; ++pi)
+        if ((int)pE[pi] > kFastMaxSlots)
+          for (int t = 2 * pi; t < 2 * pi + 2; ++t) if (umap[t] >= 0) gen.push_back(umap[t]);
       d.fast_ok = true;
       d.f_gen_count = (int)gen.size();
       CHK(dalloc(&d.f_gen_units, std::max<size_t>(gen.size(), 1), false));
