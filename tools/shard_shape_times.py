@@ -1,0 +1,12 @@
+"""Per-rank kernel times at a shard's shape: a single-rank rows x 8192, K=64 problem (its U sweep and R.V contraction are
+what one of N ranks runs per iteration of the 8192^2 problem).  Run under `rocprofv3 --kernel-trace --stats`."""
+import sys, os, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bnmtf_amd import bnmf_gibbs_optimised
+from bnmtf_amd.synthetic import generate_bnmf
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+R, M, _, _ = generate_bnmf(rows, 8192, 64, 0.1, tau=1.0, seed_data=0, seed_mask=1)
+s = bnmf_gibbs_optimised(R, M, 64, dict(alpha=1., beta=1., lambdaU=0.1, lambdaV=0.1), verbose=False, seed=7)
+s.initialise("random")
+s.run(60, store_samples=False)
+s.close()
