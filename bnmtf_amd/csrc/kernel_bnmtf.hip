@@ -11,8 +11,9 @@
 //   for l = 0..L-1:  tauS_kl = tau Omega_ll ,
 //                    muS_kl  = (-lambdaS_kl + tau (eta_l + S_kl Omega_ll - sum_{l''<l} delta_l'' Omega_l''l)) / tauS_kl
 // (P = F S G^T, Pv = R~^T F, Cf = F^T F, q = P on the missing entries, delta = S_new - S_old).
-// srow_gather_kernel makes the J-vectors and per-block partial eta/Omega for one k;
-// srow_draw_kernel reduces them, runs the L sequential draws and propagates delta.
+// w_k and Omega^k do not depend on S: srow_w_kernel / srow_omega_kernel form them for every k once per iteration.
+// Per row k, srow_gather_kernel makes h_k (carrying q forward by the previous row's delta) and per-block partial eta;
+// srow_draw_kernel sums the partials, runs the L sequential draws and propagates delta.
 #include <algorithm>
 
 #include "sweep_common.h"
@@ -58,32 +59,97 @@ __device__ __forceinline__ float wsum(float v) {
   return v;
 }
 
-// One wave per column j (grid-strided).  Lane l (< L) holds G_jl.
-__global__ __launch_bounds__(256) void srow_gather_kernel(SRowArgs a) {
-  __shared__ float red[64 * 65 + 64];
-  for (int t = threadIdx.x; t < 64 * 65 + 64; t += 256) red[t] = 0.f;
-  __syncthreads();
+// w[j][k] = sum_i M_ij F_ik^2 = Cf_kk - sum_{i in miss(j)} F_ik^2 for every k: one wave per column j, lane k.  Does not
+// depend on S, so it is formed once per iteration, ahead of the K sequential rows.
+__global__ __launch_bounds__(256) void srow_w_kernel(SOmegaArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (u >= a.n) return;
+  const uint32_t s0 = a.slot_ptr[u], s1 = a.slot_ptr[u + 1];
+  const int kk = lane < a.KPk ? lane : 0;
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+  for (uint32_t e0 = s0; e0 < s1; e0 += 64) {
+    const uint32_t iv = (e0 + lane < s1) ? a.idx[e0 + lane] : (uint32_t)a.zero_row;     // padding slots point at the zero row too
+    const int cnt = (int)min(64u, s1 - e0);
+    int t = 0;
+    for (; t + 4 <= cnt; t += 4) {
+      const float f0 = a.F[(size_t)__builtin_amdgcn_readlane((int)iv, t) * a.KPk + kk];
+      const float f1 = a.F[(size_t)__builtin_amdgcn_readlane((int)iv, t + 1) * a.KPk + kk];
+      const float f2 = a.F[(size_t)__builtin_amdgcn_readlane((int)iv, t + 2) * a.KPk + kk];
+      const float f3 = a.F[(size_t)__builtin_amdgcn_readlane((int)iv, t + 3) * a.KPk + kk];
+      acc0 = fmaf(f0, f0, acc0); acc1 = fmaf(f1, f1, acc1); acc2 = fmaf(f2, f2, acc2); acc3 = fmaf(f3, f3, acc3);
+    }
+    for (; t < cnt; ++t) { const float f0 = a.F[(size_t)__builtin_amdgcn_readlane((int)iv, t) * a.KPk + kk]; acc0 = fmaf(f0, f0, acc0); }
+  }
+  if (lane < a.KPk) a.w[(size_t)u * a.KPk + lane] = (lane < a.K ? a.Cf32[(size_t)lane * a.KPk + lane] : 0.f) - ((acc0 + acc1) + (acc2 + acc3));
+}
+
+// Omega^k[l][l'] = sum_j w_kj G_jl G_jl' for every row k of S, as nch partial sums over column chunks: block (k, c).
+// LP = padded L (32 or 64); thread t owns l = t mod LP and NACC consecutive l'.
+template <int LP>
+__global__ __launch_bounds__(256) void srow_omega_kernel(SOmegaArgs a) {
+  constexpr int TJ = 64, NACC = LP * LP / 256;
+  __shared__ float Gs[TJ][LP], ws[TJ];
+  const int k = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+  const int chunk = (a.n + a.nch - 1) / a.nch;
+  const int j0 = c * chunk, j1 = min(a.n, j0 + chunk);
+  const int l = tid % LP, g = tid / LP;
+  float acc[NACC];
+#pragma unroll
+  for (int t = 0; t < NACC; ++t) acc[t] = 0.f;
+  for (int jb = j0; jb < j1; jb += TJ) {
+    const int nj = min(TJ, j1 - jb);
+    __syncthreads();
+    for (int t = tid; t < TJ * LP; t += 256) {
+      const int jj = t / LP, ll = t % LP;
+      Gs[jj][ll] = (jj < nj && ll < a.L) ? a.G[((size_t)a.n0 + jb + jj) * a.KPl + ll] : 0.f;
+    }
+    if (tid < TJ) ws[tid] = tid < nj ? a.w[(size_t)(jb + tid) * a.KPk + k] : 0.f;
+    __syncthreads();
+#pragma unroll 4
+    for (int jj = 0; jj < TJ; ++jj) {
+      const float wg = ws[jj] * Gs[jj][l];
+#pragma unroll
+      for (int t = 0; t < NACC; ++t) acc[t] = fmaf(wg, Gs[jj][g * NACC + t], acc[t]);
+    }
+  }
+  float* out = a.omp + ((size_t)k * a.nch + c) * LP * LP + (size_t)l * LP + g * NACC;
+#pragma unroll
+  for (int t = 0; t < NACC; ++t) out[t] = acc[t];
+}
+void launch_srow_omega(const SOmegaArgs& a, hipStream_t st) {
+  if (a.n <= 0) return;
+  hipLaunchKernelGGL(srow_w_kernel, dim3((a.n + 3) / 4), dim3(256), 0, st, a);
+  if (a.KPl == 32) hipLaunchKernelGGL(srow_omega_kernel<32>, dim3(a.K, a.nch), dim3(256), 0, st, a);
+  else             hipLaunchKernelGGL(srow_omega_kernel<64>, dim3(a.K, a.nch), dim3(256), 0, st, a);
+}
+
+// Row k: one wave per column j, 16 columns per block.  Lane l (< L) holds G_jl; the block's share of eta_l = sum_j G_jl h_kj
+// goes to partial[block][L] (summed by the draw kernel in a fixed order).
+__global__ __launch_bounds__(1024) void srow_gather_kernel(SRowArgs a) {
+  __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int L = a.L, k = a.k;
-  float eta = 0.f;                    // lane l: sum_j G_jl h_kj
-  float om[64];                       // lane l: Omega[l][l'] partial
-#pragma unroll
-  for (int t = 0; t < 64; ++t) om[t] = 0.f;
-  const float* FTk = a.FT + (size_t)k * a.ldT;
-  const float* FTp = a.FT + (size_t)(k > 0 ? k - 1 : 0) * a.ldT;
-  const float cfs_l = (lane < L) ? a.CfS[k * L + lane] : 0.f;
-  const float cfkk = *a.cfkk_ptr;
-  const float dprev_l = (k > 0 && a.apply_prev && lane < L) ? a.delta_prev[lane] : 0.f;
-  for (int u = blockIdx.x * 4 + wave; u < a.n; u += gridDim.x * 4) {
+  const int u = blockIdx.x * 16 + wave;
+  float contrib = 0.f;
+  if (u < a.n) {
+    const float* FTk = a.FT + (size_t)k * a.ldT;
+    const float* FTp = a.FT + (size_t)(k > 0 ? k - 1 : 0) * a.ldT;
+    const bool upd = k > 0 && a.apply_prev;
+    const float cfs_l = (lane < L) ? a.CfS[k * L + lane] : 0.f;
+    const float dprev_l = (upd && lane < L) ? a.delta_prev[lane] : 0.f;
     const float g = (lane < L) ? a.G[((size_t)a.n0 + u) * a.KPl + lane] : 0.f;
-    const float dj = wsum(g * dprev_l);                              // G_j . delta_{k-1}
     float pv = 0.f;                                                   // Pv_jk = sum of the contraction's partial slabs
     for (int s = lane; s < a.split; s += 64) pv += a.slabs[((size_t)s * a.n_pad + u) * a.KPk + k];
     const uint32_t s0 = a.slot_ptr[u], s1 = a.slot_ptr[u + 1];
     const uint32_t* __restrict__ idxp = a.idx;
     float* __restrict__ qp = a.q;
-    const bool upd = k > 0 && a.apply_prev;
-    float hm = 0.f, wm = 0.f;
+    // one combined butterfly for the per-unit sums (G.delta, pv, G.CfS)
+    float r0 = g * dprev_l, r2 = pv, r3 = g * cfs_l;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { r0 += __shfl_xor(r0, m, 64); r2 += __shfl_xor(r2, m, 64); r3 += __shfl_xor(r3, m, 64); }
+    const float dj = r0;                                              // G_j . delta_{k-1}
+    float hm = 0.f;
     for (uint32_t e = s0 + lane; e < s1; e += 128) {                 // two independent slots per trip
       const uint32_t e2 = e + 64;
       const bool two = e2 < s1;
@@ -95,130 +161,132 @@ __global__ __launch_bounds__(256) void srow_gather_kernel(SRowArgs a) {
         if (two) { q1 = fmaf(FTp[i1], dj, q1); qp[e2] = q1; }
       }
       hm = fmaf(q0, f0, fmaf(q1, f1, hm));
-      wm = fmaf(f0, f0, fmaf(f1, f1, wm));
     }
-    // one combined butterfly for the four per-unit sums (hm, wm, pv, G.CfS)
-    float r0 = hm, r1 = wm, r2 = pv, r3 = g * cfs_l;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { r0 += __shfl_xor(r0, m, 64); r1 += __shfl_xor(r1, m, 64); r2 += __shfl_xor(r2, m, 64); r3 += __shfl_xor(r3, m, 64); }
-    hm = r0; wm = r1;
-    const float h = r2 - r3 + hm;
-    const float w = cfkk - wm;
-    eta = fmaf(g, h, eta);
-    const float wg = w * g;
-#pragma unroll
-    for (int lp = 0; lp < 64; ++lp)
-      if (lp < L) om[lp] = fmaf(wg, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g), lp)), om[lp]);
+    hm = wsum(hm);
+    contrib = g * (r2 - r3 + hm);
   }
-  // block partials -> slab [block][L + L*L]
-  // the four waves add their partials in turn (LDS float atomics compile to a CAS loop here: 60k stall cycles)
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
-      red[64 * 65 + lane] += eta;
+  red[wave][lane] = contrib;
+  __syncthreads();
+  if (threadIdx.x < L) {
+    float s = 0.f;
 #pragma unroll
-      for (int lp = 0; lp < 64; ++lp)
-        if (lp < L) red[lane * 65 + lp] += om[lp];
-    }
-    __syncthreads();
+    for (int w = 0; w < 16; ++w) s += red[w][threadIdx.x];
+    a.partial[(size_t)blockIdx.x * L + threadIdx.x] = s;
   }
-  float* out = a.partial + (size_t)blockIdx.x * (L + L * L);
-  for (int t = threadIdx.x; t < L + L * L; t += 256)
-    out[t] = (t < L) ? red[64 * 65 + t] : red[((t - L) / L) * 65 + (t - L) % L];
 }
 void launch_srow_gather(const SRowArgs& a, int blocks, hipStream_t st) {
-  hipLaunchKernelGGL(srow_gather_kernel, dim3(blocks), dim3(256), 0, st, a);
+  if (blocks > 0) hipLaunchKernelGGL(srow_gather_kernel, dim3(blocks), dim3(1024), 0, st, a);
 }
 
-// sum the per-block partial (eta, Omega) slabs: 32 outputs per block, 32 partial strides per output
-__global__ __launch_bounds__(1024) void srow_reduce_kernel(const float* partial, int nblocks, int nvals, float* out) {
-  __shared__ float red[1024];
-  const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int t = blockIdx.x * 32 + e;
-  float s = 0.f;
-  if (t < nvals)
-    for (int b = g; b < nblocks; b += 32) s += partial[(size_t)b * nvals + t];
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int w = 16; w >= 1; w >>= 1) {
-    if (g < w) red[threadIdx.x] += red[threadIdx.x + 32 * w];
+// Single block: sum the partials, run the L sequential conditionals of row k, write S[k][:], delta_k, and keep Cf.S
+// current.  cond_l >= 0: only evaluate (k, cond_l) and write numer/tau.
+// The sequential part is one wave with lane l' owning entry (k, l'): its running correction sum_{l''<l'} delta_l'' Omega_l''l'
+// grows by one FMA per step (row l of Omega read from LDS ahead of the chain), so a step is readlanes + the sampler, with
+// no reduction and no LDS round trip; the first four candidates of every entry are hoisted (lane l' holds those of
+// (k, l')) and evaluated by lanes 0-3 at once, later ones 64 at a time.
+__global__ __launch_bounds__(1024) void srow_draw_kernel(SDrawArgs a) {
+  __shared__ float eta[64], Om[64 * 65], delta[64], red[32][64];
+  const int L = a.L, K = a.K, k = a.k, tid = threadIdx.x;
+  {   // eta = the gather kernel's block partials (NG interleaved running sums, then those in order); Omega^k = its chunk partials
+    const int NG = 1024 / a.LP;                        // groups of LP threads; group g takes blocks g, g + NG, ...
+    const int l = tid % a.LP, grp = tid / a.LP;
+    float sp[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) sp[t] = 0.f;
+    if (l < L)
+      for (int b0 = grp; b0 < a.nblocks; b0 += 8 * NG) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { const int b = b0 + t * NG; if (b < a.nblocks) sp[t] += a.partial[(size_t)b * L + l]; }
+      }
+    red[grp][l] = ((sp[0] + sp[1]) + (sp[2] + sp[3])) + ((sp[4] + sp[5]) + (sp[6] + sp[7]));
+    const float* op = a.omp + (size_t)k * kSOmegaChunks * a.LP * a.LP;
+    for (int t = tid; t < L * L; t += 1024) {
+      const int l1 = t / L, l2 = t % L;
+      float o[kSOmegaChunks];
+#pragma unroll
+      for (int c = 0; c < kSOmegaChunks; ++c) o[c] = op[(size_t)c * a.LP * a.LP + l1 * a.LP + l2];
+      float os = 0.f;
+#pragma unroll
+      for (int c = 0; c < kSOmegaChunks; ++c) os += o[c];
+      Om[l1 * 65 + l2] = os;
+    }
+    if (tid < 64) delta[tid] = 0.f;
+    __syncthreads();
+    if (tid < L) { float e = 0.f; for (int w = 0; w < NG; ++w) e += red[w][tid]; eta[tid] = e; }
     __syncthreads();
   }
-  if (g == 0 && t < nvals) out[t] = red[e];
-}
-
-// Single block: run the L sequential conditionals of row k on the reduced (eta, Omega), write S[k][:],
-// delta_k, and keep Cf.S current.  cond_l >= 0: only evaluate (k, cond_l) and write numer/tau.
-__global__ __launch_bounds__(1024) void srow_draw_kernel(SDrawArgs a) {
-  __shared__ float eta[64], Om[64 * 65], delta[64], srow[64];
-  const int L = a.L, K = a.K, k = a.k, tid = threadIdx.x;
-  for (int t = tid; t < L + L * L; t += 1024) {
-    const float s = a.partial[t];
-    if (t < L) eta[t] = s; else Om[((t - L) / L) * 65 + (t - L) % L] = s;
-  }
-  if (tid < L) { delta[tid] = 0.f; srow[tid] = a.S[k * L + tid]; }
-  __syncthreads();
   if (tid < 64) {                                   // one wave: the sequential l loop
+    const int lane = tid;
+    const bool on = lane < L;
     const float tau = *a.tau;
-    // hoisted Philox: lane l holds candidates 0 and 1 of entry (k, l)
-    uint32_t c0a = 0, c0b = 0, c1a = 0, c1b = 0;
-    if (a.update == 0 && a.cond_l < 0 && tid < L) {
-      const U4 r0 = philox4x32_10(0u, (uint32_t)(k * L + tid), a.it, kStreamS, a.key0, a.key1);
-      const U4 r1 = philox4x32_10(0u, (uint32_t)(k * L + tid), a.it, kStreamS + 16u, a.key0, a.key1);
-      c0a = r0.x; c0b = r0.y; c1a = r1.x; c1b = r1.y;
+    const float my_eta = on ? eta[lane] : 0.f, my_oll = on ? Om[lane * 65 + lane] : 0.f, my_lam = on ? a.lambdaS[k * L + lane] : 0.f;
+    float my_s = on ? a.S[k * L + lane] : 0.f, my_delta = 0.f, corr = 0.f;
+    const TnPre my_pre = tn_fast_pre(tau * my_oll);     // tau_p of every entry is known before the chain starts
+    constexpr int NH = 4;                            // hoisted candidates per entry
+    uint32_t wa[NH], wb[NH];
+#pragma unroll
+    for (int c = 0; c < NH; ++c) { wa[c] = 0u; wb[c] = 0u; }
+    if (a.update == 0 && a.cond_l < 0 && on) {
+#pragma unroll
+      for (int c = 0; c < NH; ++c) {
+        const U4 r = philox4x32_10(0u, (uint32_t)(k * L + lane), a.it, kStreamS + 16u * (uint32_t)c, a.key0, a.key1);
+        wa[c] = r.x; wb[c] = r.y;
+      }
     }
     const int lbeg = a.cond_l >= 0 ? a.cond_l : 0, lend = a.cond_l >= 0 ? a.cond_l + 1 : L;
     for (int l = lbeg; l < lend; ++l) {
-      float corr = (tid < l && a.cond_l < 0) ? delta[tid] * Om[tid * 65 + l] : 0.f;
-      corr = wsum(corr);
-      const float oll = Om[l * 65 + l];
-      const float sold = srow[l];
+      const float row = on ? Om[l * 65 + lane] : 0.f;                  // Omega[l][lane]: off the chain
+      const float numer_v = fmaf(tau, my_eta + my_s * my_oll - corr, -my_lam);
+      const float numer = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, numer_v), l));
+      const float oll = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_oll), l));
+      const float sold = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_s), l));
       const float tau_p = tau * oll;
-      const float numer = fmaf(tau, eta[l] + sold * oll - corr, -a.lambdaS[k * L + l]);
       if (a.cond_l >= 0) { if (tid == 0) { a.numer_out[0] = (double)numer; a.tau_out[0] = (double)tau_p; } break; }
-      const float mu = numer / tau_p;
       float snew = 0.f;
       if (a.update == 0) {
-        const TnFast tp = tn_fast_params(numer, tau_p);           // the one-instruction forms the factor sweeps use
+        TnPre pre;
+        pre.irt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_pre.irt), l));
+        pre.rcp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_pre.rcp), l));
+        pre.tpirt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_pre.tpirt), l));
+        pre.live = tau_p > 0.0f;
+        const TnFast tp = tn_fast_post(pre, numer);              // the one-instruction forms the factor sweeps use
         if (tp.live) {
-          // candidates 0, 1 from the hoisted words (lane l), then 64 fresh candidates per round
-          const uint32_t w0a = (uint32_t)__builtin_amdgcn_readlane((int)c0a, l), w0b = (uint32_t)__builtin_amdgcn_readlane((int)c0b, l);
-          const uint32_t w1a = (uint32_t)__builtin_amdgcn_readlane((int)c1a, l), w1b = (uint32_t)__builtin_amdgcn_readlane((int)c1b, l);
-          float x0, x1;
-          const bool a0 = tn_eval_fast(tp, w0a, w0b, &x0), a1 = tn_eval_fast(tp, w1a, w1b, &x1);
-          if (a0) snew = tn_guard(x0);
-          else if (a1) snew = tn_guard(x1);
-          else {
-            for (uint32_t round = 0; round < 64u; ++round) {
-              const U4 r = philox4x32_10(0u, (uint32_t)(k * L + l), a.it, kStreamS + 16u * (2u + round * 64u + tid), a.key0, a.key1);
-              float xc;
-              const bool acc = tn_eval_fast(tp, r.x, r.y, &xc);
-              const unsigned long long m = __ballot(acc);
-              if (m) { snew = tn_guard(__shfl(xc, __ffsll((long long)m) - 1, 64)); break; }
-            }
+          // lane c < NH takes hoisted candidate c of entry (k, l) (lane l holds its words)
+          uint32_t ca = 0u, cb = 0u;
+#pragma unroll
+          for (int c = 0; c < NH; ++c) {
+            const uint32_t ra = (uint32_t)__builtin_amdgcn_readlane((int)wa[c], l), rb = (uint32_t)__builtin_amdgcn_readlane((int)wb[c], l);
+            if (lane == c) { ca = ra; cb = rb; }
           }
+          float xc;
+          bool acc = tn_eval_fast(tp, ca, cb, &xc) && lane < NH;
+          unsigned long long m = __ballot(acc);
+          for (uint32_t round = 0; m == 0ull && round < 64u; ++round) {     // candidates NH + 64 round + lane
+            const U4 r = philox4x32_10(0u, (uint32_t)(k * L + l), a.it, kStreamS + 16u * ((uint32_t)NH + round * 64u + (uint32_t)lane), a.key0, a.key1);
+            acc = tn_eval_fast(tp, r.x, r.y, &xc);
+            m = __ballot(acc);
+          }
+          if (m) snew = tn_guard(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xc), __ffsll((long long)m) - 1)));
         }
       } else {
+        const float mu = numer / tau_p;
         snew = fmaxf((tau_p > 0.f && mu > 0.f) ? mu : 0.f, a.min_x);
       }
-      if (tid == 0) { delta[l] = snew - sold; srow[l] = snew; }
-      __builtin_amdgcn_s_waitcnt(0);
-      __builtin_amdgcn_wave_barrier();
+      const float dl = snew - sold;
+      if (lane == l) { my_s = snew; my_delta = dl; }
+      corr = fmaf(dl, row, corr);                     // what lanes l' > l subtract when their turn comes
     }
+    if (a.cond_l < 0 && on) { a.S[k * L + lane] = my_s; a.delta_out[lane] = my_delta; delta[lane] = my_delta; }
   }
   __syncthreads();
   if (a.cond_l >= 0) return;
-  if (tid < L) { a.S[k * L + tid] = srow[tid]; a.delta_out[tid] = delta[tid]; }
   for (int t = tid; t < K * L; t += 1024) {           // (Cf S)[k'][l] += Cf[k'][k] delta_l
     const int kp = t / L, l = t % L;
     a.CfS[t] += (float)a.Cf64[(size_t)kp * a.KPk + k] * delta[l];
   }
 }
 void launch_srow_draw(const SDrawArgs& a, hipStream_t st) {
-  const int nvals = a.L + a.L * a.L;
-  hipLaunchKernelGGL(srow_reduce_kernel, dim3((nvals + 31) / 32), dim3(1024), 0, st, a.partial, a.nblocks, nvals, a.reduced);
-  SDrawArgs b = a;
-  b.partial = a.reduced;
-  hipLaunchKernelGGL(srow_draw_kernel, dim3(1), dim3(1024), 0, st, b);
+  hipLaunchKernelGGL(srow_draw_kernel, dim3(1), dim3(1024), 0, st, a);
 }
 
 }  // namespace bnmtf

@@ -170,15 +170,25 @@ struct SRowArgs {           // one row k of S: J-vectors h_k, w_k and per-block 
   const float* slabs; int split, n_pad;   // Pv = R~^T F partial slabs, width KPk
   const uint32_t* slot_ptr; const uint32_t* idx; float* q;   // generic (64-wide) slots of the cols direction
   const float* CfS;                    // [K][L] current Cf.S
-  float cfkk; const float* cfkk_ptr;   // Cf[k][k] (read on the device)
   const float* delta_prev; int apply_prev;   // delta of row k-1: q += F_{i,k-1} (G_j . delta) before use
-  float* partial;                      // [blocks][L + L*L]
+  float* partial;                      // [blocks][L]: per-block share of eta
 };
+constexpr int kSOmegaChunks = 8;       // column chunks of the Omega^k partial sums
+struct SOmegaArgs {         // w[j][k] and the chunk partials of Omega^k for every k (once per iteration)
+  int n, n0, K, L, KPk, KPl, nch, zero_row;
+  const float* F;                      // [I+][KPk] row major (row zero_row is zero)
+  const float* G;                      // [J][KPl]
+  const float* Cf32;                   // F^T F [KPk][KPk]
+  const uint32_t* slot_ptr; const uint32_t* idx;
+  float* w;                            // [J][KPk]
+  float* omp;                          // [K][nch][LP*LP]
+};
+void launch_srow_omega(const SOmegaArgs& a, hipStream_t st);
 void launch_srow_gather(const SRowArgs& a, int blocks, hipStream_t st);
 struct SDrawArgs {
-  int k, K, L, KPk, nblocks, update, cond_l;
+  int k, K, L, KPk, nblocks, update, cond_l, LP, nch;
   float min_x;                         // mode updates: lower clamp (ICM minimum_TN)
-  const float* partial; float* reduced; float* S; const float* lambdaS; const float* tau;
+  const float* partial; const float* omp; float* S; const float* lambdaS; const float* tau;
   const double* Cf64; float* CfS; float* delta_out;
   uint32_t key0, key1, it;
   double* numer_out; double* tau_out;

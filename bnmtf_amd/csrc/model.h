@@ -99,7 +99,7 @@ struct bnmtf_model {
   // BNMTF extras
   float* S = nullptr;            // [K][L] on device (row major, unpadded)
   bnmtf::Dir reff, ceff;         // effective factors U_eff = F S (I x L), V_eff = G S^T (J x K): factor storage only
-  float *slabsS = nullptr, *CfS = nullptr, *deltaS = nullptr, *s_partial = nullptr, *s_reduced = nullptr, *lambdaS = nullptr;
+  float *slabsS = nullptr, *CfS = nullptr, *deltaS = nullptr, *s_partial = nullptr, *s_w = nullptr, *s_omp = nullptr, *lambdaS = nullptr;
   double *s_numer = nullptr, *s_taup = nullptr;
   int s_blocks = 0;
   // profiling

@@ -45,20 +45,32 @@ __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __bu
 
 // reciprocal-based parameters (v_rcp / v_rsq, ~1 ulp): the sampler needs no correctly rounded division
 struct TnFast { float mu, irt, a, d, ilam; bool live, tail; };
-__device__ __forceinline__ TnFast tn_fast_params(float numer, float tau_p) {
+// the part that needs tau_p only (a kernel that knows tau_p ahead of its sequential chain takes it off the chain) ...
+struct TnPre { float irt, rcp, tpirt; bool live; };
+__device__ __forceinline__ TnPre tn_fast_pre(float tau_p) {
 #pragma clang fp contract(off)      // explicit fmaf only: every kernel that inlines this rounds identically (same chain on 1 and N GPUs)
+  TnPre q;
+  q.live = tau_p > 0.0f;
+  const float tp = q.live ? tau_p : 1.0f;
+  q.irt = __builtin_amdgcn_rsqf(tp);             // sigma   (v_rsq_f32 / v_rcp_f32 / v_sqrt_f32: ~1 ulp, one instruction each)
+  q.rcp = __builtin_amdgcn_rcpf(tp);
+  q.tpirt = tp * q.irt;                          // sqrt(tau)
+  return q;
+}
+// ... and the part that needs the numerator
+__device__ __forceinline__ TnFast tn_fast_post(const TnPre& q, float numer) {
+#pragma clang fp contract(off)
   TnFast p;
-  p.live = tau_p > 0.0f;
-  const float tp = p.live ? tau_p : 1.0f;
-  p.irt = __builtin_amdgcn_rsqf(tp);             // sigma   (v_rsq_f32 / v_rcp_f32 / v_sqrt_f32: ~1 ulp, one instruction each)
-  p.mu = numer * __builtin_amdgcn_rcpf(tp);
-  p.a = -p.mu * (tp * p.irt);                    // -mu * sqrt(tau)
-  p.live = p.live && isfinite(p.a);
+  p.irt = q.irt;
+  p.mu = numer * q.rcp;
+  p.a = -p.mu * q.tpirt;                         // -mu * sqrt(tau)
+  p.live = q.live && isfinite(p.a);
   p.d = 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(p.a, p.a, 4.0f)) + p.a);
   p.ilam = __builtin_amdgcn_rcpf(p.a + p.d);
   p.tail = p.a >= kTnA0;
   return p;
 }
+__device__ __forceinline__ TnFast tn_fast_params(float numer, float tau_p) { return tn_fast_post(tn_fast_pre(tau_p), numer); }
 __device__ __forceinline__ bool tn_eval_fast(const TnFast& p, uint32_t r0, uint32_t r1, float* x) {
 #pragma clang fp contract(off)
   const float u1 = u24(r0), u2 = u24(r1);
