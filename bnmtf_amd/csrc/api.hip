@@ -147,8 +147,8 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
     std::vector<int> order(d.n);
     for (int i = 0; i < d.n; ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return Eu[x] > Eu[y]; });
-    // Units pair up in descending slot-count order.  The 8-wave kernel takes the pairs in that order (homogeneous
-    // blocks, one slot class per block).  The 16-wave kernel picks the class per WAVE, so its pairs are dealt to the
+    // Units pair up in descending slot-count order.  The 2/4/8-wave blocks take the pairs in that order.  The on-chip
+    // kernel picks the slot class per WAVE, so for the 16-wave shape the pairs are dealt to the
     // blocks boustrophedon (and to the four SIMDs of a block likewise): every block, and every SIMD, gets the same mix
     // of full and light units, and one round of blocks ends together.
     const int npairs_real = (d.n + 1) / 2;
@@ -201,7 +201,7 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
     HIPCHK(hipMemcpy(d.f_pair_base, pB.data(), pB.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     CHK(dalloc(&d.f_off, off.size(), false));
     HIPCHK(hipMemcpy(d.f_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    {   // 16-bit packed slot pairs (two inner indices per word): the slot table the 16-wave kernels load
+    {   // 16-bit packed slot pairs (two inner indices per word): the slot table the on-chip kernels load
       d.pair_ok = d.mz + 32 < 65536;
       std::vector<uint32_t> off16(std::max<size_t>(rows_total / 2, 1) * 64, 0);
       if (d.pair_ok)

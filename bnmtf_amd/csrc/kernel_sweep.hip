@@ -13,7 +13,7 @@
 //
 // Generic version: one 64-lane wave per row; the row's missing entries live in
 // 64-wide slots (slot e*64+lane), q in global memory.  Correct for any mask; the
-// register/LDS-resident fast path (kernel_sweep_fast.hip) handles the dense-mask
+// register/LDS-resident fast path (sweep_chip.inc) handles the dense-mask
 // shapes of the benchmark configs.
 #include "kernels.h"
 #include "device_rng.h"

@@ -1,5 +1,5 @@
 // K3-VB: the variational half sweep (bnmf_vb_optimised.py:189-211, update_U(k) + update_exp_U(k) for k = 0..K-1)
-// in the register/LDS-resident shape of kernel_sweep_wide.hip: 16 units per block, 8 waves (the fp64 moments need the 256-VGPR budget).
+// in the register/LDS-resident shape of sweep_chip.inc: 16 units per block, 8 waves (the fp64 moments need the 256-VGPR budget).
 //
 // Per unit i and column k (E = expectations, S2 = var + E^2 of the OTHER factor):
 //   tau_ik = exptau * sum_j M_ij S2_jk                = exptau * (colsum2_k - sum_{j in miss(i)} S2_jk)

@@ -73,14 +73,14 @@ struct SweepArgs {
 };
 void launch_sweep(const SweepArgs& a, hipStream_t st);
 
-// fast path (kernel_sweep_fast.hip): bank-aware slot layout, q in registers, panels in LDS
+// on-chip path (sweep_chip.inc): bank-aware slot layout, q in registers, panels in LDS
 struct FastArgs {
   const int* unit_map;         // [2*npairs] local unit of each half wave, or -1
   const uint32_t* pair_E;      // [npairs] slots of the pair (max of its two units)
   const uint32_t* pair_base;   // [npairs] first slot row of the pair
   const uint32_t* off;         // [(base+s)*64 + lane] inner index j (j mod 32 == lane mod 32) or mz + lane%32
-  const uint32_t* off16;       // [(base/2+h)*64 + lane] slots 2h (low 16 bits) and 2h+1 (high) packed (16-wave kernels), or null
-  int nw;                      // waves per block of the fast sweep (2, 4 or 8)
+  const uint32_t* off16;       // [(base/2+h)*64 + lane] slots 2h (low 16 bits) and 2h+1 (high) packed, or null
+  int nw;                      // unit waves per block (2, 4, 8 or 16)
   int npairs;                  // pairs in descending slot-count order
   int mz, pw;                  // inner extent rounded up to 32 (sentinel zero words at mz..mz+31); panel floats pw = round_up(mz+32, 256)
   const float* XoT; int ldT_o;   // other factor transposed [KP][ldT_o]
@@ -90,10 +90,11 @@ struct FastArgs {
   const float* XoS;            // other factor's (E, S2) pair panels [KP][ld2_o][2]
   float* vb_asq; float* vb_vsq;  // [rows][KP] per (unit, column): sum_miss S2other, sum_miss Eother^2 (for vb_pieces_kernel)
 };
-constexpr int kFastMaxSlots = 56;   // blocks whose fullest pair needs more slots per lane go to the generic kernel
+// 2/4/8-wave instantiations (kernel_sweep_fast.hip): pairs that need more than kFastMaxSlots slots per lane go to the generic kernel
+constexpr int kFastMaxSlots = 56;
 bool sweep_fast_supported(int KP, int pw);
 void launch_sweep_fast(const SweepArgs& a, const FastArgs& f, hipStream_t st);
-// 16-wave kernel (kernel_sweep_wide.hip): balanced slots, at most kWideMaxSlots per lane, 16 pairs per block
+// 16-wave instantiation (kernel_sweep_wide.hip): at most kWideMaxSlots slots per lane, 16 pairs per block
 constexpr int kWideMaxSlots = 32;
 bool sweep_wide_supported(int KP, int pw);
 void launch_sweep_wide(const SweepArgs& a, const FastArgs& f, hipStream_t st);

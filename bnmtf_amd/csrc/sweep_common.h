@@ -1,4 +1,4 @@
-// Shared device helpers of the register-resident sweep kernels (kernel_sweep_fast.hip, kernel_sweep_wide.hip):
+// Shared device helpers of the register-resident sweep kernels (sweep_chip.inc, kernel_sweep_vb.hip, kernel_bnmtf.hip):
 // half-wave reductions and broadcasts, the one-instruction TN candidate arithmetic, LDS-DMA panel staging.
 #pragma once
 #include "kernels.h"

@@ -1,4 +1,4 @@
-"""The 16-wave sweep kernel (kernel_sweep_wide.hip) and the bf16x3 contraction on shapes the default selection would
+"""The 16-wave shape of the on-chip sweep kernel (sweep_chip.inc via kernel_sweep_wide.hip) and the bf16x3 contraction on shapes the default selection would
 not give them: BNMTF_WIDE=1 forces the 16-wave kernel whenever it can run (<= 32 slots per lane), so ragged sizes,
 K < 32, K = 64, dense and sparse masks, rows with very different missing counts (balanced slots with parked
 entries, slot classes 8..32 mixed in one block) are all compared with

@@ -1,4 +1,4 @@
-"""Does the 8-wave kernel (shards of a multi-GPU run, small problems) produce exactly the chain of the 16-wave kernel?"""
+"""Do the 8-wave blocks (shards of a multi-GPU run, small problems) produce exactly the chain of the 16-wave blocks?  (one body, sweep_chip.inc)"""
 import os, sys, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bnmtf_amd
