@@ -7,7 +7,7 @@ namespace bnmtf {
 bool sweep_wide_supported(int KP, int pw) { return pw <= kChipPanelStride && sweep_chip_lds_bytes(KP, pw, 16) <= 160 * 1024; }
 
 // f describes the pairs this launch owns (f.npairs of them, at most kWideMaxSlots slots each), 16 pairs per block.
-void launch_sweep_wide(const SweepArgs& a, const FastArgs& f, hipStream_t st) { static const bool sp = !(getenv("BNMTF_SPLIT") && atoi(getenv("BNMTF_SPLIT")) == 0);
-  if (sp) launch_chip<16, 0, 1>(a, f, st); else launch_chip<16, 0, 0>(a, f, st); }
+void launch_sweep_wide(const SweepArgs& a, const FastArgs& f, hipStream_t st) {
+  if (chip_split_enabled()) launch_chip<16, 0, 1>(a, f, st); else launch_chip<16, 0, 0>(a, f, st); }
 
 }  // namespace bnmtf

@@ -84,3 +84,31 @@ def test_headline_shape_properties():
     assert abs(p["MSE"] - mse[-1]) < 1e-4 * mse[-1]
     assert abs(p["Rp"] - b.all_performances["Rp"][-1]) < 1e-5
     assert np.isfinite(b.U).all() and np.isfinite(b.V).all() and b.U.min() >= 0 and b.V.min() >= 0
+
+
+@pytest.mark.parametrize("I,J,K,env", [(2048, 1500, 64, {"BNMTF_WIDE": "1"}),      # 16-wave blocks
+                                       (1100, 900, 32, {"BNMTF_WIDE": "0"}),      # 8-wave blocks
+                                       (700, 600, 20, {"BNMTF_WIDE": "0", "BNMTF_FAST_NW": "4"}),
+                                       (700, 600, 20, {"BNMTF_WIDE": "0", "BNMTF_FAST_NW": "2"})])
+def test_block_shape_variants_draw_the_same_chain(monkeypatch, I, J, K, env):
+    """The per-block split sampler (8/16-wave shapes, BNMTF_SPLIT) and the staging wave (2/4-wave shapes) only move work
+    between waves: with either switched off the chain is bit-identical."""
+    rs = np.random.RandomState(K)
+    R = rs.exponential(1.0, (I, K)) @ rs.exponential(1.0, (J, K)).T + rs.randn(I, J)
+    M = (rs.rand(I, J) > 0.12).astype(float)
+    M[rs.randint(I, size=J), np.arange(J)] = 1
+    M[np.arange(I), rs.randint(J, size=I)] = 1
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    out = {}
+    for variant in ("default", "plain"):
+        if variant == "plain":
+            monkeypatch.setenv("BNMTF_SPLIT", "0")
+            monkeypatch.setenv("BNMTF_NO_STAGING_WAVE", "1")
+        b = bnmf_gibbs_optimised(R, M, K, PRI, verbose=False, seed=11)
+        np.random.seed(4); b.initialise("random")
+        b.run(3)
+        out[variant] = (b.all_U.copy(), b.all_V.copy(), b.all_tau.copy())
+        b.close()
+    for x, y in zip(out["default"], out["plain"]):
+        assert np.array_equal(x, y)
