@@ -71,18 +71,28 @@ __device__ __forceinline__ TnFast tn_fast_post(const TnPre& q, float numer) {
   return p;
 }
 __device__ __forceinline__ TnFast tn_fast_params(float numer, float tau_p) { return tn_fast_post(tn_fast_pre(tau_p), numer); }
-__device__ __forceinline__ bool tn_eval_fast(const TnFast& p, uint32_t r0, uint32_t r1, float* x) {
+// One candidate, in two parts: what depends on the random words only (can be issued ahead of the sequential chain) ...
+struct TnCand { float nl, z, u2; };
+__device__ __forceinline__ TnCand tn_cand_pre(uint32_t r0, uint32_t r1) {
 #pragma clang fp contract(off)
-  const float u1 = u24(r0), u2 = u24(r1);
-  const float nl = -0.69314718f * __builtin_amdgcn_logf(u1);            // v_log_f32 is log2
-  const float e = nl * p.ilam;
+  TnCand c;
+  const float u1 = u24(r0);
+  c.u2 = u24(r1);
+  c.nl = -0.69314718f * __builtin_amdgcn_logf(u1);                       // v_log_f32 is log2
+  c.z = __builtin_amdgcn_sqrtf(2.0f * c.nl) * __builtin_amdgcn_cosf(c.u2);   // v_cos_f32 takes revolutions
+  return c;
+}
+// ... and the acceptance test + value given the conditional's parameters
+__device__ __forceinline__ bool tn_cand_post(const TnFast& p, const TnCand& c, float* x) {
+#pragma clang fp contract(off)
+  const float e = c.nl * p.ilam;
   const float t = e - p.d;
-  const bool acc_t = u2 <= __builtin_amdgcn_exp2f(-0.72134752f * t * t);   // exp(-t^2/2) via v_exp_f32 (2^x)
-  const float z = __builtin_amdgcn_sqrtf(2.0f * nl) * __builtin_amdgcn_cosf(u2);   // v_cos_f32 takes revolutions
-  const bool acc_n = z >= p.a;
-  *x = p.tail ? e * p.irt : fmaf(z, p.irt, p.mu);
+  const bool acc_t = c.u2 <= __builtin_amdgcn_exp2f(-0.72134752f * t * t);   // exp(-t^2/2) via v_exp_f32 (2^x)
+  const bool acc_n = c.z >= p.a;
+  *x = p.tail ? e * p.irt : fmaf(c.z, p.irt, p.mu);
   return p.tail ? acc_t : acc_n;
 }
+__device__ __forceinline__ bool tn_eval_fast(const TnFast& p, uint32_t r0, uint32_t r1, float* x) { return tn_cand_post(p, tn_cand_pre(r0, r1), x); }
 
 // LDS-direct staging of one panel: `chunks` pieces of 1 KiB (64 lanes x 16 B), wave w takes
 // chunks w, w+8, ...  No VGPRs, no ds_write; completion is covered by the vmcnt(0) that
