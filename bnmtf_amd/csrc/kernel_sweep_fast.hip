@@ -9,12 +9,8 @@ namespace bnmtf {
 bool sweep_fast_supported(int KP, int pw) { return pw <= kChipPanelStride && sweep_chip_lds_bytes(KP, pw, 8) <= 160 * 1024; }
 
 void launch_sweep_fast(const SweepArgs& a, const FastArgs& f, hipStream_t st) {
-  // read per launch (not cached): tests flip them inside one process
-  const bool dw = getenv("BNMTF_NO_STAGING_WAVE") == nullptr;
-  const bool sp = chip_split_enabled();
-  if (f.nw == 2) { if (dw) launch_chip<2, 1, 0>(a, f, st); else launch_chip<2, 0, 0>(a, f, st); }
-  else if (f.nw == 4) { if (dw) launch_chip<4, 1, 0>(a, f, st); else launch_chip<4, 0, 0>(a, f, st); }
-  else if (sp) launch_chip<8, 0, 1>(a, f, st);
+  if (f.nw == 2 || f.nw == 4) launch_sweep_small(a, f, st);         // kernel_sweep_small.hip
+  else if (chip_split_enabled()) launch_chip<8, 0, 1>(a, f, st);
   else launch_chip<8, 0, 0>(a, f, st);
 }
 

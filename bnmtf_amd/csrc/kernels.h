@@ -94,6 +94,7 @@ struct FastArgs {
 constexpr int kFastMaxSlots = 56;
 bool sweep_fast_supported(int KP, int pw);
 void launch_sweep_fast(const SweepArgs& a, const FastArgs& f, hipStream_t st);
+void launch_sweep_small(const SweepArgs& a, const FastArgs& f, hipStream_t st);   // nw = 2, 4 (kernel_sweep_small.hip)
 // 16-wave instantiation (kernel_sweep_wide.hip): at most kWideMaxSlots slots per lane, 16 pairs per block
 constexpr int kWideMaxSlots = 32;
 bool sweep_wide_supported(int KP, int pw);
