@@ -185,7 +185,7 @@ void launch_srow_gather(const SRowArgs& a, int blocks, hipStream_t st) {
 // no reduction and no LDS round trip; the first four candidates of every entry are hoisted (lane l' holds those of
 // (k, l')) and evaluated by lanes 0-3 at once, later ones 64 at a time.
 __global__ __launch_bounds__(1024) void srow_draw_kernel(SDrawArgs a) {
-  __shared__ float eta[64], Om[64 * 65], delta[64], red[32][64];
+  __shared__ float eta[64], Om[64 * 65], delta[64], red[32][64], cands[64 * 4 * 3];
   const int L = a.L, K = a.K, k = a.k, tid = threadIdx.x;
   {   // eta = the gather kernel's block partials (NG interleaved running sums, then those in order); Omega^k = its chunk partials
     const int NG = 1024 / a.LP;                        // groups of LP threads; group g takes blocks g, g + NG, ...
@@ -223,19 +223,23 @@ __global__ __launch_bounds__(1024) void srow_draw_kernel(SDrawArgs a) {
     float my_s = on ? a.S[k * L + lane] : 0.f, my_delta = 0.f, corr = 0.f;
     const TnPre my_pre = tn_fast_pre(tau * my_oll);     // tau_p of every entry is known before the chain starts
     constexpr int NH = 4;                            // hoisted candidates per entry
-    uint32_t wa[NH], wb[NH];
-#pragma unroll
-    for (int c = 0; c < NH; ++c) { wa[c] = 0u; wb[c] = 0u; }
+    // lane l' makes the word-only half (tn_cand_pre) of the first NH candidates of entry (k, l') and parks it in LDS;
+    // at step l lane c < NH reads candidate c of entry l back, ahead of the chain
     if (a.update == 0 && a.cond_l < 0 && on) {
 #pragma unroll
       for (int c = 0; c < NH; ++c) {
         const U4 r = philox4x32_10(0u, (uint32_t)(k * L + lane), a.it, kStreamS + 16u * (uint32_t)c, a.key0, a.key1);
-        wa[c] = r.x; wb[c] = r.y;
+        const TnCand cd = tn_cand_pre(r.x, r.y);
+        cands[(lane * NH + c) * 3 + 0] = cd.nl; cands[(lane * NH + c) * 3 + 1] = cd.z; cands[(lane * NH + c) * 3 + 2] = cd.u2;
       }
     }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
     const int lbeg = a.cond_l >= 0 ? a.cond_l : 0, lend = a.cond_l >= 0 ? a.cond_l + 1 : L;
     for (int l = lbeg; l < lend; ++l) {
       const float row = on ? Om[l * 65 + lane] : 0.f;                  // Omega[l][lane]: off the chain
+      TnCand cd0 = {0.f, 0.f, 0.f};                                     // hoisted candidate `lane` of entry l: off the chain too
+      if (lane < NH) { cd0.nl = cands[(l * NH + lane) * 3 + 0]; cd0.z = cands[(l * NH + lane) * 3 + 1]; cd0.u2 = cands[(l * NH + lane) * 3 + 2]; }
       const float numer_v = fmaf(tau, my_eta + my_s * my_oll - corr, -my_lam);
       const float numer = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, numer_v), l));
       const float oll = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_oll), l));
@@ -251,15 +255,8 @@ __global__ __launch_bounds__(1024) void srow_draw_kernel(SDrawArgs a) {
         pre.live = tau_p > 0.0f;
         const TnFast tp = tn_fast_post(pre, numer);              // the one-instruction forms the factor sweeps use
         if (tp.live) {
-          // lane c < NH takes hoisted candidate c of entry (k, l) (lane l holds its words)
-          uint32_t ca = 0u, cb = 0u;
-#pragma unroll
-          for (int c = 0; c < NH; ++c) {
-            const uint32_t ra = (uint32_t)__builtin_amdgcn_readlane((int)wa[c], l), rb = (uint32_t)__builtin_amdgcn_readlane((int)wb[c], l);
-            if (lane == c) { ca = ra; cb = rb; }
-          }
           float xc;
-          bool acc = tn_eval_fast(tp, ca, cb, &xc) && lane < NH;
+          bool acc = tn_cand_post(tp, cd0, &xc) && lane < NH;
           unsigned long long m = __ballot(acc);
           for (uint32_t round = 0; m == 0ull && round < 64u; ++round) {     // candidates NH + 64 round + lane
             const U4 r = philox4x32_10(0u, (uint32_t)(k * L + l), a.it, kStreamS + 16u * ((uint32_t)NH + round * 64u + (uint32_t)lane), a.key0, a.key1);
