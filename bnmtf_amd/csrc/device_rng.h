@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.h"
+#include "tn_moments_coeffs.h"
 
 namespace bnmtf {
 
@@ -126,17 +127,72 @@ __host__ __device__ inline double gamma_draw_serial(double shape, double rate, u
 
 // TN moments in fp64, as truncated_normal_vector.py:53-73 (incl. the exponential
 // fall-back for mu < -30 sigma and the negative / non-finite -> 0 guard).
+// fp64 helpers of tn_moments: hardware seed + two Newton steps (the seeds are good to ~2^-26), no denormal/overflow fix-ups --
+// the callers' arguments are ordinary positive numbers, and a non-finite result is caught by the guards at the end
+__device__ __forceinline__ double fast_rcp(double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  r = fma(fma(-b, r, 1.0), r, r);
+  r = fma(fma(-b, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double fast_div(double a, double b) {
+  const double r = fast_rcp(b), q = a * r;
+  return fma(fma(-b, q, a), r, q);
+}
+__device__ __forceinline__ double fast_rsqrt(double a) {
+  double r = __builtin_amdgcn_rsq(a);
+  r = fma(r * fma(-a * r, r, 1.0), 0.5, r);
+  r = fma(r * fma(-a * r, r, 1.0), 0.5, r);
+  return r;
+}
+
+// Expectation and variance of TN(mu, tau_p) on [0, inf) (truncated_normal_vector.py:53-73; oracle tn_expectation /
+// tn_variance), in fp64 and branch-free: every VB column update waits for one evaluation of this per unit.
+//   lam = pdf(x) / (1 - cdf(x)),  x = -mu sqrt(tau_p)
+//   x >= 0:  lam = sqrt(2/pi) / erfcx(x / sqrt 2)
+//   x <  0:  lam = pdf(x) / (1 - exp(-x^2/2) erfcx(|x| / sqrt 2) / 2)
+// with erfcx from one degree-26 polynomial in s = (t - 3)/(t + 3) (tn_moments_coeffs.h, generated and checked against
+// 50-digit values by tools/gen_tn_moments_coeffs.py: 4e-16) and exp from Cody-Waite reduction + degree-13 Taylor.  ~120
+// fp64 operations and ~25 VGPRs, against ~400 for exp() + erfc() + three IEEE divisions.  The reference's own fp64
+// value has the same cancellation (x^2 in E, x^4 in Var for mu << 0); agreement with it: tests/test_distributions_gpu.py.
 __device__ inline void tn_moments(double mu, double tau_p, double* e_out, double* v_out) {
-  // lam = pdf(x) / (1 - cdf(x)) = sqrt(2/pi) / erfcx(x / sqrt 2): one scaled-erfc evaluation instead of exp and erfc
-  // (the reference forms pdf / (0.5 erfc), truncated_normal_vector.py:53-73; same value to a few ulp, no underflow in between)
-  const double rt = sqrt(tau_p);
-  const double sig = 1.0 / rt;
+  const double sig = fast_rsqrt(tau_p);
+  const double rt = tau_p * sig;
   const double x = -mu * rt;
-  const double lam = 0.7978845608028654 / erfcx(x * 0.7071067811865476);
-  double e = mu + sig * lam;
+  const double t = fabs(x) * 0.7071067811865476;
+  const double s = fast_div(t - kErfcxA, t + kErfcxA);
+  double f = kErfcxP[kErfcxDeg];
+#pragma unroll
+  for (int k = kErfcxDeg - 1; k >= 0; --k) f = fma(f, s, kErfcxP[k]);       // (1 + 2t) erfcx(t)
+  const double w = fma(2.0, t, 1.0);
+  const double rf = fast_rcp(f);
+  const double lam_pos = 0.7978845608028654 * w * rf;
+  // exp(-y), y = x^2/2 (only the x < 0 side uses it)
+  const double y = fmin(0.5 * x * x, 745.0);
+  const double n = rint(y * 1.4426950408889634);
+  const double r = fma(n, 1.9082149292705877e-10, fma(n, 0.6931471803691238, -y));
+  double e13 = 1.6059043836821613e-10;                                     // 1/13!
+  e13 = fma(e13, r, 2.08767569878681e-09);                                 // 1/12!
+  e13 = fma(e13, r, 2.505210838544172e-08);
+  e13 = fma(e13, r, 2.755731922398589e-07);
+  e13 = fma(e13, r, 2.7557319223985893e-06);
+  e13 = fma(e13, r, 2.48015873015873e-05);
+  e13 = fma(e13, r, 0.0001984126984126984);
+  e13 = fma(e13, r, 0.001388888888888889);
+  e13 = fma(e13, r, 0.008333333333333333);
+  e13 = fma(e13, r, 0.041666666666666664);
+  e13 = fma(e13, r, 0.16666666666666666);
+  e13 = fma(e13, r, 0.5);
+  e13 = fma(e13, r, 1.0);
+  e13 = fma(e13, r, 1.0);
+  const double p = ldexp(e13, -(int)n);
+  const double ecx = f * fast_rcp(w);
+  const double lam_neg = fast_div(0.3989422804014327 * p, fma(-0.5 * p, ecx, 1.0));
+  const double lam = x >= 0.0 ? lam_pos : lam_neg;
+  double e = fma(sig, lam, mu);
   double v = sig * sig * (1.0 - lam * (lam - x));
   if (mu < -30.0 * sig) {
-    e = 1.0 / (fabs(mu) * tau_p);
+    e = fast_rcp(fabs(mu) * tau_p);
     v = e * e;
   }
   *e_out = (isfinite(e) && e >= 0.0) ? e : 0.0;
