@@ -225,7 +225,7 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
       d.f_gen_count = (int)gen.size();
       CHK(dalloc(&d.f_gen_units, std::max<size_t>(gen.size(), 1), false));
       if (!gen.empty()) HIPCHK(hipMemcpy(d.f_gen_units, gen.data(), gen.size() * sizeof(int), hipMemcpyHostToDevice));
-      d.stats_blocks = (d.f_npairs + d.f_nw - 1) / d.f_nw + 2;
+      d.stats_blocks = std::max((d.f_npairs + d.f_nw - 1) / d.f_nw, sweep_vb_blocks(d.f_npairs)) + 2;   // the VB sweep writes its own block count of rows
     }
     CHK(dalloc(&d.stats, (size_t)d.stats_blocks * 4));
   }

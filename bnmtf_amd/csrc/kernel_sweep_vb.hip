@@ -21,7 +21,7 @@
 
 namespace bnmtf {
 
-constexpr int kVbNW = 8;     // 8 waves x 256 VGPRs: the fp64 exp/erfc of the moments do not fit beside 28 slots at 128
+constexpr int kVbNW = 8;      // 8 unit waves: with 16 (<= 128 VGPRs) the fp64 moments spill ~90 registers per lane and the sweep is slower (938 vs 1 219 it/s at cfg5)
 
 template <int EM, int NX>
 __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs& f, float* lds) {
@@ -156,19 +156,24 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
       *reinterpret_cast<float4*>(&xch[(2 * wave + half) * 4]) = o;
     }
     __syncthreads();
-    if (wave == 0 && lane < 2 * NW) {
-      const float4 o = *reinterpret_cast<const float4*>(&xch[lane * 4]);
+    // wave 0: the block's moments, one unit per lane.  Its seven global stores per unit are issued AFTER the barrier that
+    // releases the other waves: the barrier's vmcnt(0) would otherwise make the whole block wait for their completion
+    float4 o = {0.f, 0.f, 0.f, 0.f};
+    float ef = 0.f, vf = 0.f;
+    const bool mom = wave == 0 && lane < 2 * NW;
+    if (mom) {
+      o = *reinterpret_cast<const float4*>(&xch[lane * 4]);
       double e_ = 0.0, v_ = 0.0;
-      if (mgi >= 0) {
-        tn_moments((double)o.x, (double)o.y, &e_, &v_);
-        const size_t p = (size_t)mgi * KP + k;
-        const float ef = (float)e_, vf = (float)v_;
-        a.Xself[p] = ef; a.mu_self[p] = o.x; a.tau_self[p] = o.y; a.var_self[p] = vf; a.S2self[p] = vf + ef * ef;
-        f.vb_asq[p] = o.z; f.vb_vsq[p] = o.w;
-      }
-      ret[lane] = (float)e_;
+      if (mgi >= 0) tn_moments((double)o.x, (double)o.y, &e_, &v_);
+      ef = (float)e_; vf = (float)v_;
+      ret[lane] = ef;
     }
     __syncthreads();                     // also lands the next panel (vmcnt) and retires this one
+    if (mom && mgi >= 0) {
+      const size_t p = (size_t)mgi * KP + k;
+      a.Xself[p] = ef; a.mu_self[p] = o.x; a.tau_self[p] = o.y; a.var_self[p] = vf; a.S2self[p] = vf + ef * ef;
+      f.vb_asq[p] = o.z; f.vb_vsq[p] = o.w;
+    }
     const float xnew = ret[2 * wave + half];
     dprev = xnew - xk;
 #pragma unroll
@@ -210,13 +215,14 @@ __global__ __launch_bounds__(kVbNW * 64, 1) void sweep_vb_kernel(SweepArgs a, Fa
   else sweep_vb_body<kWideMaxSlots, NX>(a, f, lds);      // host guarantees e0 <= kWideMaxSlots
 }
 
+int sweep_vb_blocks(int npairs) { return (npairs + kVbNW - 1) / kVbNW; }
 size_t sweep_vb_lds_bytes(int KP, int pw) { return sizeof(float) * ((size_t)KP * KP + KP + 2 * kVbNW * 5 + 4 * (size_t)pw); }
 
 bool sweep_vb_supported(int KP, int pw) { return sweep_vb_lds_bytes(KP, pw) <= 160 * 1024; }
 
 void launch_sweep_vb(const SweepArgs& a, const FastArgs& f, hipStream_t st) {
   const size_t lds_bytes = sweep_vb_lds_bytes(a.KP, f.pw);
-  const int nblocks = (f.npairs + kVbNW - 1) / kVbNW;
+  const int nblocks = sweep_vb_blocks(f.npairs);
   static bool once[2] = {false, false};
   const int nx = a.KP / 32;
   if (!once[nx - 1]) {
