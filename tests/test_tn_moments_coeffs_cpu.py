@@ -1,0 +1,57 @@
+"""The device's fp64 TN-moments routine (bnmtf_amd/csrc/device_rng.h: tn_moments) restated in NumPy with the committed
+coefficients (bnmtf_amd/csrc/tn_moments_coeffs.h), against the oracle (= the reference's formula,
+truncated_normal_vector.py:53-73) and against 50-digit values.  The GPU side of the same check: tests/test_distributions_gpu.py."""
+import importlib.util
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import bnmtf_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _gen():
+    spec = importlib.util.spec_from_file_location("gen_tn", os.path.join(ROOT, "tools", "gen_tn_moments_coeffs.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _header_coeffs():
+    txt = open(os.path.join(ROOT, "bnmtf_amd", "csrc", "tn_moments_coeffs.h")).read()
+    body = re.search(r"kErfcxP\[\d+\] = \{(.*?)\};", txt, re.S).group(1)
+    P = [float(x) for x in body.replace("\n", " ").split(",") if x.strip()]
+    deg = int(re.search(r"kErfcxDeg = (\d+)", txt).group(1))
+    assert len(P) == deg + 1
+    return P
+
+
+def test_routine_matches_the_oracle_formula():
+    g = _gen()
+    P = _header_coeffs()
+    rs = np.random.RandomState(1)
+    mu = np.concatenate([rs.randn(4000) * 4, -np.abs(rs.randn(1000)) * 25, np.linspace(-35, 35, 141)])
+    tau = np.exp(rs.randn(mu.size))
+    e, v = g.moments_fp64(mu, tau, P)
+    eo, vo = O.tn_expectation(mu, tau), O.tn_variance(mu, tau)
+    np.testing.assert_allclose(e, eo, rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(v, vo, rtol=2e-6, atol=1e-300)      # 1 - lam (lam - x) cancels like x^4 near the -30 sigma switch
+
+
+def test_erfcx_polynomial_against_mpmath():
+    mp = pytest.importorskip("mpmath")
+    g = _gen()
+    P = _header_coeffs()
+    mp.mp.dps = 40
+    worst = 0.0
+    for t in np.concatenate([np.linspace(0, 10, 201), [15.0, 30.0, 100.0, 1e4]]):
+        s = (t - g.A) / (t + g.A)
+        f = P[-1]
+        for c in P[-2::-1]:
+            f = f * s + c
+        ref = mp.exp(mp.mpf(float(t)) ** 2) * mp.erfc(mp.mpf(float(t)))
+        worst = max(worst, abs((mp.mpf(f / (1 + 2 * t)) - ref) / ref))
+    assert worst < 6e-16
