@@ -112,3 +112,24 @@ def test_block_shape_variants_draw_the_same_chain(monkeypatch, I, J, K, env):
         b.close()
     for x, y in zip(out["default"], out["plain"]):
         assert np.array_equal(x, y)
+
+
+def test_inner_extent_beyond_the_on_chip_panel_falls_back_to_the_generic_kernel():
+    """A factor with more than 9184 rows does not fit the on-chip kernels' LDS panel (kChipPanelStride): the direction that
+    gathers from it runs the generic kernel.  Same results as the oracle (mode update), no error."""
+    I, J, K = 40, 9400, 6
+    rs = np.random.RandomState(9)
+    R = rs.exponential(1.0, (I, K)) @ rs.exponential(1.0, (J, K)).T + rs.randn(I, J)
+    M = (rs.rand(I, J) > 0.2).astype(float)
+    M[rs.randint(I, size=J), np.arange(J)] = 1
+    b = bnmf_gibbs_optimised(R, M, K, PRI, verbose=False, seed=1)
+    b.U, b.V, b.tau = rs.exponential(1.0, (I, K)), rs.exponential(1.0, (J, K)), 1.0     # at the data's scale (no collapse to zero)
+    o = O.BNMFGibbsOracle(R, M, K, PRI)
+    o.U, o.V, o.tau = b.U.copy(), b.V.copy(), b.tau
+    b.run(3, update="mode")
+    o.run(3, draw=False)
+    assert o.U.max() > 0.1 and o.V.max() > 0.1
+    np.testing.assert_allclose(b.all_tau[-1], o.tau, rtol=2e-4)
+    assert np.abs(b.U - o.U).max() <= 2e-3 * np.abs(o.U).max() and np.abs(b.V - o.V).max() <= 2e-3 * np.abs(o.V).max()
+    b.run(2)                                   # draws through the same path
+    assert np.isfinite(b.U).all() and b.U.min() >= 0
