@@ -40,6 +40,66 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l5 = lane & 31;
+  const int chunks2 = (2 * PW) / 256;
+  const uint32_t buf_b = (uint32_t)(2 * PW) * 4u;           // bytes between the two buffers
+  if (wave == NW) {
+    // The service wave: it owns no units, so it has the registers for the fp64 moments and the time for the LDS-DMA.
+    // It issues every piece of every panel (a (E, S2) pair panel is 66 KiB: issued by the unit waves that was eight
+    // pieces per wave and column, each blocking its wave for 150-250 cycles) and, between the two barriers of a column,
+    // evaluates the block's moments, one unit per lane.  Same barrier sequence as the unit waves.
+    const int K = a.K;
+    int mgi = -1;
+    if (lane < 2 * NW) {
+      const int pr = blockIdx.x * NW + (lane >> 1);
+      const int uu = pr < f.npairs ? f.unit_map[2 * pr + (lane & 1)] : -1;
+      mgi = uu >= 0 ? a.n0 + uu : -1;
+    }
+    const uint32_t stride_b = (uint32_t)f.ld2_o * 8u;
+    const __amdgpu_buffer_rsrc_t rs2 = panel_rsrc(f.XoT2, (size_t)(KP / 2) * f.ld2_o * 8);
+    const __amdgpu_buffer_rsrc_t rsx = panel_rsrc(f.XoS, (size_t)KP * f.ld2_o * 8);
+    stage_panel_buf<1>(rs2, 0u, pan, chunks2, 0, lane * 16);
+    __syncthreads();
+    for (int kp = 0; kp < KP / 2; ++kp) {
+      if (kp + 1 < KP / 2) stage_panel_buf<1>(rs2, (uint32_t)(kp + 1) * stride_b, pan + (size_t)((kp + 1) & 1) * 2 * PW, chunks2, 0, lane * 16);
+      __syncthreads();
+    }
+    stage_panel_buf<1>(rsx, 0u, pan, chunks2, 0, lane * 16);
+    __syncthreads();
+#ifdef BNMTF_PHASE_TIMING
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = tick(0.f);
+#endif
+    for (int k = 0; k < K; ++k) {
+      if (k + 1 < K) stage_panel_buf<1>(rsx, (uint32_t)(k + 1) * stride_b, pan + (size_t)((k + 1) & 1) * 2 * PW, chunks2, 0, lane * 16);
+      // first barrier of the column without a vmcnt wait: the pieces just issued land while the moments are evaluated
+      // (the second barrier carries the vmcnt(0))
+      TICK(0, 0.f);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      TICK(1, 0.f);
+      float4 o = {0.f, 0.f, 0.f, 0.f};
+      float ef = 0.f, vf = 0.f;
+      if (lane < 2 * NW) {
+        o = *reinterpret_cast<const float4*>(&xch[lane * 4]);
+        double e_ = 0.0, v_ = 0.0;
+        if (mgi >= 0) tn_moments((double)o.x, (double)o.y, &e_, &v_);
+        ef = (float)e_; vf = (float)v_;
+        ret[lane] = ef;
+      }
+      TICK(2, ef);
+      __syncthreads();                   // lands the next panel (vmcnt) and releases the unit waves
+      TICK(3, ef);
+      if (lane < 2 * NW && mgi >= 0) {   // the seven stores per unit go out behind the barrier: nobody waits for them
+        const size_t p = (size_t)mgi * KP + k;
+        a.Xself[p] = ef; a.mu_self[p] = o.x; a.tau_self[p] = o.y; a.var_self[p] = vf; a.S2self[p] = vf + ef * ef;
+        f.vb_asq[p] = o.z; f.vb_vsq[p] = o.w;
+      }
+    }
+#ifdef BNMTF_PHASE_TIMING
+    if (blockIdx.x % 101 == 0 && lane == 0)
+      printf("vb block %d service wave: dma issue %llu  wait1 %llu  moments %llu  wait2 %llu (cycles, %d columns)\n", (int)blockIdx.x, ph[0], ph[1], ph[2], ph[3], K);
+#endif
+    if (f.stats) __syncthreads();
+    return;
+  }
   const int pair = blockIdx.x * NW + wave;
   const bool wave_on = pair < f.npairs;
   const uint32_t base = wave_on ? f.pair_base[pair] : 0u;
@@ -75,25 +135,11 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
   }
   for (int t = tid; t < KP * KP; t += NW * 64) Cs[t] = a.C32[t];
   if (tid < KP) c2s[tid] = (float)a.colsum2_o[tid];
-  // wave 0, lane un: the unit it evaluates the moments for
-  int mgi = -1;
-  if (wave == 0 && lane < 2 * NW) {
-    const int pr = blockIdx.x * NW + (lane >> 1);
-    const int uu = pr < f.npairs ? f.unit_map[2 * pr + (lane & 1)] : -1;
-    mgi = uu >= 0 ? a.n0 + uu : -1;
-  }
-
-  const int chunks2 = (2 * PW) / 256;
-  const uint32_t buf_b = (uint32_t)(2 * PW) * 4u;           // bytes between the two buffers
   // ------------------------------------------------------------ pre-pass: q = E[U_i] . E[V_j]  (pair panels of E)
   {
-    const uint32_t stride_b = (uint32_t)f.ld2_o * 8u;
-    const __amdgpu_buffer_rsrc_t rs2 = panel_rsrc(f.XoT2, (size_t)(KP / 2) * f.ld2_o * 8);
-    stage_panel_buf<NW>(rs2, 0u, pan, chunks2, wave, lane * 16);
     __syncthreads();
     const int npair = KP / 2;
     for (int kp = 0; kp < npair; ++kp) {
-      if (kp + 1 < npair) stage_panel_buf<NW>(rs2, (uint32_t)(kp + 1) * stride_b, pan + (size_t)((kp + 1) & 1) * 2 * PW, chunks2, wave, lane * 16);
       const uint32_t boff = (uint32_t)(kp & 1) * buf_b;
       const int k0 = 2 * kp, k1 = 2 * kp + 1;
       const float xs0 = (NX == 2 && k0 >= 32) ? x[NX - 1] : x[0];
@@ -113,13 +159,12 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
   }
 
   // ------------------------------------------------------------ the K sequential columns, panels of (E_k, S2_k)
-  const __amdgpu_buffer_rsrc_t rsx = panel_rsrc(f.XoS, (size_t)KP * f.ld2_o * 8);
-  const uint32_t cstride_b = (uint32_t)f.ld2_o * 8u;
-  stage_panel_buf<NW>(rsx, 0u, pan, chunks2, wave, lane * 16);
   __syncthreads();
+#ifdef BNMTF_PHASE_TIMING
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = tick(q2[0].x);
+#endif
   float dprev = 0.f;
   for (int k = 0; k < K; ++k) {
-    if (k + 1 < K) stage_panel_buf<NW>(rsx, (uint32_t)(k + 1) * cstride_b, pan + (size_t)((k + 1) & 1) * 2 * PW, chunks2, wave, lane * 16);
     const uint32_t boff = (uint32_t)(k & 1) * buf_b;
     const float xsel = (NX == 2 && k >= 32) ? x[NX - 1] : x[0];
     const float xk = half_bcast(xsel, k & 31, half);
@@ -127,7 +172,7 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
     const f32x2 dp2 = {dprev, dprev};
 #pragma unroll
     for (int h = 0; h < EH; ++h) q2[h] = pk_fma(dp2, vp2[h], q2[h]);
-    __builtin_amdgcn_sched_barrier(0);
+    TICK(0, q2[0].x);
     // (B, C) gather (E_jk, S2_jk); sum q E, sum E^2, sum S2
     f32x2 qv2 = {0.f, 0.f}, vv2 = {0.f, 0.f}, ss2 = {0.f, 0.f};
 #pragma unroll
@@ -143,7 +188,7 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
     float corr_t = fmaf(-xk, vv_t, qv2.x + qv2.y);
 #pragma unroll
     for (int nx = 0; nx < NX; ++nx) corr_t = fmaf(-x[nx], Cs[k * KP + l5 + 32 * nx], corr_t);   // all l: the l = k term is put back below
-    __builtin_amdgcn_sched_barrier(0);
+    TICK(1, corr_t);
     corr_t = half_sum_upper(corr_t);     // right in lanes 16-31 of the half
     vv_t = half_sum_upper(vv_t);
     ss_t = half_sum_upper(ss_t);
@@ -155,25 +200,11 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
       float4 o; o.x = numer / tau_p; o.y = tau_p; o.z = ss_t; o.w = vv_t;
       *reinterpret_cast<float4*>(&xch[(2 * wave + half) * 4]) = o;
     }
+    TICK(2, numer);
     __syncthreads();
-    // wave 0: the block's moments, one unit per lane.  Its seven global stores per unit are issued AFTER the barrier that
-    // releases the other waves: the barrier's vmcnt(0) would otherwise make the whole block wait for their completion
-    float4 o = {0.f, 0.f, 0.f, 0.f};
-    float ef = 0.f, vf = 0.f;
-    const bool mom = wave == 0 && lane < 2 * NW;
-    if (mom) {
-      o = *reinterpret_cast<const float4*>(&xch[lane * 4]);
-      double e_ = 0.0, v_ = 0.0;
-      if (mgi >= 0) tn_moments((double)o.x, (double)o.y, &e_, &v_);
-      ef = (float)e_; vf = (float)v_;
-      ret[lane] = ef;
-    }
-    __syncthreads();                     // also lands the next panel (vmcnt) and retires this one
-    if (mom && mgi >= 0) {
-      const size_t p = (size_t)mgi * KP + k;
-      a.Xself[p] = ef; a.mu_self[p] = o.x; a.tau_self[p] = o.y; a.var_self[p] = vf; a.S2self[p] = vf + ef * ef;
-      f.vb_asq[p] = o.z; f.vb_vsq[p] = o.w;
-    }
+    TICK(3, numer);
+    __syncthreads();                     // the service wave evaluates the moments between these two barriers
+    TICK(4, numer);
     const float xnew = ret[2 * wave + half];
     dprev = xnew - xk;
 #pragma unroll
@@ -181,6 +212,10 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
       if (l5 + 32 * nx == k) x[nx] = xnew;
   }
 
+#ifdef BNMTF_PHASE_TIMING
+  if (blockIdx.x % 101 == 0 && (tid & 127) == 0)
+    printf("vb block %d wave %d EM %d: A %llu  BC %llu  reduce+post %llu  wait1 %llu  window %llu (cycles, %d columns)\n", (int)blockIdx.x, wave, EM, ph[0], ph[1], ph[2], ph[3], ph[4], K);
+#endif
   // ------------------------------------------------------------ the three sums of the SSE identity (cols sweep)
   if (f.stats) {
     double px = 0.0, sq = 0.0, sq2 = 0.0;
@@ -204,10 +239,11 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
 }
 
 template <int NX>
-__global__ __launch_bounds__(kVbNW * 64, 1) void sweep_vb_kernel(SweepArgs a, FastArgs f) {
+__global__ __launch_bounds__((kVbNW + 1) * 64, 1) void sweep_vb_kernel(SweepArgs a, FastArgs f) {
   extern __shared__ float lds[];
-  const int pr = blockIdx.x * kVbNW + (int)(threadIdx.x >> 6);
-  const int e0 = __builtin_amdgcn_readfirstlane(pr < f.npairs ? (int)f.pair_E[pr] : 0);
+  const int wv = (int)(threadIdx.x >> 6);
+  const int pr = blockIdx.x * kVbNW + wv;
+  const int e0 = __builtin_amdgcn_readfirstlane((wv < kVbNW && pr < f.npairs) ? (int)f.pair_E[pr] : 0);   // the service wave runs in the smallest class
   if (e0 <= 8) sweep_vb_body<8, NX>(a, f, lds);
   else if (e0 <= 16) sweep_vb_body<16, NX>(a, f, lds);
   else if (e0 <= 24) sweep_vb_body<24, NX>(a, f, lds);
@@ -231,8 +267,8 @@ void launch_sweep_vb(const SweepArgs& a, const FastArgs& f, hipStream_t st) {
     once[nx - 1] = true;
   }
   if (nblocks <= 0) return;
-  if (nx == 1) hipLaunchKernelGGL((sweep_vb_kernel<1>), dim3(nblocks), dim3(kVbNW * 64), lds_bytes, st, a, f);
-  else         hipLaunchKernelGGL((sweep_vb_kernel<2>), dim3(nblocks), dim3(kVbNW * 64), lds_bytes, st, a, f);
+  if (nx == 1) hipLaunchKernelGGL((sweep_vb_kernel<1>), dim3(nblocks), dim3((kVbNW + 1) * 64), lds_bytes, st, a, f);
+  else         hipLaunchKernelGGL((sweep_vb_kernel<2>), dim3(nblocks), dim3((kVbNW + 1) * 64), lds_bytes, st, a, f);
 }
 
 // ELBO / exp_square_diff pieces of one sweep (bnmf_vb_optimised.py:163-177, 185-187), one wave per unit, lane = column:
