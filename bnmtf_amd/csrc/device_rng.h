@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include "kernels.h"
 #include "tn_moments_coeffs.h"
+#include "tn_moments_f32_coeffs.h"
 
 namespace bnmtf {
 
@@ -197,6 +198,46 @@ __device__ inline void tn_moments(double mu, double tau_p, double* e_out, double
   }
   *e_out = (isfinite(e) && e >= 0.0) ? e : 0.0;
   *v_out = (isfinite(v) && v >= 0.0) ? v : 0.0;
+}
+
+// The sweeps' version: fp32 in, fp32 out, ~70 fp32 instructions instead of ~120 fp64 ones.  E = sigma r(x), Var = sigma^2
+// h(x) with r = lam - x and h = 1 - lam (lam - x) approximated directly (polynomials in s = (x - 3)/(x + 3) for x > 0;
+// exp + an erfcx polynomial for x <= 0, where nothing cancels), so the x^2 / x^4 cancellation that makes the textbook
+// formula need fp64 for mu << 0 never happens.  Against 40-digit values: 2.5e-7 (E), 1e-6 (Var) over x in [-40, 30]
+// (tools/gen_tn_moments_f32_coeffs.py; tests/test_tn_moments_coeffs_cpu.py) -- the results are stored as fp32 anyway.
+__device__ __forceinline__ void tn_moments_f32(float mu, float tau_p, float* e_out, float* v_out) {
+  const float sig = __builtin_amdgcn_rsqf(tau_p);
+  const float x = -mu * (tau_p * sig);
+  const float ax = fabsf(x);
+  // x > 0
+  const float s = (ax - kTnF32A) * __builtin_amdgcn_rcpf(ax + kTnF32A);
+  float pr = kTnF32R[kTnF32RDeg], ph = kTnF32H[kTnF32HDeg];
+#pragma unroll
+  for (int k = kTnF32RDeg - 1; k >= 0; --k) pr = fmaf(pr, s, kTnF32R[k]);
+#pragma unroll
+  for (int k = kTnF32HDeg - 1; k >= 0; --k) ph = fmaf(ph, s, kTnF32H[k]);
+  const float r_pos = pr * __builtin_amdgcn_rcpf(1.0f + ax);
+  const float h_pos = ph * __builtin_amdgcn_rcpf(fmaf(ax, ax, 1.0f));
+  // x <= 0
+  const float t = ax * 0.70710678f;
+  const float st = (t - kTnF32A) * __builtin_amdgcn_rcpf(t + kTnF32A);
+  float pe = kTnF32E[kTnF32EDeg];
+#pragma unroll
+  for (int k = kTnF32EDeg - 1; k >= 0; --k) pe = fmaf(pe, st, kTnF32E[k]);
+  const float ecx = pe * __builtin_amdgcn_rcpf(fmaf(2.0f, t, 1.0f));
+  const float p = __builtin_amdgcn_exp2f(-0.72134752f * ax * ax);          // exp(-x^2/2)
+  const float lam = 0.39894228f * p * __builtin_amdgcn_rcpf(fmaf(-0.5f * p, ecx, 1.0f));
+  const float r_neg = lam + ax;
+  const float h_neg = fmaf(-lam, r_neg, 1.0f);
+  const float r = x > 0.0f ? r_pos : r_neg, h = x > 0.0f ? h_pos : h_neg;
+  float e = sig * r;
+  float v = sig * sig * h;
+  if (mu < -30.0f * sig) {
+    e = __builtin_amdgcn_rcpf(fabsf(mu) * tau_p);
+    v = e * e;
+  }
+  *e_out = (isfinite(e) && e >= 0.0f) ? e : 0.0f;
+  *v_out = (isfinite(v) && v >= 0.0f) ? v : 0.0f;
 }
 
 }  // namespace bnmtf

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void sweep_generic_kernel(SweepArgs a) {
       xnew = fmaxf((tau_p > 0.f && mu > 0.f) ? mu : 0.f, a.min_x);
     } else {
       double e_, v_;
-      if (a.vb_moments) tn_moments((double)mu, (double)tau_p, &e_, &v_);
+      if (a.vb_moments) { float ef_, vf_; tn_moments_f32(mu, tau_p, &ef_, &vf_); e_ = (double)ef_; v_ = (double)vf_; }   // the sweeps' fp32 routine (device_rng.h)
       else { e_ = (double)xk; v_ = (double)__shfl(var_in, k, 64); }       // update_U(k) without update_exp_U(k)
       xnew = (float)e_;
       if (lane == k) { mu_l = mu; tau_l = tau_p; var_l = (float)v_; }

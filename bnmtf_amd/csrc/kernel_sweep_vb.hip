@@ -1,5 +1,5 @@
 // K3-VB: the variational half sweep (bnmf_vb_optimised.py:189-211, update_U(k) + update_exp_U(k) for k = 0..K-1)
-// in the register/LDS-resident shape of sweep_chip.inc: 16 units per block, 8 waves (the fp64 moments need the 256-VGPR budget).
+// in the register/LDS-resident shape of sweep_chip.inc (block shapes: below).
 //
 // Per unit i and column k (E = expectations, S2 = var + E^2 of the OTHER factor):
 //   tau_ik = exptau * sum_j M_ij S2_jk                = exptau * (colsum2_k - sum_{j in miss(i)} S2_jk)
@@ -21,11 +21,13 @@
 
 namespace bnmtf {
 
-constexpr int kVbNW = 8;      // 8 unit waves: with 16 (<= 128 VGPRs) the fp64 moments spill ~90 registers per lane and the sweep is slower (938 vs 1 219 it/s at cfg5)
+// Two block shapes (the panels a block stages are L2/fabric traffic: 6.3 MB per block and sweep at cfg5, so units per
+// block is what the large sizes pay for):
+//   16 unit waves, 32 units per block (<= 128 VGPRs; wave 0 also evaluates the moments)    -- when that fills the chip;
+//    8 unit waves + 2 service waves (staging of every panel, the first one the moments)     -- smaller problems.
 
-template <int EM, int NX>
+template <int EM, int NX, int NW, int NS>
 __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs& f, float* lds) {
-  constexpr int NW = kVbNW;
   constexpr int KP = NX * 32;
   constexpr int EH = EM / 2;
   static_assert(EM % 2 == 0, "slots are processed in pairs");
@@ -42,14 +44,15 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
   const int half = lane >> 5, l5 = lane & 31;
   const int chunks2 = (2 * PW) / 256;
   const uint32_t buf_b = (uint32_t)(2 * PW) * 4u;           // bytes between the two buffers
-  if (wave == NW) {
-    // The service wave: it owns no units, so it has the registers for the fp64 moments and the time for the LDS-DMA.
+  if (NS > 0 && wave >= NW) {
+    const int sid = wave - NW;               // NS service waves share the staging; the first one also does the moments
+    // The service waves: they own no units, so it has the registers for the fp64 moments and the time for the LDS-DMA.
     // It issues every piece of every panel (a (E, S2) pair panel is 66 KiB: issued by the unit waves that was eight
     // pieces per wave and column, each blocking its wave for 150-250 cycles) and, between the two barriers of a column,
     // evaluates the block's moments, one unit per lane.  Same barrier sequence as the unit waves.
     const int K = a.K;
     int mgi = -1;
-    if (lane < 2 * NW) {
+    if (sid == 0 && lane < 2 * NW) {
       const int pr = blockIdx.x * NW + (lane >> 1);
       const int uu = pr < f.npairs ? f.unit_map[2 * pr + (lane & 1)] : -1;
       mgi = uu >= 0 ? a.n0 + uu : -1;
@@ -57,19 +60,19 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
     const uint32_t stride_b = (uint32_t)f.ld2_o * 8u;
     const __amdgpu_buffer_rsrc_t rs2 = panel_rsrc(f.XoT2, (size_t)(KP / 2) * f.ld2_o * 8);
     const __amdgpu_buffer_rsrc_t rsx = panel_rsrc(f.XoS, (size_t)KP * f.ld2_o * 8);
-    stage_panel_buf<1>(rs2, 0u, pan, chunks2, 0, lane * 16);
+    stage_panel_buf<(NS > 0 ? NS : 1)>(rs2, 0u, pan, chunks2, sid, lane * 16);
     __syncthreads();
     for (int kp = 0; kp < KP / 2; ++kp) {
-      if (kp + 1 < KP / 2) stage_panel_buf<1>(rs2, (uint32_t)(kp + 1) * stride_b, pan + (size_t)((kp + 1) & 1) * 2 * PW, chunks2, 0, lane * 16);
+      if (kp + 1 < KP / 2) stage_panel_buf<(NS > 0 ? NS : 1)>(rs2, (uint32_t)(kp + 1) * stride_b, pan + (size_t)((kp + 1) & 1) * 2 * PW, chunks2, sid, lane * 16);
       __syncthreads();
     }
-    stage_panel_buf<1>(rsx, 0u, pan, chunks2, 0, lane * 16);
+    stage_panel_buf<(NS > 0 ? NS : 1)>(rsx, 0u, pan, chunks2, sid, lane * 16);
     __syncthreads();
 #ifdef BNMTF_PHASE_TIMING
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = tick(0.f);
 #endif
     for (int k = 0; k < K; ++k) {
-      if (k + 1 < K) stage_panel_buf<1>(rsx, (uint32_t)(k + 1) * stride_b, pan + (size_t)((k + 1) & 1) * 2 * PW, chunks2, 0, lane * 16);
+      if (k + 1 < K) stage_panel_buf<(NS > 0 ? NS : 1)>(rsx, (uint32_t)(k + 1) * stride_b, pan + (size_t)((k + 1) & 1) * 2 * PW, chunks2, sid, lane * 16);
       // first barrier of the column without a vmcnt wait: the pieces just issued land while the moments are evaluated
       // (the second barrier carries the vmcnt(0))
       TICK(0, 0.f);
@@ -77,24 +80,22 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
       TICK(1, 0.f);
       float4 o = {0.f, 0.f, 0.f, 0.f};
       float ef = 0.f, vf = 0.f;
-      if (lane < 2 * NW) {
+      if (sid == 0 && lane < 2 * NW) {
         o = *reinterpret_cast<const float4*>(&xch[lane * 4]);
-        double e_ = 0.0, v_ = 0.0;
-        if (mgi >= 0) tn_moments((double)o.x, (double)o.y, &e_, &v_);
-        ef = (float)e_; vf = (float)v_;
+        if (mgi >= 0) tn_moments_f32(o.x, o.y, &ef, &vf);
         ret[lane] = ef;
       }
       TICK(2, ef);
       __syncthreads();                   // lands the next panel (vmcnt) and releases the unit waves
       TICK(3, ef);
-      if (lane < 2 * NW && mgi >= 0) {   // the seven stores per unit go out behind the barrier: nobody waits for them
+      if (sid == 0 && lane < 2 * NW && mgi >= 0) {   // the seven stores per unit go out behind the barrier: nobody waits for them
         const size_t p = (size_t)mgi * KP + k;
         a.Xself[p] = ef; a.mu_self[p] = o.x; a.tau_self[p] = o.y; a.var_self[p] = vf; a.S2self[p] = vf + ef * ef;
         f.vb_asq[p] = o.z; f.vb_vsq[p] = o.w;
       }
     }
 #ifdef BNMTF_PHASE_TIMING
-    if (blockIdx.x % 101 == 0 && lane == 0)
+    if (blockIdx.x % 101 == 0 && lane == 0 && sid == 0)
       printf("vb block %d service wave: dma issue %llu  wait1 %llu  moments %llu  wait2 %llu (cycles, %d columns)\n", (int)blockIdx.x, ph[0], ph[1], ph[2], ph[3], K);
 #endif
     if (f.stats) __syncthreads();
@@ -135,11 +136,22 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
   }
   for (int t = tid; t < KP * KP; t += NW * 64) Cs[t] = a.C32[t];
   if (tid < KP) c2s[tid] = (float)a.colsum2_o[tid];
+  // NS == 0: wave 0, lane un: the unit it evaluates the moments for
+  int mgi = -1;
+  if (NS == 0 && wave == 0 && lane < 2 * NW) {
+    const int pr = blockIdx.x * NW + (lane >> 1);
+    const int uu = pr < f.npairs ? f.unit_map[2 * pr + (lane & 1)] : -1;
+    mgi = uu >= 0 ? a.n0 + uu : -1;
+  }
   // ------------------------------------------------------------ pre-pass: q = E[U_i] . E[V_j]  (pair panels of E)
   {
+    const uint32_t stride_b = (uint32_t)f.ld2_o * 8u;
+    const __amdgpu_buffer_rsrc_t rs2 = panel_rsrc(f.XoT2, (size_t)(KP / 2) * f.ld2_o * 8);
+    if (NS == 0) stage_panel_buf<NW>(rs2, 0u, pan, chunks2, wave, lane * 16);
     __syncthreads();
     const int npair = KP / 2;
     for (int kp = 0; kp < npair; ++kp) {
+      if (NS == 0 && kp + 1 < npair) stage_panel_buf<NW>(rs2, (uint32_t)(kp + 1) * stride_b, pan + (size_t)((kp + 1) & 1) * 2 * PW, chunks2, wave, lane * 16);
       const uint32_t boff = (uint32_t)(kp & 1) * buf_b;
       const int k0 = 2 * kp, k1 = 2 * kp + 1;
       const float xs0 = (NX == 2 && k0 >= 32) ? x[NX - 1] : x[0];
@@ -159,12 +171,16 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
   }
 
   // ------------------------------------------------------------ the K sequential columns, panels of (E_k, S2_k)
+  const __amdgpu_buffer_rsrc_t rsx = panel_rsrc(f.XoS, (size_t)KP * f.ld2_o * 8);
+  const uint32_t cstride_b = (uint32_t)f.ld2_o * 8u;
+  if (NS == 0) stage_panel_buf<NW>(rsx, 0u, pan, chunks2, wave, lane * 16);
   __syncthreads();
 #ifdef BNMTF_PHASE_TIMING
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = tick(q2[0].x);
 #endif
   float dprev = 0.f;
   for (int k = 0; k < K; ++k) {
+    if (NS == 0 && k + 1 < K) stage_panel_buf<NW>(rsx, (uint32_t)(k + 1) * cstride_b, pan + (size_t)((k + 1) & 1) * 2 * PW, chunks2, wave, lane * 16);
     const uint32_t boff = (uint32_t)(k & 1) * buf_b;
     const float xsel = (NX == 2 && k >= 32) ? x[NX - 1] : x[0];
     const float xk = half_bcast(xsel, k & 31, half);
@@ -203,7 +219,23 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
     TICK(2, numer);
     __syncthreads();
     TICK(3, numer);
-    __syncthreads();                     // the service wave evaluates the moments between these two barriers
+    // between the two barriers of a column the block's moments are evaluated, one unit per lane: by the first service
+    // wave, or (NS == 0) by wave 0.  The seven global stores per unit go out behind the second barrier, whose vmcnt(0)
+    // would otherwise make the whole block wait for them.
+    float4 o = {0.f, 0.f, 0.f, 0.f};
+    float ef = 0.f, vf = 0.f;
+    const bool mom = NS == 0 && wave == 0 && lane < 2 * NW;
+    if (mom) {
+      o = *reinterpret_cast<const float4*>(&xch[lane * 4]);
+      if (mgi >= 0) tn_moments_f32(o.x, o.y, &ef, &vf);
+      ret[lane] = ef;
+    }
+    __syncthreads();                     // also lands the next panel (vmcnt) and retires this one
+    if (mom && mgi >= 0) {
+      const size_t p = (size_t)mgi * KP + k;
+      a.Xself[p] = ef; a.mu_self[p] = o.x; a.tau_self[p] = o.y; a.var_self[p] = vf; a.S2self[p] = vf + ef * ef;
+      f.vb_asq[p] = o.z; f.vb_vsq[p] = o.w;
+    }
     TICK(4, numer);
     const float xnew = ret[2 * wave + half];
     dprev = xnew - xk;
@@ -238,37 +270,37 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
   }
 }
 
-template <int NX>
-__global__ __launch_bounds__((kVbNW + 1) * 64, 1) void sweep_vb_kernel(SweepArgs a, FastArgs f) {
+template <int NX, int NW, int NS>
+__global__ __launch_bounds__((NW + NS) * 64, 1) void sweep_vb_kernel(SweepArgs a, FastArgs f) {
   extern __shared__ float lds[];
   const int wv = (int)(threadIdx.x >> 6);
-  const int pr = blockIdx.x * kVbNW + wv;
-  const int e0 = __builtin_amdgcn_readfirstlane((wv < kVbNW && pr < f.npairs) ? (int)f.pair_E[pr] : 0);   // the service wave runs in the smallest class
-  if (e0 <= 8) sweep_vb_body<8, NX>(a, f, lds);
-  else if (e0 <= 16) sweep_vb_body<16, NX>(a, f, lds);
-  else if (e0 <= 24) sweep_vb_body<24, NX>(a, f, lds);
-  else if (e0 <= 28) sweep_vb_body<28, NX>(a, f, lds);
-  else sweep_vb_body<kWideMaxSlots, NX>(a, f, lds);      // host guarantees e0 <= kWideMaxSlots
+  const int pr = blockIdx.x * NW + wv;
+  const int e0 = __builtin_amdgcn_readfirstlane((wv < NW && pr < f.npairs) ? (int)f.pair_E[pr] : 0);   // service waves run in the smallest class
+  if (e0 <= 8) sweep_vb_body<8, NX, NW, NS>(a, f, lds);
+  else if (e0 <= 16) sweep_vb_body<16, NX, NW, NS>(a, f, lds);
+  else if (e0 <= 24) sweep_vb_body<24, NX, NW, NS>(a, f, lds);
+  else if (e0 <= 28) sweep_vb_body<28, NX, NW, NS>(a, f, lds);
+  else sweep_vb_body<kWideMaxSlots, NX, NW, NS>(a, f, lds);      // host guarantees e0 <= kWideMaxSlots
 }
 
-int sweep_vb_blocks(int npairs) { return (npairs + kVbNW - 1) / kVbNW; }
-size_t sweep_vb_lds_bytes(int KP, int pw) { return sizeof(float) * ((size_t)KP * KP + KP + 2 * kVbNW * 5 + 4 * (size_t)pw); }
+int sweep_vb_blocks(int npairs, int nw) { return (npairs + nw - 1) / nw; }
+static size_t sweep_vb_lds_bytes(int KP, int pw) { return sizeof(float) * ((size_t)KP * KP + KP + 2 * 16 * 5 + 4 * (size_t)pw); }
 
 bool sweep_vb_supported(int KP, int pw) { return sweep_vb_lds_bytes(KP, pw) <= 160 * 1024; }
 
+template <int NX, int NW, int NS>
+static void launch_vb_inst(const SweepArgs& a, const FastArgs& f, hipStream_t st) {
+  static bool once = false;
+  if (!once) { (void)hipFuncSetAttribute((const void*)sweep_vb_kernel<NX, NW, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+  const int nblocks = sweep_vb_blocks(f.npairs, NW);
+  if (nblocks > 0) hipLaunchKernelGGL((sweep_vb_kernel<NX, NW, NS>), dim3(nblocks), dim3((NW + NS) * 64), sweep_vb_lds_bytes(a.KP, f.pw), st, a, f);
+}
+
+// f.nw = 16: 16 unit waves per block; anything else: 8 unit waves + 2 service waves
 void launch_sweep_vb(const SweepArgs& a, const FastArgs& f, hipStream_t st) {
-  const size_t lds_bytes = sweep_vb_lds_bytes(a.KP, f.pw);
-  const int nblocks = sweep_vb_blocks(f.npairs);
-  static bool once[2] = {false, false};
   const int nx = a.KP / 32;
-  if (!once[nx - 1]) {
-    if (nx == 1) (void)hipFuncSetAttribute((const void*)sweep_vb_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    else         (void)hipFuncSetAttribute((const void*)sweep_vb_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    once[nx - 1] = true;
-  }
-  if (nblocks <= 0) return;
-  if (nx == 1) hipLaunchKernelGGL((sweep_vb_kernel<1>), dim3(nblocks), dim3((kVbNW + 1) * 64), lds_bytes, st, a, f);
-  else         hipLaunchKernelGGL((sweep_vb_kernel<2>), dim3(nblocks), dim3((kVbNW + 1) * 64), lds_bytes, st, a, f);
+  if (f.nw == 16) { if (nx == 1) launch_vb_inst<1, 16, 0>(a, f, st); else launch_vb_inst<2, 16, 0>(a, f, st); }
+  else            { if (nx == 1) launch_vb_inst<1, 8, 2>(a, f, st);  else launch_vb_inst<2, 8, 2>(a, f, st); }
 }
 
 // ELBO / exp_square_diff pieces of one sweep (bnmf_vb_optimised.py:163-177, 185-187), one wave per unit, lane = column:

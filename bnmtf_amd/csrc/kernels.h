@@ -101,7 +101,7 @@ bool sweep_wide_supported(int KP, int pw);
 void launch_sweep_wide(const SweepArgs& a, const FastArgs& f, hipStream_t st);
 // VB sweep in the 16-wave shape (kernel_sweep_vb.hip) and the ELBO pieces it leaves to a second pass
 bool sweep_vb_supported(int KP, int pw);
-int sweep_vb_blocks(int npairs);             // blocks (= rows of FastArgs::stats) of a VB sweep over npairs pairs
+int sweep_vb_blocks(int npairs, int nw = 8);  // blocks (= rows of FastArgs::stats) of a VB sweep over npairs pairs with nw unit waves per block (16 or 8)
 void launch_sweep_vb(const SweepArgs& a, const FastArgs& f, hipStream_t st);
 void launch_vb_pieces(int n, int n0, int KP, int K, const float* mu, const float* tauq, const float* ex, const float* var,
                       const float* lambda, const float* asq, const float* vsq, double* out, hipStream_t st);
