@@ -55,3 +55,40 @@ def test_erfcx_polynomial_against_mpmath():
         ref = mp.exp(mp.mpf(float(t)) ** 2) * mp.erfc(mp.mpf(float(t)))
         worst = max(worst, abs((mp.mpf(f / (1 + 2 * t)) - ref) / ref))
     assert worst < 6e-16
+
+
+def _gen32():
+    spec = importlib.util.spec_from_file_location("gen_tn32", os.path.join(ROOT, "tools", "gen_tn_moments_f32_coeffs.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _header_f32():
+    txt = open(os.path.join(ROOT, "bnmtf_amd", "csrc", "tn_moments_f32_coeffs.h")).read()
+    out = {}
+    for name in ("kTnF32R", "kTnF32H", "kTnF32E"):
+        body = re.search(name + r"\[\d+\] = \{(.*?)\};", txt, re.S).group(1)
+        out[name] = [float(x.strip().rstrip("f")) for x in body.replace("\n", " ").split(",") if x.strip()]
+        assert len(out[name]) == int(re.search(name + r"Deg = (\d+)", txt).group(1)) + 1
+    return out["kTnF32R"], out["kTnF32H"], out["kTnF32E"]
+
+
+def test_fp32_sweep_routine_matches_the_oracle_formula():
+    """tn_moments_f32 (the routine inside the VB sweeps) in NumPy fp32 with the committed coefficients: fp32-level agreement
+    with the reference's formula over both signs of mu, including mu << 0 where that formula itself needs fp64."""
+    g = _gen32()
+    PR, PH, PE = _header_f32()
+    rs = np.random.RandomState(2)
+    x = np.concatenate([rs.uniform(-12, 29.5, 6000), np.linspace(-40, 29.9, 700)])
+    tau = np.exp(rs.randn(x.size)).astype(np.float32)
+    mu = (-x / np.sqrt(tau.astype(np.float64))).astype(np.float32)
+    e, v = g.moments_f32(mu, tau, PR, PH, PE)
+    eo = O.tn_expectation(mu.astype(np.float64), tau.astype(np.float64))
+    vo = O.tn_variance(mu.astype(np.float64), tau.astype(np.float64))
+    xr = -mu.astype(np.float64) * np.sqrt(tau.astype(np.float64))
+    ok = xr < 29.99                     # away from the reference's -30 sigma switch (the two sides differ by 1e-3 there)
+    np.testing.assert_allclose(e[ok], eo[ok], rtol=2e-6, atol=1e-30)
+    # the oracle's own fp64 variance loses ~x^4 eps for mu << 0; compare where that is below the fp32 level
+    okv = ok & (xr < 12)
+    np.testing.assert_allclose(v[okv], vo[okv], rtol=5e-6, atol=1e-30)
