@@ -104,39 +104,50 @@ __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
 }
 // VB end of iteration (bnmf_vb_optimised.py:181-187, 213-215): exp_square_diff from Gram identities,
 // exptau = alpha_s / beta_s, training-mask metrics, and the O((I+J)K) sums elbo() needs.
-__global__ __launch_bounds__(256) void vb_finish_kernel(VbFinishArgs a) {
-  __shared__ double red[4][13];
+__global__ __launch_bounds__(1024) void vb_finish_kernel(VbFinishArgs a) {
+  __shared__ double red[16][16];
   const int KP = a.KP, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // 13 sums at once: <Cr, Cc>, six columns of the rows-sweep pieces, six of the cols-sweep pieces
-  double v[13];
+  // 16 sums at once: <Cr, Cc>, six columns of the rows-sweep pieces, six of the cols-sweep pieces, and the three
+  // K-term sums (colsum . colsum, colsum2 . colsum2, diag(Cr) . diag(Cc))
+  double v[16];
 #pragma unroll
-  for (int t = 0; t < 13; ++t) v[t] = 0.0;
-  for (int t = threadIdx.x; t < KP * KP; t += 256) v[0] = fma(a.Cr64[t], a.Cc64[t], v[0]);
-  for (int b = threadIdx.x; b < a.nr; b += 256)
+  for (int t = 0; t < 16; ++t) v[t] = 0.0;
+  for (int t = threadIdx.x; t < KP * KP; t += 1024) v[0] = fma(a.Cr64[t], a.Cc64[t], v[0]);
+  for (int b = threadIdx.x; b < a.nr; b += 1024)
 #pragma unroll
     for (int c = 0; c < 6; ++c) v[1 + c] += a.stats_r[(size_t)b * 8 + c];
-  for (int b = threadIdx.x; b < a.nc; b += 256)
+  for (int b = threadIdx.x; b < a.nc; b += 1024)
 #pragma unroll
     for (int c = 0; c < 6; ++c) v[7 + c] += a.stats_c[(size_t)b * 8 + c];
+  if (threadIdx.x < KP) {
+    const int t = threadIdx.x;
+    v[13] = a.sr[t] * a.sc[t];
+    v[14] = a.s2r[t] * a.s2c[t];
+    v[15] = a.Cr64[t * KP + t] * a.Cc64[t * KP + t];
+  }
 #pragma unroll
-  for (int t = 0; t < 13; ++t) {
+  for (int t = 0; t < 16; ++t) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v[t] += __shfl_xor(v[t], m, 64);
     if (lane == 0) red[wave][t] = v[t];
   }
   __syncthreads();
+  // lane (w, t) of the first four waves sums red[w][t] over w by shuffles: tot[t] ends up in red[0][t]
+  if (threadIdx.x < 256) {
+    const int t = threadIdx.x & 15, w = threadIdx.x >> 4;
+    double sw = red[w][t];
+#pragma unroll
+    for (int m = 32; m >= 16; m >>= 1) sw += __shfl_xor(sw, m, 64);      // the four w of this wave
+    red[w][t] = sw;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    double tot[13];
-    for (int t = 0; t < 13; ++t) tot[t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    double tot[16];
+    for (int t = 0; t < 16; ++t) tot[t] = (red[0][t] + red[4][t]) + (red[8][t] + red[12][t]);
     const double dot = tot[0];
     const double* su = &tot[1];
     const double* sv = &tot[7];
-    double sp1 = 0.0, s22 = 0.0, sdd = 0.0;
-    for (int t = 0; t < KP; ++t) {
-      sp1 = fma(a.sr[t], a.sc[t], sp1);
-      s22 = fma(a.s2r[t], a.s2c[t], s22);
-      sdd = fma(a.Cr64[t * KP + t], a.Cc64[t * KP + t], sdd);
-    }
+    const double sp1 = tot[13], s22 = tot[14], sdd = tot[15];
     const double srp = a.acc[0], sp = sp1 - a.acc[1], spp = dot - a.acc[2];
     const double n = a.n_obs;
     const double sse = a.sumR2 - 2.0 * srp + spp;
@@ -154,7 +165,7 @@ __global__ __launch_bounds__(256) void vb_finish_kernel(VbFinishArgs a) {
   }
 }
 void launch_vb_finish(const VbFinishArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(vb_finish_kernel, dim3(1), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(vb_finish_kernel, dim3(1), dim3(1024), 0, st, a);
 }
 
 void launch_finish(const FinishArgs& a, hipStream_t st) {
