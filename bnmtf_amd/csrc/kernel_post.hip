@@ -3,7 +3,7 @@
 //   XT  [KP][ldT]        column k contiguous      -> LDS panel of the other direction's sweep
 //   XT2 [KP/2][ld2][2]   column pairs interleaved -> pre-pass panels (ds_read_b64)
 //   C = X^T X (fp64), column sums                 -> sweep (fp32 copy) and the SSE identity
-// One pass over X: 128 rows per block staged in LDS; per-block Gram partials go to a
+// One pass over X: kPostRows (32) rows per block staged in LDS; per-block Gram partials go to a
 // slab and are summed by gram_reduce_kernel (deterministic, no atomics).
 #include "kernels.h"
 
