@@ -9,6 +9,13 @@
 
 namespace bnmtf {
 
+// tile p of the packed upper triangle (rows of tiles 0 .. NT-1, row y holding tiles (y, y) .. (y, NT-1)) -> (ty, tx)
+__device__ __forceinline__ void tri_tile(int p, int NT, int* ty, int* tx) {
+  int y = 0, rem = p;
+  while (rem >= NT - y) { rem -= NT - y; ++y; }
+  *ty = y; *tx = y + rem;
+}
+
 __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
   constexpr int RB = kPostRows;
   __shared__ float tile0[RB * 68], tile1[RB * 68];     // X rows ; VB: S2 rows
@@ -37,8 +44,12 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
         if (r < nr) a.XT2[((size_t)kp * a.ld2 + r0 + r) * 2 + c] = tile[r * LD + 2 * kp + c];
       }
     if (pass == 0) {
-      const int ty = tid >> 4, tx = tid & 15;
-      if (4 * ty < KP && 4 * tx < KP) {
+      // Gram partial of this block's rows: C is symmetric, so only the 4x4 tiles on and above the diagonal are formed
+      // (NT (NT + 1) / 2 of NT^2, NT = KP / 4), one per thread, and stored packed -- 16 contiguous doubles per tile
+      const int NT = KP / 4, NU = NT * (NT + 1) / 2;
+      if (tid < NU) {
+        int ty, tx;
+        tri_tile(tid, NT, &ty, &tx);
         double acc[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -53,11 +64,11 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = fma(ad[i], bd[j], acc[i][j]);
         }
-        double* out = a.Cpart + (size_t)blockIdx.x * KP * KP;
+        double* out = a.Cpart + ((size_t)blockIdx.x * NU + tid) * 16;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) out[(4 * ty + i) * KP + 4 * tx + j] = acc[i][j];
+          for (int j = 0; j < 4; ++j) out[i * 4 + j] = acc[i][j];
       }
     }
     if (tid < KP) {
@@ -73,12 +84,13 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
   }
 }
 
-// 32 entries per block, 32 partial-slab strides per entry (thread = entry e + 32*g), summed through LDS in a fixed order:
-// KP*KP/32 blocks of 1024 threads (+ one for the column sums), every slab read is a coalesced 256 B row segment.
+// 32 packed entries per block, 32 partial-slab strides per entry (thread = entry e + 32*g), summed through LDS in a fixed
+// order: ceil(PS/32) blocks of 1024 threads (+ one for the column sums), every slab read is a coalesced 256 B segment; a
+// tile above the diagonal is written twice (itself and its mirror).
 __global__ __launch_bounds__(1024) void gram_reduce_kernel(PostArgs a, int nblk) {
   __shared__ double red[1024];
   const int KP = a.KP;
-  if ((int)blockIdx.x == KP * KP / 32) {
+  if ((int)blockIdx.x == (int)gridDim.x - 1) {
     // the extra block: column sums, 16 partial strides per column (KP <= 64 columns), in parallel with the Gram blocks
     const int col = threadIdx.x >> 4, gq = threadIdx.x & 15;
     double v = 0.0, v2 = 0.0;
@@ -89,24 +101,31 @@ __global__ __launch_bounds__(1024) void gram_reduce_kernel(PostArgs a, int nblk)
     if (col < KP && gq == 0) { a.colsum[col] = v; if (a.S2) a.colsum2[col] = v2; }
     return;
   }
+  const int NT = KP / 4, NU = NT * (NT + 1) / 2, PS = NU * 16;       // packed slab: NU tiles of 16 doubles
   const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int t = blockIdx.x * 32 + e;
+  const int t = blockIdx.x * 32 + e;                                   // packed entry
   double s = 0.0;
-  for (int b = g; b < nblk; b += 32) s += a.Cpart[(size_t)b * KP * KP + t];
+  if (t < PS)
+    for (int b = g; b < nblk; b += 32) s += a.Cpart[(size_t)b * PS + t];
   red[threadIdx.x] = s;
   __syncthreads();
-  if (g == 0) {                          // one barrier, then 32 threads add the 32 strides in a fixed order
+  if (g == 0 && t < PS) {                // one barrier, then 32 threads add the 32 strides in a fixed order
     double tot = 0.0;
 #pragma unroll
     for (int j = 0; j < 32; ++j) tot += red[e + 32 * j];
-    a.C64[t] = tot; a.C32[t] = (float)tot;
+    int ty, tx;
+    tri_tile(t >> 4, NT, &ty, &tx);
+    const int row = 4 * ty + ((t >> 2) & 3), col = 4 * tx + (t & 3);
+    a.C64[row * KP + col] = tot; a.C32[row * KP + col] = (float)tot;
+    if (ty != tx) { a.C64[col * KP + row] = tot; a.C32[col * KP + row] = (float)tot; }    // the mirror tile
   }
 }
 
 void launch_post(const PostArgs& a, hipStream_t st) {
   const int nblk = post_blocks(a.rows);
   hipLaunchKernelGGL(post_kernel, dim3(nblk), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3(a.KP * a.KP / 32 + 1), dim3(1024), 0, st, a, nblk);
+  const int nt = a.KP / 4, ps = nt * (nt + 1) / 2 * 16;
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3((ps + 31) / 32 + 1), dim3(1024), 0, st, a, nblk);
 }
 
 }  // namespace bnmtf
