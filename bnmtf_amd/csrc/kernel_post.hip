@@ -91,14 +91,41 @@ __global__ __launch_bounds__(1024) void gram_reduce_kernel(PostArgs a, int nblk)
   __shared__ double red[1024];
   const int KP = a.KP;
   if ((int)blockIdx.x == (int)gridDim.x - 1) {
-    // the extra block: column sums, 16 partial strides per column (KP <= 64 columns), in parallel with the Gram blocks
-    const int col = threadIdx.x >> 4, gq = threadIdx.x & 15;
+    // the extra block: column sums, in parallel with the Gram blocks.  Thread = column + 64 * group: a wave reads one
+    // coalesced row of partials per load, eight loads in flight, 16 groups summed through LDS in a fixed order
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
     double v = 0.0, v2 = 0.0;
     if (col < KP)
-      for (int b = gq; b < nblk; b += 16) { v += a.spart[(size_t)b * KP + col]; if (a.S2) v2 += a.s2part[(size_t)b * KP + col]; }
+      for (int b0 = grp; b0 < nblk; b0 += 8 * 16) {
+        double w[8], w2[8];
 #pragma unroll
-    for (int m = 1; m < 16; m <<= 1) { v += __shfl_xor(v, m, 64); v2 += __shfl_xor(v2, m, 64); }
-    if (col < KP && gq == 0) { a.colsum[col] = v; if (a.S2) a.colsum2[col] = v2; }
+        for (int u = 0; u < 8; ++u) {
+          const int b = b0 + 16 * u;
+          w[u] = b < nblk ? a.spart[(size_t)b * KP + col] : 0.0;
+          w2[u] = (a.S2 && b < nblk) ? a.s2part[(size_t)b * KP + col] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { v += w[u]; v2 += w2[u]; }
+      }
+    red[threadIdx.x] = v;
+    __syncthreads();
+    if (grp == 0 && col < KP) {
+      double tot = 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) tot += red[col + 64 * j];
+      a.colsum[col] = tot;
+    }
+    if (a.S2) {
+      __syncthreads();
+      red[threadIdx.x] = v2;
+      __syncthreads();
+      if (grp == 0 && col < KP) {
+        double tot = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) tot += red[col + 64 * j];
+        a.colsum2[col] = tot;
+      }
+    }
     return;
   }
   const int NT = KP / 4, NU = NT * (NT + 1) / 2, PS = NU * 16;       // packed slab: NU tiles of 16 doubles
