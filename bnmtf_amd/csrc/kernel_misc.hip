@@ -54,13 +54,18 @@ void launch_gram(const GramArgs& a, hipStream_t st) {
 //   sum_Omega Rp^2 = <U^T U, V^T V> - sum_miss q^2 ;  sum_Omega Rp = (1^T U).(1^T V) - sum_miss q
 //   sum_Omega R Rp = sum (Pv o V)   (Pv = R~^T U only holds observed entries)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
-  __shared__ double red[4][4];
+__global__ __launch_bounds__(1024) void finish_kernel(FinishArgs a) {
+  __shared__ double red[16][4];
   const int KP = a.KP, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // four sums at once: <Cr, Cc>, and the three columns of the per-block sweep statistics
   double v[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int t = threadIdx.x; t < KP * KP; t += 256) v[0] = fma(a.Cr64[t], a.Cc64[t], v[0]);
-  for (int b = threadIdx.x; b < a.nstats; b += 256)
+  {
+    double p[4] = {0.0, 0.0, 0.0, 0.0};          // 4 x 1024 entries cover K = 64: all eight loads in flight
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int t = threadIdx.x + 1024 * u; if (t < KP * KP) p[u] = a.Cr64[t] * a.Cc64[t]; }
+    v[0] = (p[0] + p[1]) + (p[2] + p[3]);
+  }
+  for (int b = threadIdx.x; b < a.nstats; b += 1024)
     for (int t = 0; t < 3; ++t) v[1 + t] += a.stats[(size_t)b * 4 + t];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -78,7 +83,12 @@ __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
   __syncthreads();
   if (threadIdx.x == 0) {
     double tot[4];
-    for (int t = 0; t < 4; ++t) tot[t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    for (int t = 0; t < 4; ++t) {
+      double s = 0.0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) s += red[w][t];
+      tot[t] = s;
+    }
     const double dot = tot[0];
     double acc[3] = {a.acc[0] + tot[1], a.acc[1] + tot[2], a.acc[2] + tot[3]};
     const double srp = acc[0], sp = sp1 - acc[1], spp = dot - acc[2];
@@ -169,7 +179,7 @@ void launch_vb_finish(const VbFinishArgs& a, hipStream_t st) {
 }
 
 void launch_finish(const FinishArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(1024), 0, st, a);
 }
 
 // ---------------------------------------------------------------------------
