@@ -150,17 +150,17 @@ __global__ __launch_bounds__(1024) void srow_gather_kernel(SRowArgs a) {
     for (int m = 32; m >= 1; m >>= 1) { r0 += __shfl_xor(r0, m, 64); r2 += __shfl_xor(r2, m, 64); r3 += __shfl_xor(r3, m, 64); }
     const float dj = r0;                                              // G_j . delta_{k-1}
     float hm = 0.f;
-    for (uint32_t e = s0 + lane; e < s1; e += 128) {                 // two independent slots per trip
-      const uint32_t e2 = e + 64;
-      const bool two = e2 < s1;
-      const uint32_t i0 = idxp[e], i1 = two ? idxp[e2] : idxp[e];
-      float q0 = qp[e], q1 = two ? qp[e2] : 0.f;
-      const float f0 = FTk[i0], f1 = two ? FTk[i1] : 0.f;
-      if (upd) {
-        q0 = fmaf(FTp[i0], dj, q0); qp[e] = q0;
-        if (two) { q1 = fmaf(FTp[i1], dj, q1); qp[e2] = q1; }
+    for (uint32_t e = s0 + lane; e < s1; e += 256) {                 // four independent slots per trip: all index loads, then all gathers
+      uint32_t ii[4]; float qq[4], ff[4], fp[4]; bool on[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { on[t] = e + 64u * t < s1; ii[t] = on[t] ? idxp[e + 64u * t] : idxp[e]; qq[t] = on[t] ? qp[e + 64u * t] : 0.f; }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { ff[t] = on[t] ? FTk[ii[t]] : 0.f; fp[t] = (upd && on[t]) ? FTp[ii[t]] : 0.f; }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (upd && on[t]) { qq[t] = fmaf(fp[t], dj, qq[t]); qp[e + 64u * t] = qq[t]; }
+        hm = fmaf(qq[t], ff[t], hm);
       }
-      hm = fmaf(q0, f0, fmaf(q1, f1, hm));
     }
     hm = wsum(hm);
     contrib = g * (r2 - r3 + hm);
