@@ -84,6 +84,33 @@ __global__ __launch_bounds__(256) void srow_w_kernel(SOmegaArgs a) {
   if (lane < a.KPk) a.w[(size_t)u * a.KPk + lane] = (lane < a.K ? a.Cf32[(size_t)lane * a.KPk + lane] : 0.f) - ((acc0 + acc1) + (acc2 + acc3));
 }
 
+// q_ij = (F S)_i . G_j on the missing entries of every column j, in the order of the column's (64-wide) slots: what the S
+// rows carry forward.  One wave per column; a 32-lane half takes one entry per trip (lane = l): a coalesced 128-byte
+// row of U_eff = F S, times G_j held in registers, summed inside the half.  KPl = 32 (L <= 32) only.
+__global__ __launch_bounds__(256) void srow_qinit_kernel(SOmegaArgs a, const float* Ueff, float* q) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, l5 = lane & 31;
+  const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (u >= a.n) return;
+  const float g = (l5 < a.L) ? a.G[((size_t)a.n0 + u) * a.KPl + l5] : 0.f;
+  const uint32_t s0 = a.slot_ptr[u], s1 = a.slot_ptr[u + 1];
+  for (uint32_t e0 = s0; e0 < s1; e0 += 16) {                          // eight trips of two entries in flight
+    uint32_t ii[8]; float uv[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { const uint32_t e = e0 + 2u * t + half; ii[t] = e < s1 ? a.idx[e] : (uint32_t)a.zero_row; }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) uv[t] = Ueff[(size_t)ii[t] * a.KPl + l5];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float sm = half_sum_upper(uv[t] * g);                      // right in lanes 16-31 of the half
+      const uint32_t e = e0 + 2u * t + half;
+      if (l5 == 16 && e < s1) q[e] = sm;
+    }
+  }
+}
+void launch_srow_qinit(const SOmegaArgs& a, const float* Ueff, float* q, hipStream_t st) {
+  if (a.n > 0) hipLaunchKernelGGL(srow_qinit_kernel, dim3((a.n + 3) / 4), dim3(256), 0, st, a, Ueff, q);
+}
+
 // Omega^k[l][l'] = sum_j w_kj G_jl G_jl' for every row k of S, as nch partial sums over column chunks: block (k, c).
 // LP = padded L (32 or 64); thread t owns l = t mod LP and NACC consecutive l'.
 template <int LP>

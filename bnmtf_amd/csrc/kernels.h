@@ -187,6 +187,7 @@ struct SOmegaArgs {         // w[j][k] and the chunk partials of Omega^k for eve
   float* omp;                          // [K][nch][LP*LP]
 };
 void launch_srow_omega(const SOmegaArgs& a, hipStream_t st);
+void launch_srow_qinit(const SOmegaArgs& a, const float* Ueff, float* q, hipStream_t st);   // q = (F S)_i . G_j on the column slots (KPl == 32)
 void launch_srow_gather(const SRowArgs& a, int blocks, hipStream_t st);
 struct SDrawArgs {
   int k, K, L, KPk, nblocks, update, cond_l, LP, nch;
