@@ -66,22 +66,40 @@ __global__ __launch_bounds__(256) void srow_w_kernel(SOmegaArgs a) {
   const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (u >= a.n) return;
   const uint32_t s0 = a.slot_ptr[u], s1 = a.slot_ptr[u + 1];
-  const int kk = lane < a.KPk ? lane : 0;
-  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-  for (uint32_t e0 = s0; e0 < s1; e0 += 64) {
-    const uint32_t iv = (e0 + lane < s1) ? a.idx[e0 + lane] : (uint32_t)a.zero_row;     // padding slots point at the zero row too
-    const int cnt = (int)min(64u, s1 - e0);
-    int t = 0;
-    for (; t + 4 <= cnt; t += 4) {
-      const float f0 = a.F[(size_t)__builtin_amdgcn_readlane((int)iv, t) * a.KPk + kk];
-      const float f1 = a.F[(size_t)__builtin_amdgcn_readlane((int)iv, t + 1) * a.KPk + kk];
-      const float f2 = a.F[(size_t)__builtin_amdgcn_readlane((int)iv, t + 2) * a.KPk + kk];
-      const float f3 = a.F[(size_t)__builtin_amdgcn_readlane((int)iv, t + 3) * a.KPk + kk];
-      acc0 = fmaf(f0, f0, acc0); acc1 = fmaf(f1, f1, acc1); acc2 = fmaf(f2, f2, acc2); acc3 = fmaf(f3, f3, acc3);
+  float tot;
+  if (a.KPk == 32) {
+    // a 32-lane half takes one entry per trip (lane = k): coalesced 128-byte rows of F, eight trips in flight
+    const int half = lane >> 5, l5 = lane & 31;
+    float acc = 0.f;
+    for (uint32_t e0 = s0; e0 < s1; e0 += 16) {
+      uint32_t ii[8]; float fv[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { const uint32_t e = e0 + 2u * t + half; ii[t] = e < s1 ? a.idx[e] : (uint32_t)a.zero_row; }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) fv[t] = a.F[(size_t)ii[t] * 32 + l5];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc = fmaf(fv[t], fv[t], acc);
     }
-    for (; t < cnt; ++t) { const float f0 = a.F[(size_t)__builtin_amdgcn_readlane((int)iv, t) * a.KPk + kk]; acc0 = fmaf(f0, f0, acc0); }
+    tot = acc + __shfl_xor(acc, 32, 64);
+  } else {
+    const int kk = lane < a.KPk ? lane : 0;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    for (uint32_t e0 = s0; e0 < s1; e0 += 64) {
+      const uint32_t iv = (e0 + lane < s1) ? a.idx[e0 + lane] : (uint32_t)a.zero_row;     // padding slots point at the zero row too
+      const int cnt = (int)min(64u, s1 - e0);
+      int t = 0;
+      for (; t + 4 <= cnt; t += 4) {
+        const float f0 = a.F[(size_t)__builtin_amdgcn_readlane((int)iv, t) * a.KPk + kk];
+        const float f1 = a.F[(size_t)__builtin_amdgcn_readlane((int)iv, t + 1) * a.KPk + kk];
+        const float f2 = a.F[(size_t)__builtin_amdgcn_readlane((int)iv, t + 2) * a.KPk + kk];
+        const float f3 = a.F[(size_t)__builtin_amdgcn_readlane((int)iv, t + 3) * a.KPk + kk];
+        acc0 = fmaf(f0, f0, acc0); acc1 = fmaf(f1, f1, acc1); acc2 = fmaf(f2, f2, acc2); acc3 = fmaf(f3, f3, acc3);
+      }
+      for (; t < cnt; ++t) { const float f0 = a.F[(size_t)__builtin_amdgcn_readlane((int)iv, t) * a.KPk + kk]; acc0 = fmaf(f0, f0, acc0); }
+    }
+    tot = (acc0 + acc1) + (acc2 + acc3);
   }
-  if (lane < a.KPk) a.w[(size_t)u * a.KPk + lane] = (lane < a.K ? a.Cf32[(size_t)lane * a.KPk + lane] : 0.f) - ((acc0 + acc1) + (acc2 + acc3));
+  if (lane < a.KPk) a.w[(size_t)u * a.KPk + lane] = (lane < a.K ? a.Cf32[(size_t)lane * a.KPk + lane] : 0.f) - tot;
 }
 
 // q_ij = (F S)_i . G_j on the missing entries of every column j, in the order of the column's (64-wide) slots: what the S
