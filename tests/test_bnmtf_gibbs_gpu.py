@@ -107,11 +107,13 @@ def test_kmeans_initialisation_runs():
     assert np.isfinite(b.all_performances['MSE']).all()
 
 
-def test_wide_column_factor_takes_the_64_wide_paths():
-    """L > 32 (G stored 64 wide): the S preparation falls back to the generic q kernel and Omega is formed 64 wide; the
-    conditional parameters still match the closed forms (bnmtf_gibbs_optimised.py:195-211) evaluated by the oracle."""
+@pytest.mark.parametrize("K,L", [(6, 40), (40, 8)])
+def test_factors_wider_than_32_take_the_64_wide_paths(K, L):
+    """L > 32 (G stored 64 wide): the S preparation falls back to the generic q kernel and Omega is formed 64 wide; K > 32
+    (F stored 64 wide): the 64-lane w kernel.  The conditional parameters still match the closed forms
+    (bnmtf_gibbs_optimised.py:195-211) evaluated by the oracle."""
     rs = np.random.RandomState(11)
-    I, J, K, L = 70, 95, 6, 40
+    I, J = 70, 95
     F0 = rs.exponential(1.0, (I, K)); S0 = rs.exponential(1.0, (K, L)); G0 = rs.exponential(1.0, (J, L))
     R = F0 @ S0 @ G0.T + rs.randn(I, J)
     M = (rs.rand(I, J) > 0.2).astype(float)
@@ -121,11 +123,11 @@ def test_wide_column_factor_takes_the_64_wide_paths():
     b.F, b.S, b.G, b.tau = rs.exponential(1.0, (I, K)), rs.exponential(1.0, (K, L)), rs.exponential(1.0, (J, L)), 0.7
     o = O.BNMTFGibbsOracle(R, M, K, L, pri)
     o.F, o.S, o.G, o.tau = b.F.copy(), b.S.copy(), b.G.copy(), b.tau
-    for (k, l) in [(0, 0), (3, 35), (5, 39)]:
+    for (k, l) in [(0, 0), (K // 2, L - 5), (K - 1, L - 1)]:
         t = b.tauS(k, l); to = o.tauS(k, l)
         assert abs(t - to) < 5e-6 * to
         assert abs(b.muS(t, k, l) - o.muS(to, k, l)) < 2e-4 * (abs(o.muS(to, k, l)) + 1 / np.sqrt(to))
-    for l in (0, 33, 39):
+    for l in (0, L - 7, L - 1):
         t = b.tauG(l); to = o.tauG(l)
         np.testing.assert_allclose(t, to, rtol=5e-6)
         assert np.abs(b.muG(t, l) - o.muG(to, l)).max() < 2e-4 * np.abs(o.muG(to, l)).max()
