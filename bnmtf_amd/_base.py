@@ -1,6 +1,7 @@
 """Shared host-side logic of the model classes: argument checks with the reference's
 exact assertion messages, the device handle, metric finishing (fp64)."""
 import ctypes as C
+import hashlib
 import math
 
 import numpy as np
@@ -73,9 +74,25 @@ class DeviceModel(object):
 
     def _init_device(self, seed, device, rank, world, comm_id):
         self._h = None
+        if world > 1 and seed is None:
+            # every rank must draw the same chain (same Philox key, same tau variates) and start from the same replicated
+            # factors: without an explicit seed the key comes from the communicator id, which all ranks share
+            assert comm_id is not None, "world > 1 needs the comm_id all ranks share"
+            seed = int.from_bytes(hashlib.sha256(bytes(comm_id)).digest()[:8], "little") >> 2
         self._seed = seed
         self._device = device
         self._rank, self._world, self._comm_id = rank, world, comm_id
+        self._init_rs = None
+
+    def _rng(self):
+        """Source of the initialisation draws: numpy.random's global stream for a single-GPU model (what the reference
+        consumes, so numpy.random.seed() reproduces its initial factors); a RandomState seeded with the shared key for a
+        sharded model, so that every rank holds the same replicated U, V."""
+        if self._world == 1:
+            return np.random
+        if self._init_rs is None:
+            self._init_rs = np.random.RandomState(self._seed % (2 ** 32))
+        return self._init_rs
 
     def _lambda_arrays(self):
         raise NotImplementedError
@@ -86,6 +103,8 @@ class DeviceModel(object):
             if self._seed is None:      # follow NumPy's global seeding like the reference's samplers do
                 self._seed = int(np.random.randint(0, 2 ** 62))
             lr, lc, ls = self._lambda_arrays()
+            # the device holds a 0/1 mask; the reference would weight by the values of M (all its callers pass 0/1)
+            assert ((self.M == 0) | (self.M == 1)).all(), "The indicator matrix M must contain only 0 and 1."
             self._keep = (np.ascontiguousarray(self.R, dtype=np.float32),
                           np.ascontiguousarray(self.M != 0, dtype=np.uint8),
                           _lib.f64(lr), _lib.f64(lc), None if ls is None else _lib.f64(ls),
@@ -141,6 +160,9 @@ class DeviceModel(object):
 
     def _metric_sums(self, M_pred, A, S, B):
         out = np.zeros(6)
+        if M_pred is not None:
+            Mp_ = np.asarray(M_pred)
+            assert ((Mp_ == 0) | (Mp_ == 1)).all(), "The indicator matrix M_pred must contain only 0 and 1."
         Mp = None if M_pred is None else np.ascontiguousarray(np.asarray(M_pred) != 0, dtype=np.uint8)
         A = None if A is None else _lib.f64(A)
         S = None if S is None else _lib.f64(S)

@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbnmtf_hip.so")
+# BNMTF_LIB: load another build of the library (tools/: the phase-timing or an A/B build) without touching the shipped one
+LIB_PATH = os.environ.get("BNMTF_LIB") or os.path.join(_HERE, "lib", "libbnmtf_hip.so")
 
 KERNEL_GEMM_ROWS, KERNEL_GEMM_COLS, KERNEL_SWEEP_ROWS, KERNEL_SWEEP_COLS = 0, 1, 2, 3
 UPDATE_DRAW, UPDATE_MODE, UPDATE_ICM = 0, 1, 2
@@ -35,6 +36,8 @@ _SIGS = {
     "bnmtf_create": ([C.POINTER(Problem), C.POINTER(_P)], C.c_int),
     "bnmtf_destroy": ([_P], C.c_int),
     "bnmtf_sync": ([_P], C.c_int),
+    "bnmtf_host_alloc": ([C.c_size_t, C.POINTER(_P)], C.c_int),
+    "bnmtf_host_free": ([_P], C.c_int),
     "bnmtf_omega_counts": ([_P, C.POINTER(C.c_uint64), _P, _P], C.c_int),
     "bnmtf_set_iteration": ([_P, C.c_uint64], C.c_int),
     "bnmtf_get_iteration": ([_P, C.POINTER(C.c_uint64)], C.c_int),
@@ -99,3 +102,33 @@ def device_count():
     n = C.c_int(0)
     check(lib().bnmtf_device_count(C.byref(n)))
     return n.value
+
+
+class _PinnedBlock(object):
+    """Owner of one bnmtf_host_alloc block (freed when the last array viewing it goes away)."""
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        check(lib().bnmtf_host_alloc(nbytes, C.byref(p)))
+        self.ptr, self.nbytes = p.value, nbytes
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().bnmtf_host_free(C.c_void_p(self.ptr))
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def sample_buffer(shape, dtype=np.float32):
+    """A zero-copy NumPy array over page-locked memory for run()'s sample outputs (asynchronous device-to-host
+    copies land in it while the next iterations compute); ordinary pageable memory when pinning fails."""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    try:
+        blk = _PinnedBlock(max(n, 1))
+    except BnmtfError:
+        return np.zeros(shape, dtype=dtype)
+    buf = (C.c_char * max(n, 1)).from_address(blk.ptr)
+    buf._owner = blk                      # the ctypes buffer (kept alive by the array's .base chain) keeps the block
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)

@@ -51,8 +51,8 @@ class bnmf_gibbs_optimised(DeviceModel):
         i.e. the same values as the reference's scalar loop for the same numpy seed."""
         assert init in ['random', 'exp'], "Unknown initialisation option: %s. Should be 'random' or 'exp'." % init
         if init == 'random':
-            self.U = np.random.exponential(scale=1.0 / self.lambdaU)
-            self.V = np.random.exponential(scale=1.0 / self.lambdaV)
+            self.U = self._rng().exponential(scale=1.0 / self.lambdaU)
+            self.V = self._rng().exponential(scale=1.0 / self.lambdaV)
         else:
             self.U = 1.0 / self.lambdaU
             self.V = 1.0 / self.lambdaV
@@ -73,14 +73,16 @@ class bnmf_gibbs_optimised(DeviceModel):
         hand-off (device-resident benchmark mode); update='mode' runs the ICM harness."""
         it = int(iterations)
         self._push()
-        U_out = np.zeros((it, self.I, self.K), dtype=np.float32) if store_samples else None
-        V_out = np.zeros((it, self.J, self.K), dtype=np.float32) if store_samples else None
+        # page-locked sample arrays: the device-to-host copy of iteration t overlaps the sweeps of iteration t+1
+        U_out = _lib.sample_buffer((it, self.I, self.K)) if store_samples else None
+        V_out = _lib.sample_buffer((it, self.J, self.K)) if store_samples else None
         taus = np.zeros(it); perf = np.zeros((it, 3)); times = np.zeros(it)
         _lib.check(_lib.lib().bnmf_gibbs_run(self._handle(), it, _lib.UPDATE_MODE if update == 'mode' else _lib.UPDATE_DRAW,
                                              _lib.ptr(U_out), _lib.ptr(V_out), _lib.ptr(taus), _lib.ptr(perf), _lib.ptr(times)))
         self._pull()
-        self.all_U = U_out.astype(np.float64) if store_samples else np.zeros((0, self.I, self.K))
-        self.all_V = V_out.astype(np.float64) if store_samples else np.zeros((0, self.J, self.K))
+        # the samples are what the device drew: fp32 (the reference's arrays are fp64; every reduction below sums in fp64)
+        self.all_U = U_out if store_samples else np.zeros((0, self.I, self.K))
+        self.all_V = V_out if store_samples else np.zeros((0, self.J, self.K))
         self.all_tau = taus
         self.all_times = list(times)
         self.all_performances = {'MSE': list(perf[:, 0]), 'R^2': list(perf[:, 1]), 'Rp': list(perf[:, 2])}
@@ -121,8 +123,8 @@ class bnmf_gibbs_optimised(DeviceModel):
     # Posterior means from the stored samples (:182-187); host fp64, accepts lists
     def approx_expectation(self, burn_in, thinning):
         indices = range(burn_in, len(self.all_U), thinning)
-        exp_U = np.array([self.all_U[i] for i in indices]).sum(axis=0) / float(len(indices))
-        exp_V = np.array([self.all_V[i] for i in indices]).sum(axis=0) / float(len(indices))
+        exp_U = np.array([self.all_U[i] for i in indices], dtype=np.float64).sum(axis=0) / float(len(indices))
+        exp_V = np.array([self.all_V[i] for i in indices], dtype=np.float64).sum(axis=0) / float(len(indices))
         exp_tau = sum([self.all_tau[i] for i in indices]) / float(len(indices))
         return (exp_U, exp_V, exp_tau)
 

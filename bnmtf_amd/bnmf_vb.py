@@ -17,7 +17,7 @@ from .distributions import TN_vector_expectation, TN_vector_variance, gamma_expe
 
 
 class bnmf_vb_optimised(DeviceModel):
-    def __init__(self, R, M, K, priors, *, device=0, verbose=True):
+    def __init__(self, R, M, K, priors, *, device=0, verbose=True, rank=0, world=1, comm_id=None):
         self.R = np.array(R, dtype=float)
         self.M = np.array(M, dtype=float)
         self.K = K
@@ -28,7 +28,7 @@ class bnmf_vb_optimised(DeviceModel):
         self.lambdaU = broadcast_lambda(priors['lambdaU'], (self.I, self.K), "lambdaU")
         self.lambdaV = broadcast_lambda(priors['lambdaV'], (self.J, self.K), "lambdaV")
         self.verbose = verbose
-        self._init_device(0, device, 0, 1, None)
+        self._init_device(0, device, rank, world, comm_id)      # VB draws nothing: the key is unused, 0 on every rank
 
     def _lambda_arrays(self):
         return self.lambdaU, self.lambdaV, None
@@ -54,8 +54,8 @@ class bnmf_vb_optimised(DeviceModel):
         assert init in ['exp', 'random'], "Unrecognised init option for F,G: %s." % init
         self.muU, self.muV = 1. / self.lambdaU, 1. / self.lambdaV
         if init == 'random':
-            self.muU = np.random.exponential(scale=1.0 / self.lambdaU)
-            self.muV = np.random.exponential(scale=1.0 / self.lambdaV)
+            self.muU = self._rng().exponential(scale=1.0 / self.lambdaU)
+            self.muV = self._rng().exponential(scale=1.0 / self.lambdaV)
         self.expU, self.varU = np.zeros((self.I, self.K)), np.zeros((self.I, self.K))
         self.expV, self.varV = np.zeros((self.J, self.K)), np.zeros((self.J, self.K))
         for k in range(self.K):

@@ -46,11 +46,11 @@ class bnmtf_gibbs_optimised(DeviceModel):
         assert init_FG in ['random', 'exp', 'kmeans'], "Unknown initialisation option for S: %s. Should be 'random', 'exp', or 'kmeans." % init_FG
         self.S = 1. / self.lambdaS
         if init_S == 'random':
-            self.S = np.random.exponential(scale=1.0 / self.lambdaS)
+            self.S = self._rng().exponential(scale=1.0 / self.lambdaS)
         self.F, self.G = 1. / self.lambdaF, 1. / self.lambdaG
         if init_FG == 'random':
-            self.F = np.random.exponential(scale=1.0 / self.lambdaF)
-            self.G = np.random.exponential(scale=1.0 / self.lambdaG)
+            self.F = self._rng().exponential(scale=1.0 / self.lambdaF)
+            self.G = self._rng().exponential(scale=1.0 / self.lambdaG)
         elif init_FG == 'kmeans':
             if self.verbose: print("Initialising F using KMeans.")
             kmeans_F = KMeans(self.R, self.M, self.K)
@@ -77,16 +77,16 @@ class bnmtf_gibbs_optimised(DeviceModel):
         """:138-180."""
         it = int(iterations)
         self._push()
-        F_out = np.zeros((it, self.I, self.K), dtype=np.float32) if store_samples else None
-        S_out = np.zeros((it, self.K, self.L), dtype=np.float32) if store_samples else None
-        G_out = np.zeros((it, self.J, self.L), dtype=np.float32) if store_samples else None
+        F_out = _lib.sample_buffer((it, self.I, self.K)) if store_samples else None
+        S_out = _lib.sample_buffer((it, self.K, self.L)) if store_samples else None
+        G_out = _lib.sample_buffer((it, self.J, self.L)) if store_samples else None
         taus = np.zeros(it); perf = np.zeros((it, 3)); times = np.zeros(it)
         _lib.check(_lib.lib().bnmtf_gibbs_run(self._handle(), it, _lib.UPDATE_MODE if update == 'mode' else _lib.UPDATE_DRAW,
                                               _lib.ptr(F_out), _lib.ptr(S_out), _lib.ptr(G_out), _lib.ptr(taus), _lib.ptr(perf), _lib.ptr(times)))
         self._pull()
-        self.all_F = F_out.astype(np.float64) if store_samples else np.zeros((0, self.I, self.K))
-        self.all_S = S_out.astype(np.float64) if store_samples else np.zeros((0, self.K, self.L))
-        self.all_G = G_out.astype(np.float64) if store_samples else np.zeros((0, self.J, self.L))
+        self.all_F = F_out if store_samples else np.zeros((0, self.I, self.K))
+        self.all_S = S_out if store_samples else np.zeros((0, self.K, self.L))
+        self.all_G = G_out if store_samples else np.zeros((0, self.J, self.L))
         self.all_tau = taus
         self.all_times = list(times)
         self.all_performances = {'MSE': list(perf[:, 0]), 'R^2': list(perf[:, 1]), 'Rp': list(perf[:, 2])}
@@ -136,9 +136,9 @@ class bnmtf_gibbs_optimised(DeviceModel):
     def approx_expectation(self, burn_in, thinning):
         """:216-223."""
         indices = range(burn_in, len(self.all_F), thinning)
-        exp_F = np.array([self.all_F[i] for i in indices]).sum(axis=0) / float(len(indices))
-        exp_S = np.array([self.all_S[i] for i in indices]).sum(axis=0) / float(len(indices))
-        exp_G = np.array([self.all_G[i] for i in indices]).sum(axis=0) / float(len(indices))
+        exp_F = np.array([self.all_F[i] for i in indices], dtype=np.float64).sum(axis=0) / float(len(indices))
+        exp_S = np.array([self.all_S[i] for i in indices], dtype=np.float64).sum(axis=0) / float(len(indices))
+        exp_G = np.array([self.all_G[i] for i in indices], dtype=np.float64).sum(axis=0) / float(len(indices))
         exp_tau = sum([self.all_tau[i] for i in indices]) / float(len(indices))
         return (exp_F, exp_S, exp_G, exp_tau)
 

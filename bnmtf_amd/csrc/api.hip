@@ -2,11 +2,13 @@
 // layout of the masked matrix for the two sweep directions), state hand-off, the
 // Gibbs / VB drivers that enqueue the kernels on the handle's stream.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "model.h"
@@ -41,6 +43,42 @@ static void dfree(T*& p) {
   p = nullptr;
 }
 
+// events / scratch buffers of one call: released on every return path
+struct EventList {
+  std::vector<hipEvent_t> ev;
+  int create(size_t n) {
+    ev.reserve(n);
+    for (size_t i = 0; i < n; ++i) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); ev.push_back(e); }
+    return BNMTF_OK;
+  }
+  hipEvent_t operator[](size_t i) const { return ev[i]; }
+  ~EventList() { for (auto e : ev) (void)hipEventDestroy(e); }
+};
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  int alloc(size_t count, bool zero = false) { return dalloc(&p, count, zero); }
+  ~DevBuf() { dfree(p); }
+};
+
+// Host threads for the O(I*J) layout passes of bnmtf_create (a cross-validation driver pays them once per model):
+// fn(begin, end) over fixed-size chunks of [0, n), so results never depend on the thread count.
+template <typename Fn>
+static void parallel_chunks(int n, int chunk, Fn fn) {
+  const int nchunks = (n + chunk - 1) / chunk;
+  int nt = (int)std::thread::hardware_concurrency();
+  if (const char* e = getenv("BNMTF_HOST_THREADS")) nt = atoi(e);
+  nt = std::max(1, std::min({nt, 32, nchunks}));
+  std::atomic<int> next{0};
+  auto work = [&]() {
+    for (int c = next.fetch_add(1); c < nchunks; c = next.fetch_add(1)) fn(c * chunk, std::min(n, (c + 1) * chunk));
+  };
+  if (nt == 1) { work(); return; }
+  std::vector<std::thread> ts;
+  for (int t = 0; t < nt; ++t) ts.emplace_back(work);
+  for (auto& t : ts) t.join();
+}
+
 // ------------------------------------------------------------------ layout
 // Fill one direction.  get(u, r) returns (observed, value) of unit u (global) at
 // inner index r.
@@ -71,21 +109,30 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
   std::vector<uint32_t> ptr(d.n + 1, 0), idx;
   d.obs_count.assign(nglob, 0);
   d.nmiss = 0;
-  idx.reserve((size_t)d.n * 64);
-  std::vector<uint32_t> miss;
+  // 64 x 64 tiles (unit x inner): both the read of R/M (contiguous along one of the two) and the write of the
+  // transposed shard stay in cache whichever direction this is; a unit's missing list still comes out in inner order
+  std::vector<std::vector<uint32_t>> missv(d.n);
+  parallel_chunks(d.n, 64, [&](int a, int b) {
+    for (int r0 = 0; r0 < m; r0 += 64)
+      for (int ul = a; ul < b; ++ul) {
+        const int u = d.n0 + ul;
+        std::vector<uint32_t>& ms = missv[ul];
+        const int r1 = std::min(m, r0 + 64);
+        for (int r = r0; r < r1; ++r) {
+          float v;
+          if (get(u, r, &v)) big[(size_t)r * d.n_pad + ul] = v;
+          else ms.push_back((uint32_t)r);
+        }
+      }
+  });
   for (int ul = 0; ul < d.n; ++ul) {
-    const int u = d.n0 + ul;
-    miss.clear();
-    for (int r = 0; r < m; ++r) {
-      float v;
-      if (get(u, r, &v)) big[(size_t)r * d.n_pad + ul] = v;
-      else miss.push_back((uint32_t)r);
-    }
-    d.nmiss += miss.size();
-    const size_t slots = (miss.size() + 63) / 64 * 64;
-    ptr[ul + 1] = ptr[ul] + (uint32_t)slots;
-    for (size_t e = 0; e < slots; ++e) idx.push_back(e < miss.size() ? miss[e] : (uint32_t)m);  // m = zero sentinel
+    d.nmiss += missv[ul].size();
+    ptr[ul + 1] = ptr[ul] + (uint32_t)((missv[ul].size() + 63) / 64 * 64);
   }
+  idx.assign(ptr[d.n], (uint32_t)m);                    // m = zero sentinel
+  parallel_chunks(d.n, 256, [&](int a, int b) {
+    for (int ul = a; ul < b; ++ul) std::copy(missv[ul].begin(), missv[ul].end(), idx.begin() + ptr[ul]);
+  });
   d.nslots = idx.size();
 
   // fast layout: a unit owns a 32-lane half wave.  Lane r prefers the entries with j mod 32 == r (bank-conflict-free
@@ -101,14 +148,12 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
     const uint32_t kNone = 0xFFFFFFFFu;
     std::vector<int> Eu(d.n, 0);
     std::vector<std::vector<uint32_t>> lanes((size_t)d.n * 32);     // per unit, per lane: slot contents (kNone = empty)
+    parallel_chunks(d.n, 64, [&](int ua, int ub) {
     std::vector<std::vector<uint32_t>> over(32);
-    for (int ul = 0; ul < d.n; ++ul) {
+    for (int ul = ua; ul < ub; ++ul) {
       std::vector<uint32_t>* L = &lanes[(size_t)ul * 32];
-      size_t cnt = 0;
-      for (uint32_t t = ptr[ul]; t < ptr[ul + 1]; ++t) {
-        const uint32_t j = idx[t];
-        if (j < (uint32_t)m) { L[j & 31].push_back(j); ++cnt; }
-      }
+      const size_t cnt = missv[ul].size();
+      for (uint32_t j : missv[ul]) L[j & 31].push_back(j);
       int emax = 0;
       for (int r = 0; r < 32; ++r) emax = std::max(emax, (int)L[r].size());
       int E = std::max(2, (emax + 1) & ~1);
@@ -143,6 +188,7 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
       }
       Eu[ul] = E;
     }
+    });
     auto res = [&](int ul, int r) -> const std::vector<uint32_t>& { return lanes[(size_t)ul * 32 + r]; };
     std::vector<int> order(d.n);
     for (int i = 0; i < d.n; ++i) order[i] = i;
@@ -182,7 +228,8 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
     size_t rows_total = 0;
     for (int sl = 0; sl < d.f_npairs; ++sl) { pB[sl] = (uint32_t)rows_total; rows_total += pE[sl]; }
     std::vector<uint32_t> off(std::max<size_t>(rows_total, 1) * 64);
-    for (int pi = 0; pi < d.f_npairs; ++pi)
+    parallel_chunks(d.f_npairs, 64, [&](int pa, int pb) {
+    for (int pi = pa; pi < pb; ++pi)
       for (int hh = 0; hh < 2; ++hh) {
         const int ul = umap[2 * pi + hh];
         for (uint32_t sidx = 0; sidx < pE[pi]; ++sidx)
@@ -192,6 +239,7 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
             off[((size_t)pB[pi] + sidx) * 64 + hh * 32 + r] = v;
           }
       }
+    });
     d.f_slots = rows_total;
     CHK(dalloc(&d.f_unit_map, umap.size(), false));
     HIPCHK(hipMemcpy(d.f_unit_map, umap.data(), umap.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -205,8 +253,10 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
       d.pair_ok = d.mz + 32 < 65536;
       std::vector<uint32_t> off16(std::max<size_t>(rows_total / 2, 1) * 64, 0);
       if (d.pair_ok)
-        for (size_t r2 = 0; r2 < rows_total / 2; ++r2)
-          for (int l = 0; l < 64; ++l) off16[r2 * 64 + l] = (off[(2 * r2) * 64 + l] & 0xFFFFu) | (off[(2 * r2 + 1) * 64 + l] << 16);
+        parallel_chunks((int)(rows_total / 2), 4096, [&](int ra, int rb) {
+          for (size_t r2 = (size_t)ra; r2 < (size_t)rb; ++r2)
+            for (int l = 0; l < 64; ++l) off16[r2 * 64 + l] = (off[(2 * r2) * 64 + l] & 0xFFFFu) | (off[(2 * r2 + 1) * 64 + l] << 16);
+        });
       CHK(dalloc(&d.f_off16, off16.size(), false));
       HIPCHK(hipMemcpy(d.f_off16, off16.data(), off16.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
@@ -391,6 +441,100 @@ static int set_tau(bnmtf_model* h, double tau) {
 
 static int bnmtf_alloc_extras(bnmtf_model* h, const double* lambdaS);
 
+// ------------------------------------------------------------ sample hand-off
+// run() hands every sample to the host (all_U[it], all_V[it]; bnmf_gibbs_optimised.py:146-148).  The factor is packed
+// ([rows][KP] -> [rows][W]) into a device snapshot slot on the compute stream -- a few microseconds -- and the compute
+// stream moves on to the next iteration; a copy stream takes the slot to the host behind it.  Caller buffers that are
+// pinned (bnmtf_host_alloc, or registered by the caller) receive the copy directly, at PCIe rate and with no host work;
+// pageable ones go through a pinned ring that the calling thread empties kDepth iterations behind the enqueue front.
+struct SampleSink {
+  static constexpr int kDepth = 4;
+  struct Mat { const float* src; int rows, W, KP; float* dst; size_t off; };
+  bnmtf_model* h = nullptr;
+  Mat m[3]; int nmat = 0;
+  size_t per_it = 0;            // floats per iteration over all matrices
+  bool active = false, direct = true;
+  int n_iter = 0;
+
+  void add(const float* src, int rows, int W, int KP, float* dst) {
+    if (!dst) return;
+    m[nmat++] = Mat{src, rows, W, KP, dst, per_it};
+    per_it += (size_t)rows * W;
+  }
+  static bool pinned(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+  }
+  int begin(bnmtf_model* h_, int n_iter_) {
+    h = h_; n_iter = n_iter_;
+    if (nmat == 0) return BNMTF_OK;
+    active = true;
+    for (int i = 0; i < nmat; ++i) direct = direct && pinned(m[i].dst) && pinned(m[i].dst + (size_t)n_iter * m[i].rows * m[i].W - 1);
+    if (getenv("BNMTF_SAMPLES_RING")) direct = false;       // test hook: force the pageable path
+    if (!h->copy_stream) {
+      HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+      for (int s = 0; s < kDepth; ++s) {
+        HIPCHK(hipEventCreateWithFlags(&h->snap_ready[s], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->copy_done[s], hipEventDisableTiming));
+      }
+    }
+    if (h->snap_dev_cap < per_it * kDepth) {
+      dfree(h->snap_dev);
+      CHK(dalloc(&h->snap_dev, per_it * kDepth, false));
+      h->snap_dev_cap = per_it * kDepth;
+    }
+    if (!direct && h->snap_host_cap < per_it * kDepth) {
+      if (h->snap_host) (void)hipHostFree(h->snap_host);
+      h->snap_host = nullptr; h->snap_host_cap = 0;
+      HIPCHK(hipHostMalloc((void**)&h->snap_host, per_it * kDepth * sizeof(float), hipHostMallocDefault));
+      h->snap_host_cap = per_it * kDepth;
+    }
+    return BNMTF_OK;
+  }
+  void drain_slot(int it) {        // ring path: iteration `it` has landed in its pinned slot -> the caller's arrays
+    const float* slot = h->snap_host + (size_t)(it % kDepth) * per_it;
+    for (int i = 0; i < nmat; ++i)
+      memcpy(m[i].dst + (size_t)it * m[i].rows * m[i].W, slot + m[i].off, (size_t)m[i].rows * m[i].W * sizeof(float));
+  }
+  // before iteration `it` is enqueued: its slot must have been taken to the host (iteration it - kDepth)
+  int open_slot(int it) {
+    if (!active || it < kDepth) return BNMTF_OK;
+    const int s = it % kDepth;
+    if (!direct) { HIPCHK(hipEventSynchronize(h->copy_done[s])); drain_slot(it - kDepth); }
+    HIPCHK(hipStreamWaitEvent(h->stream, h->copy_done[s], 0));
+    return BNMTF_OK;
+  }
+  // matrix `src` is final for iteration `it`: pack it into the slot (compute stream)
+  void snapshot(int it, const float* src) {
+    if (!active) return;
+    for (int i = 0; i < nmat; ++i)
+      if (m[i].src == src) launch_compact_rows(src, m[i].rows, m[i].W, m[i].KP, h->snap_dev + (size_t)(it % kDepth) * per_it + m[i].off, h->stream);
+  }
+  int close_slot(int it) {         // every matrix of iteration `it` is in the slot: hand it to the copy stream
+    if (!active) return BNMTF_OK;
+    const int s = it % kDepth;
+    HIPCHK(hipEventRecord(h->snap_ready[s], h->stream));
+    HIPCHK(hipStreamWaitEvent(h->copy_stream, h->snap_ready[s], 0));
+    const float* slot = h->snap_dev + (size_t)s * per_it;
+    if (direct) {
+      for (int i = 0; i < nmat; ++i)
+        HIPCHK(hipMemcpyAsync(m[i].dst + (size_t)it * m[i].rows * m[i].W, slot + m[i].off, (size_t)m[i].rows * m[i].W * sizeof(float),
+                              hipMemcpyDeviceToHost, h->copy_stream));
+    } else {
+      HIPCHK(hipMemcpyAsync(h->snap_host + (size_t)s * per_it, slot, per_it * sizeof(float), hipMemcpyDeviceToHost, h->copy_stream));
+    }
+    HIPCHK(hipEventRecord(h->copy_done[s], h->copy_stream));
+    return BNMTF_OK;
+  }
+  int finish() {
+    if (!active) return BNMTF_OK;
+    HIPCHK(hipStreamSynchronize(h->copy_stream));
+    if (!direct) for (int it = std::max(0, n_iter - kDepth); it < n_iter; ++it) drain_slot(it);
+    return BNMTF_OK;
+  }
+};
+
 static int ensure_rec(bnmtf_model* h, size_t n) {
   if (h->rec_cap >= n) return BNMTF_OK;
   dfree(h->rec); dfree(h->gunit);
@@ -450,6 +594,7 @@ int bnmtf_create(const bnmtf_problem* p, bnmtf_handle* out) {
   if (p->world > p->I || p->world > p->J) { set_error("bnmtf_create: world %d larger than a matrix dimension", p->world); return BNMTF_EINVAL; }
   HIPCHK(hipSetDevice(p->device));
 
+  const auto t_create0 = std::chrono::steady_clock::now();
   bnmtf_model* h = new bnmtf_model();
   h->I = p->I; h->J = p->J; h->K = p->K; h->L = p->L;
   h->alpha = p->alpha; h->beta = p->beta; h->seed = p->seed;
@@ -463,12 +608,32 @@ int bnmtf_create(const bnmtf_problem* p, bnmtf_handle* out) {
   // observed counts, training-mask constants (fp64) and the empty row/column check
   std::vector<uint32_t> rc(I, 0), cc(J, 0);
   double n_obs = 0, sR = 0, sR2 = 0;
-  for (int i = 0; i < I; ++i)
-    for (int j = 0; j < J; ++j)
-      if (M[(size_t)i * J + j]) {
-        const double r = (double)R[(size_t)i * J + j];
-        rc[i]++; cc[j]++; n_obs += 1.0; sR += r; sR2 += r * r;
+  {
+    constexpr int kRows = 64;                     // fixed chunks, combined in chunk order: the sums do not depend on the thread count
+    const int nch = (I + kRows - 1) / kRows;
+    std::vector<double> part((size_t)nch * 3, 0.0);
+    std::vector<std::vector<uint32_t>> ccp(nch);
+    parallel_chunks(I, kRows, [&](int a, int b) {
+      const int ch = a / kRows;
+      std::vector<uint32_t>& cl = ccp[ch];
+      cl.assign(J, 0);
+      double n = 0, s1 = 0, s2 = 0;
+      for (int i = a; i < b; ++i) {
+        uint32_t cnt = 0;
+        for (int j = 0; j < J; ++j)
+          if (M[(size_t)i * J + j]) {
+            const double r = (double)R[(size_t)i * J + j];
+            ++cnt; cl[j]++; s1 += r; s2 += r * r;
+          }
+        rc[i] = cnt; n += cnt;
       }
+      part[(size_t)ch * 3] = n; part[(size_t)ch * 3 + 1] = s1; part[(size_t)ch * 3 + 2] = s2;
+    });
+    for (int ch = 0; ch < nch; ++ch) {
+      n_obs += part[(size_t)ch * 3]; sR += part[(size_t)ch * 3 + 1]; sR2 += part[(size_t)ch * 3 + 2];
+      for (int j = 0; j < J; ++j) cc[j] += ccp[ch][j];
+    }
+  }
   for (int i = 0; i < I; ++i) if (!rc[i]) { set_error("Fully unobserved row in R, row %d.", i); return fail(BNMTF_EINVAL); }
   for (int j = 0; j < J; ++j) if (!cc[j]) { set_error("Fully unobserved column in R, column %d.", j); return fail(BNMTF_EINVAL); }
   h->n_obs = n_obs; h->sumR = sR; h->sumR2 = sR2;
@@ -499,19 +664,31 @@ int bnmtf_create(const bnmtf_problem* p, bnmtf_handle* out) {
 
   if (p->world > 1) {
     if ((rcode = comm_create(&h->comm, p->comm_id, p->rank, p->world, h->stream))) return fail(rcode);
+    // every rank must hold the same Philox key (same draws, same tau variates): compare through the communicator
+    const double mine[4] = {(double)(uint32_t)p->seed, (double)(uint32_t)(p->seed >> 32), -(double)(uint32_t)p->seed, -(double)(uint32_t)(p->seed >> 32)};
+    double got[4];
+    if (hipMemcpy(h->acc, mine, sizeof(mine), hipMemcpyHostToDevice) != hipSuccess) { set_error("seed check: copy failed"); return fail(BNMTF_EHIP); }
+    if ((rcode = comm_allreduce_max(h->comm, h->acc, 4, h->stream))) return fail(rcode);
+    if (hipStreamSynchronize(h->stream) != hipSuccess || hipMemcpy(got, h->acc, sizeof(got), hipMemcpyDeviceToHost) != hipSuccess) { set_error("seed check: copy failed"); return fail(BNMTF_EHIP); }
+    (void)hipMemset(h->acc, 0, 4 * sizeof(double));
+    if (memcmp(mine, got, sizeof(mine)) != 0) {
+      set_error("bnmtf_create: the ranks were given different seeds (this rank %llu): a sharded model needs one shared seed", (unsigned long long)p->seed);
+      return fail(BNMTF_EINVAL);
+    }
   } else if (getenv("BNMTF_FORCE_COMM")) {     // test hook: run the RCCL exchange path with a 1-rank communicator
     uint8_t id[128];
     if ((rcode = comm_unique_id(id))) return fail(rcode);
     if ((rcode = comm_create(&h->comm, id, 0, 1, h->stream))) return fail(rcode);
   }
 
-  char buf[512];
+  h->create_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create0).count();
+  char buf[768];
   snprintf(buf, sizeof(buf),
-           "I=%d J=%d K=%d L=%d rank=%d/%d rows[n=%d n_pad=%d split=%d ipw=%d inner_pad=%d nmiss=%zu nslots=%zu] "
-           "cols[n=%d n_pad=%d split=%d ipw=%d inner_pad=%d nmiss=%zu nslots=%zu] n_obs=%.0f",
+           "I=%d J=%d K=%d L=%d rank=%d/%d rows[n=%d n_pad=%d split=%d ipw=%d inner_pad=%d nmiss=%zu nslots=%zu sweep_nw=%d emax=%d generic_units=%d] "
+           "cols[n=%d n_pad=%d split=%d ipw=%d inner_pad=%d nmiss=%zu nslots=%zu sweep_nw=%d emax=%d generic_units=%d] n_obs=%.0f create_ms=%.0f",
            I, J, p->K, p->L, p->rank, p->world, h->rows.n, h->rows.n_pad, h->rows.split, h->rows.ipw, h->rows.inner_pad,
-           h->rows.nmiss, h->rows.nslots, h->cols.n, h->cols.n_pad, h->cols.split, h->cols.ipw, h->cols.inner_pad,
-           h->cols.nmiss, h->cols.nslots, n_obs);
+           h->rows.nmiss, h->rows.nslots, h->rows.f_nw, h->rows.f_emax, h->rows.f_gen_count, h->cols.n, h->cols.n_pad, h->cols.split,
+           h->cols.ipw, h->cols.inner_pad, h->cols.nmiss, h->cols.nslots, h->cols.f_nw, h->cols.f_emax, h->cols.f_gen_count, n_obs, h->create_ms);
   h->description = buf;
   *out = h;
   return BNMTF_OK;
@@ -529,6 +706,13 @@ int bnmtf_destroy(bnmtf_handle h) {
   dfree(h->tau_d); dfree(h->tau_f); dfree(h->acc); dfree(h->rec); dfree(h->gunit); dfree(h->S);
   for (auto& pe : h->pending_events) { (void)hipEventDestroy(pe.second.first); (void)hipEventDestroy(pe.second.second); }
   for (auto e : h->event_pool) (void)hipEventDestroy(e);
+  if (h->copy_stream) {
+    (void)hipStreamSynchronize(h->copy_stream);
+    for (int s2 = 0; s2 < 8; ++s2) { if (h->snap_ready[s2]) (void)hipEventDestroy(h->snap_ready[s2]); if (h->copy_done[s2]) (void)hipEventDestroy(h->copy_done[s2]); }
+    (void)hipStreamDestroy(h->copy_stream);
+  }
+  dfree(h->snap_dev);
+  if (h->snap_host) (void)hipHostFree(h->snap_host);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return BNMTF_OK;
@@ -544,6 +728,16 @@ int bnmtf_omega_counts(bnmtf_handle h, uint64_t* total, uint32_t* row, uint32_t*
   if (total) *total = (uint64_t)h->n_obs;
   if (row) memcpy(row, h->rows.obs_count.data(), sizeof(uint32_t) * h->I);
   if (col) memcpy(col, h->cols.obs_count.data(), sizeof(uint32_t) * h->J);
+  return BNMTF_OK;
+}
+
+int bnmtf_host_alloc(size_t bytes, void** out) {
+  *out = nullptr;
+  HIPCHK(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+  return BNMTF_OK;
+}
+int bnmtf_host_free(void* p) {
+  if (p) HIPCHK(hipHostFree(p));
   return BNMTF_OK;
 }
 
@@ -631,11 +825,16 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
   // the [3] accumulator is only written by the generic sweep kernel (and summed across ranks): zero once, reset when used
   const bool acc_used = h->comm != nullptr || !h->use_fast || !c.fast_ok || c.f_gen_count > 0 || !sweep_fast_supported(c.KP, c.pw);
   HIPCHK(hipMemsetAsync(h->acc, 0, 4 * sizeof(double), h->stream));
-  std::vector<hipEvent_t> ev(times_out ? n_iter + 1 : 0);
-  for (auto& e : ev) HIPCHK(hipEventCreate(&e));
+  EventList ev;
+  CHK(ev.create(times_out ? n_iter + 1 : 0));
+  SampleSink sink;
+  sink.add(r.X, h->I, r.W, r.KP, U_out);
+  sink.add(c.X, h->J, c.W, c.KP, V_out);
+  CHK(sink.begin(h, n_iter));
   if (times_out) HIPCHK(hipEventRecord(ev[0], h->stream));
 
   for (int it = 0; it < n_iter; ++it) {
+    CHK(sink.open_slot(it));
     // ---- U columns: P = R~ . V, then the K sequential row-wise updates
     enqueue_gemm(h, r, c, BNMTF_KERNEL_GEMM_ROWS);
     {
@@ -644,6 +843,7 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
       enqueue_sweep(h, r, c, s, false);
     }
     if (h->comm) CHK(comm_allgather_factor(h->comm, r.X, r.KP, r.nglob, h->world, h->stream));
+    sink.snapshot(it, r.X);
     enqueue_post(h, r);
     // ---- V columns: Pv = R~^T . U
     enqueue_gemm(h, c, r, BNMTF_KERNEL_GEMM_COLS);
@@ -660,6 +860,8 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
       if (fast_stats) launch_sum_stats(c.stats, c.stats_blocks, h->acc, h->stream);   // fold the slab before the exchange
       CHK(comm_allreduce_sum(h->comm, h->acc, 4, h->stream));
     }
+    sink.snapshot(it, c.X);
+    CHK(sink.close_slot(it));
     enqueue_post(h, c);
     // ---- tau and the metrics of this sample
     FinishArgs f;
@@ -671,15 +873,11 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
     f.gunit = mode == kSweepDraw ? h->gunit + it : nullptr;
     f.tau_d = h->tau_d; f.tau_f = h->tau_f; f.rec = h->rec + (size_t)it * 5;
     launch_finish(f, h->stream);
-    // ---- sample hand-off (all_U[it], all_V[it])
-    if (U_out) HIPCHK(hipMemcpy2DAsync(U_out + (size_t)it * h->I * r.W, r.W * sizeof(float), r.X, r.KP * sizeof(float),
-                                       r.W * sizeof(float), h->I, hipMemcpyDeviceToHost, h->stream));
-    if (V_out) HIPCHK(hipMemcpy2DAsync(V_out + (size_t)it * h->J * c.W, c.W * sizeof(float), c.X, c.KP * sizeof(float),
-                                       c.W * sizeof(float), h->J, hipMemcpyDeviceToHost, h->stream));
     if (times_out) HIPCHK(hipEventRecord(ev[it + 1], h->stream));
     h->iteration++;
   }
   HIPCHK(hipStreamSynchronize(h->stream));
+  CHK(sink.finish());
   HIPCHK(hipGetLastError());
   drain_events(h);
   std::vector<double> rec((size_t)n_iter * 5);
@@ -693,7 +891,6 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
       times_out[it] = (double)ms * 1e-3;
     }
   }
-  for (auto& e : ev) (void)hipEventDestroy(e);
   return BNMTF_OK;
 }
 
@@ -761,40 +958,37 @@ int bnmtf_tn_sample(const double* mu, const double* tau, size_t n, uint64_t seed
                     uint32_t elem0, int device, double* out) {
   if (n == 0) return BNMTF_OK;
   HIPCHK(hipSetDevice(device));
-  double *dm = nullptr, *dt = nullptr, *dout = nullptr;
-  CHK(dalloc(&dm, n, false)); CHK(dalloc(&dt, n, false)); CHK(dalloc(&dout, n, false));
-  HIPCHK(hipMemcpy(dm, mu, n * sizeof(double), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dt, tau, n * sizeof(double), hipMemcpyHostToDevice));
-  launch_tn_sample(dm, dt, n, seed, (uint32_t)it, col, elem0, dout, nullptr);
-  HIPCHK(hipMemcpy(out, dout, n * sizeof(double), hipMemcpyDeviceToHost));
+  DevBuf<double> dm, dt, dout;
+  CHK(dm.alloc(n)); CHK(dt.alloc(n)); CHK(dout.alloc(n));
+  HIPCHK(hipMemcpy(dm.p, mu, n * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dt.p, tau, n * sizeof(double), hipMemcpyHostToDevice));
+  launch_tn_sample(dm.p, dt.p, n, seed, (uint32_t)it, col, elem0, dout.p, nullptr);
+  HIPCHK(hipMemcpy(out, dout.p, n * sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipGetLastError());
-  dfree(dm); dfree(dt); dfree(dout);
   return BNMTF_OK;
 }
 
 int bnmtf_tn_moments(const double* mu, const double* tau, size_t n, int device, double* exp_out, double* var_out) {
   if (n == 0) return BNMTF_OK;
   HIPCHK(hipSetDevice(device));
-  double *dm = nullptr, *dt = nullptr, *de = nullptr, *dv = nullptr;
-  CHK(dalloc(&dm, n, false)); CHK(dalloc(&dt, n, false)); CHK(dalloc(&de, n, false)); CHK(dalloc(&dv, n, false));
-  HIPCHK(hipMemcpy(dm, mu, n * sizeof(double), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dt, tau, n * sizeof(double), hipMemcpyHostToDevice));
-  launch_tn_moments(dm, dt, n, de, dv, nullptr);
-  HIPCHK(hipMemcpy(exp_out, de, n * sizeof(double), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(var_out, dv, n * sizeof(double), hipMemcpyDeviceToHost));
+  DevBuf<double> dm, dt, de, dv;
+  CHK(dm.alloc(n)); CHK(dt.alloc(n)); CHK(de.alloc(n)); CHK(dv.alloc(n));
+  HIPCHK(hipMemcpy(dm.p, mu, n * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dt.p, tau, n * sizeof(double), hipMemcpyHostToDevice));
+  launch_tn_moments(dm.p, dt.p, n, de.p, dv.p, nullptr);
+  HIPCHK(hipMemcpy(exp_out, de.p, n * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(var_out, dv.p, n * sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipGetLastError());
-  dfree(dm); dfree(dt); dfree(de); dfree(dv);
   return BNMTF_OK;
 }
 
 int bnmtf_gamma_sample(double alpha, double beta, uint64_t seed, uint64_t it, int device, double* out) {
   HIPCHK(hipSetDevice(device));
-  double* d = nullptr;
-  CHK(dalloc(&d, 1));
-  launch_gamma_sample(alpha, beta, seed, (uint32_t)it, d, nullptr);
-  HIPCHK(hipMemcpy(out, d, sizeof(double), hipMemcpyDeviceToHost));
+  DevBuf<double> d;
+  CHK(d.alloc(1, true));
+  launch_gamma_sample(alpha, beta, seed, (uint32_t)it, d.p, nullptr);
+  HIPCHK(hipMemcpy(out, d.p, sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipGetLastError());
-  dfree(d);
   return BNMTF_OK;
 }
 

@@ -16,4 +16,6 @@ void comm_destroy(Comm* c);
 // [nglob*r/world, nglob*(r+1)/world)) in place (the caller re-lays it out afterwards).
 int comm_allgather_factor(Comm* c, float* X, int KP, int nglob, int world, hipStream_t st);
 int comm_allreduce_sum(Comm* c, double* buf, int count, hipStream_t st);
+int comm_allreduce_max(Comm* c, double* buf, int count, hipStream_t st);
+int comm_allreduce_sum_f32(Comm* c, float* buf, int count, hipStream_t st);
 }  // namespace bnmtf

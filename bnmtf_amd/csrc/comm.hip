@@ -3,6 +3,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -182,27 +183,37 @@ int comm_allgather_factor(Comm* c, float* X, int KP, int nglob, int world, hipSt
   return BNMTF_OK;
 }
 
-int comm_allreduce_sum(Comm* c, double* buf, int count, hipStream_t st) {
+// op: 0 sum, 1 max.  In-process transport: every rank forms the result in rank order, so all ranks hold the same bits.
+template <typename T>
+static int allreduce_impl(Comm* c, T* buf, int count, int op, ncclDataType_t dt, hipStream_t st) {
   if (c->local) {
     LocalGroup& g = *c->local;
+    const size_t words = ((size_t)c->world * count * sizeof(T) + sizeof(double) - 1) / sizeof(double);
     {
       std::lock_guard<std::mutex> lk(g.m);
-      if (g.vals.size() < (size_t)c->world * count) g.vals.assign((size_t)c->world * count, 0.0);
+      if (g.vals.size() < words) g.vals.assign(words, 0.0);
     }
     if (!g.barrier()) { set_error("local communicator: peer did not arrive"); return BNMTF_ECOMM; }
-    HIPCHK(hipMemcpyAsync(g.vals.data() + (size_t)c->rank * count, buf, count * sizeof(double), hipMemcpyDeviceToHost, st));
+    T* all = reinterpret_cast<T*>(g.vals.data());
+    HIPCHK(hipMemcpyAsync(all + (size_t)c->rank * count, buf, count * sizeof(T), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (!g.barrier()) { set_error("local communicator: peer did not arrive"); return BNMTF_ECOMM; }
-    std::vector<double> sum(count, 0.0);
-    for (int r = 0; r < c->world; ++r)                     // rank order: every rank forms the same sum
-      for (int t = 0; t < count; ++t) sum[t] += g.vals[(size_t)r * count + t];
-    HIPCHK(hipMemcpyAsync(buf, sum.data(), count * sizeof(double), hipMemcpyHostToDevice, st));
+    std::vector<T> res(count);
+    for (int t = 0; t < count; ++t) {
+      T v = all[t];
+      for (int r = 1; r < c->world; ++r) { const T x = all[(size_t)r * count + t]; v = op == 1 ? std::max(v, x) : v + x; }
+      res[t] = v;
+    }
+    HIPCHK(hipMemcpyAsync(buf, res.data(), count * sizeof(T), hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
     if (!g.barrier()) { set_error("local communicator: peer did not arrive"); return BNMTF_ECOMM; }
     return BNMTF_OK;
   }
-  NCHK(g_api.AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, c->comm, st));
+  NCHK(g_api.AllReduce(buf, buf, (size_t)count, dt, op == 1 ? ncclMax : ncclSum, c->comm, st));
   return BNMTF_OK;
 }
+int comm_allreduce_sum(Comm* c, double* buf, int count, hipStream_t st) { return allreduce_impl(c, buf, count, 0, ncclDouble, st); }
+int comm_allreduce_max(Comm* c, double* buf, int count, hipStream_t st) { return allreduce_impl(c, buf, count, 1, ncclDouble, st); }
+int comm_allreduce_sum_f32(Comm* c, float* buf, int count, hipStream_t st) { return allreduce_impl(c, buf, count, 0, ncclFloat, st); }
 
 }  // namespace bnmtf

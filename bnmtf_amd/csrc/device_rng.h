@@ -27,8 +27,9 @@ __host__ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, u
   return U4{c0, c1, c2, c3};
 }
 
-// uint32 -> (0,1), 24 significant bits: identical value in fp32 and fp64
-__device__ __forceinline__ float u24(uint32_t r) { return ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+// uint32 -> (0,1) from the top 23 bits: (n + 0.5) * 2^-23 with n < 2^23 needs 24 significant bits, so the value is exact
+// in fp32 (and the same number in the oracle's fp64), lies strictly inside (0,1) and never rounds to 1.0
+__device__ __forceinline__ float u23(uint32_t r) { return ((float)(r >> 9) + 0.5f) * (1.0f / 8388608.0f); }
 __host__ __device__ __forceinline__ double u32d(uint32_t r) { return ((double)r + 0.5) * (1.0 / 4294967296.0); }
 
 // Per-draw constants of TN(mu, tau_p) on [0,inf): a = -mu*sqrt(tau_p).
@@ -56,7 +57,7 @@ __device__ __forceinline__ TnParams tn_params(float mu, float tau_p) {
 __device__ __forceinline__ bool tn_candidate(const TnParams& p, uint32_t elem, uint32_t col, uint32_t it,
                                              uint32_t stream, uint32_t cand, uint32_t k0, uint32_t k1, float* x) {
   const U4 r = philox4x32_10(elem, col, it, stream + 16u * cand, k0, k1);
-  const float u1 = u24(r.x), u2 = u24(r.y);
+  const float u1 = u23(r.x), u2 = u23(r.y);
   const float nl = -logf(u1);
   bool acc;
   if (p.tail) {
@@ -74,7 +75,7 @@ __device__ __forceinline__ bool tn_candidate(const TnParams& p, uint32_t elem, u
 
 // acceptance / value of a candidate from two raw 32-bit words (Philox done elsewhere)
 __device__ __forceinline__ bool tn_eval_words(const TnParams& p, uint32_t r0, uint32_t r1, float* x) {
-  const float u1 = u24(r0), u2 = u24(r1);
+  const float u1 = u23(r0), u2 = u23(r1);
   const float nl = -logf(u1);
   if (p.tail) {
     const float e = nl / p.lam, t = e - p.d;

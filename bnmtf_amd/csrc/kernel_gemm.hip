@@ -299,8 +299,8 @@ __global__ __launch_bounds__(256, (TW == 4 ? 1 : 2)) void gemm_bf16x3_kernel(Gem
 
 void launch_gemm(const GemmArgs& a, int KP, hipStream_t st) {
   dim3 grid(a.n_pad / 128, a.split), block(256);
-  static const char* mode = getenv("BNMTF_GEMM");                 // "f32": the f32-MFMA kernel (kept for comparison)
-  static const bool f32 = mode && !strcmp(mode, "f32");
+  const char* mode = getenv("BNMTF_GEMM");                        // "f32": the f32-MFMA kernel (kept as the cross-check of the bf16x3 products: tests/test_contraction_gpu.py); read per launch
+  const bool f32 = mode && !strcmp(mode, "f32");
   if (!f32) {
     // three raw-operand register sets (two 8 KiB steps in flight per wave); deeper rings measured no faster
     // TW = 4 column tiles (128 columns) per wave, one wave per SIMD.  TW = 2 with two waves per SIMD (grid n_pad/64) was

@@ -1,6 +1,8 @@
 // Small kernels around the two hot ones: Gram matrices, end-of-iteration scalar
 // work (masked SSE from Gram identities, tau draw, metrics), direct fp64 metric
 // sums for predict(), layout helpers and the stand-alone distribution hooks.
+#include <algorithm>
+
 #include "kernels.h"
 #include "device_rng.h"
 
@@ -261,6 +263,43 @@ __global__ __launch_bounds__(256) void sum_stats_kernel(const double* stats, int
 }
 void launch_sum_stats(const double* stats, int nblocks, double* acc, hipStream_t st) {
   hipLaunchKernelGGL(sum_stats_kernel, dim3(1), dim3(256), 0, st, stats, nblocks, acc);
+}
+
+// out[c] += sum_r stats[r * ld + c] for c < ncols (<= 8): the per-unit / per-block partial sums of a sweep folded into one
+// short vector, so that a multi-GPU run exchanges a handful of doubles
+__global__ __launch_bounds__(256) void sum_cols_kernel(const double* stats, int nrows, int ld, int ncols, double* out) {
+  __shared__ double red[4][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double v[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int b = threadIdx.x; b < nrows; b += 256)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) if (t < ncols) v[t] += stats[(size_t)b * ld + t];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v[t] += __shfl_xor(v[t], m, 64);
+    if (lane == 0) red[wave][t] = v[t];
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < ncols) out[threadIdx.x] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+void launch_sum_cols(const double* stats, int nrows, int ld, int ncols, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(sum_cols_kernel, dim3(1), dim3(256), 0, st, stats, nrows, ld, ncols, out);
+}
+
+// sample hand-off: the W true columns of X [rows][KP] packed into dst [rows][W] (what all_U[it] holds)
+__global__ __launch_bounds__(256) void compact_rows_kernel(const float* X, int rows, int W, int KP, float* dst) {
+  const size_t n = (size_t)rows * W;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+    const size_t r = e / W; const int k = (int)(e - r * W);
+    dst[e] = X[r * KP + k];
+  }
+}
+void launch_compact_rows(const float* X, int rows, int W, int KP, float* dst, hipStream_t st) {
+  if (rows <= 0) return;
+  if (W == KP) { (void)hipMemcpyAsync(dst, X, (size_t)rows * W * sizeof(float), hipMemcpyDeviceToDevice, st); return; }
+  const size_t n = (size_t)rows * W;
+  hipLaunchKernelGGL(compact_rows_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, st, X, rows, W, KP, dst);
 }
 
 // ---------------------------------------------------------------------------

@@ -290,10 +290,9 @@ bool sweep_vb_supported(int KP, int pw) { return sweep_vb_lds_bytes(KP, pw) <= 1
 
 template <int NX, int NW, int NS>
 static void launch_vb_inst(const SweepArgs& a, const FastArgs& f, hipStream_t st) {
-  static bool once = false;
-  if (!once) { (void)hipFuncSetAttribute((const void*)sweep_vb_kernel<NX, NW, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+  static std::atomic<uint64_t> lds_ok{0};
   const int nblocks = sweep_vb_blocks(f.npairs, NW);
-  if (nblocks > 0) hipLaunchKernelGGL((sweep_vb_kernel<NX, NW, NS>), dim3(nblocks), dim3((NW + NS) * 64), sweep_vb_lds_bytes(a.KP, f.pw), st, a, f);
+  if (nblocks > 0 && allow_full_lds((const void*)sweep_vb_kernel<NX, NW, NS>, lds_ok)) hipLaunchKernelGGL((sweep_vb_kernel<NX, NW, NS>), dim3(nblocks), dim3((NW + NS) * 64), sweep_vb_lds_bytes(a.KP, f.pw), st, a, f);
 }
 
 // f.nw = 16: 16 unit waves per block; anything else: 8 unit waves + 2 service waves

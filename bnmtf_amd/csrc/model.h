@@ -114,4 +114,10 @@ struct bnmtf_model {
   std::vector<hipEvent_t> event_pool;
   bnmtf::Comm* comm = nullptr;
   std::string description;
+  // sample hand-off (all_U / all_V ...): device snapshots + a copy stream (api.hip, SampleSink)
+  hipStream_t copy_stream = nullptr;
+  float* snap_dev = nullptr; size_t snap_dev_cap = 0;       // [depth][floats per iteration]
+  float* snap_host = nullptr; size_t snap_host_cap = 0;     // pinned ring, used when the caller's buffers are pageable
+  hipEvent_t snap_ready[8] = {nullptr}, copy_done[8] = {nullptr};
+  double create_ms = 0.0;                                   // wall time of bnmtf_create (host layout + uploads)
 };

@@ -1,6 +1,8 @@
 // Shared device helpers of the register-resident sweep kernels (sweep_chip.inc, kernel_sweep_vb.hip, kernel_bnmtf.hip):
 // half-wave reductions and broadcasts, the one-instruction TN candidate arithmetic, LDS-DMA panel staging.
 #pragma once
+#include <atomic>
+
 #include "kernels.h"
 #include "device_rng.h"
 
@@ -76,8 +78,8 @@ struct TnCand { float nl, z, u2; };
 __device__ __forceinline__ TnCand tn_cand_pre(uint32_t r0, uint32_t r1) {
 #pragma clang fp contract(off)
   TnCand c;
-  const float u1 = u24(r0);
-  c.u2 = u24(r1);
+  const float u1 = u23(r0);
+  c.u2 = u23(r1);
   c.nl = -0.69314718f * __builtin_amdgcn_logf(u1);                       // v_log_f32 is log2
   c.z = __builtin_amdgcn_sqrtf(2.0f * c.nl) * __builtin_amdgcn_cosf(c.u2);   // v_cos_f32 takes revolutions
   return c;
@@ -147,6 +149,19 @@ __device__ __forceinline__ float slab_sum_ordered(const float* slabs, int split,
     for (int j = 0; j < 8; ++j) if (s0 + j < split) p += t[j];
   }
   return p;
+}
+
+// Dynamic-LDS opt-in of a kernel (more than 64 KiB): a per-DEVICE attribute, so it is set once per (kernel, device) --
+// a process may hold handles on several devices -- and its result is checked (a launch that asks for more LDS than the
+// attribute allows fails late and anonymously otherwise).  `mask` is the calling instantiation's own flag word.
+inline bool allow_full_lds(const void* kernel, std::atomic<uint64_t>& mask) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 63;     // devices >= 63 share a flag: set every time
+  const uint64_t bit = 1ull << dev;
+  if (dev != 63 && (mask.load(std::memory_order_acquire) & bit)) return true;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+  mask.fetch_or(bit, std::memory_order_release);
+  return true;
 }
 
 typedef __attribute__((address_space(3))) const float lds_cf;

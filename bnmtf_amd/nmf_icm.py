@@ -29,8 +29,8 @@ class nmf_icm(bnmf_gibbs_optimised):
         """:93-111 ('random' consumes numpy.random.exponential in the reference's (i,k) order)."""
         assert init in ['random', 'exp'], "Unknown initialisation option: %s. Should be 'random' or 'exp'." % init
         if init == 'random':
-            self.U = np.random.exponential(scale=1.0 / self.lambdaU)
-            self.V = np.random.exponential(scale=1.0 / self.lambdaV)
+            self.U = self._rng().exponential(scale=1.0 / self.lambdaU)
+            self.V = self._rng().exponential(scale=1.0 / self.lambdaV)
         else:
             self.U = 1.0 / self.lambdaU
             self.V = 1.0 / self.lambdaV

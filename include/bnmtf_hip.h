@@ -89,6 +89,13 @@ int bnmtf_sync(bnmtf_handle h);
  * row/col may be NULL. */
 int bnmtf_omega_counts(bnmtf_handle h, uint64_t* total, uint32_t* row, uint32_t* col);
 
+/* Page-locked host memory for the sample arrays run() fills (all_U, all_V, ...; bnmf_gibbs_optimised.py:125-127,
+ * 146-148).  *_gibbs_run accepts ANY host pointer for its sample outputs; buffers from here (or registered by the
+ * caller with hipHostRegister) are written by asynchronous device-to-host copies that overlap the following
+ * iterations, pageable ones go through an internal pinned ring and a host memcpy. */
+int bnmtf_host_alloc(size_t bytes, void** out);
+int bnmtf_host_free(void* p);
+
 /* Gibbs iteration counter = RNG counter word 2 (continues across run calls). */
 int bnmtf_set_iteration(bnmtf_handle h, uint64_t it);
 int bnmtf_get_iteration(bnmtf_handle h, uint64_t* it);

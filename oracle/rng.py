@@ -71,9 +71,10 @@ def philox4x32_10(c0, c1, c2, c3, seed):
             c2.astype(np.uint32), c3.astype(np.uint32))
 
 
-def u24(r):
-    """uint32 -> uniform in (0,1) with 24 significant bits (exact in fp32)."""
-    return ((r >> np.uint32(8)).astype(np.float64) + 0.5) * (1.0 / 16777216.0)
+def u23(r):
+    """uint32 -> uniform in (0,1) from the top 23 bits: (n + 0.5) * 2^-23, n < 2^23, is exact in
+    fp32 (24 significant bits), strictly inside (0,1), and the same number on the device."""
+    return ((r >> np.uint32(9)).astype(np.float64) + 0.5) * (1.0 / 8388608.0)
 
 
 def u32(r):
@@ -109,7 +110,7 @@ def tn_draw(mu, tau, elem, col, it, stream, seed, max_cand=4096):
             idx = np.nonzero(todo)[0]
             r0, r1, _, _ = philox4x32_10(elem[idx], col[idx], it,
                                          int(stream) + 16 * cand, seed)
-            u1 = u24(r0); u2 = u24(r1)
+            u1 = u23(r0); u2 = u23(r1)
             nl = -np.log(u1)
             t = tail[idx]
             # normal proposal

@@ -9,12 +9,23 @@ from bnmtf_amd import bnmf_vb_optimised
 
 pytestmark = pytest.mark.gpu
 
+# BNMTF_WIDE=1 (read when the handle is created) selects the 16-unit-wave block shape of the VB sweep -- the shape the
+# 8192 x 8192 configuration runs, sweep_vb_kernel<., 16, 0> with the fp32 moments routine on wave 0 -- on any size
+SHAPES = pytest.mark.parametrize("wide", [None, "1"], ids=["8wave", "16wave"])
 
-def test_toy_trajectory_matches_reference(golden):
+
+def _shape(monkeypatch, wide):
+    if wide is not None:
+        monkeypatch.setenv("BNMTF_WIDE", wide)
+
+
+@SHAPES
+def test_toy_trajectory_matches_reference(golden, monkeypatch, wide):
     """Config-5 algorithm on config-1 data: MSE / exptau / ELBO per iteration vs the reference.
     The q-parameters live on the device in fp32 (reductions fp64); 20 deterministic fixed-point
     iterations amplify that rounding (the run passes through a fast transition around iterations 8-12): rel 1e-3 on
     MSE and exptau, 2e-4 on the ELBO; the first iterations, before any amplification, 2e-5."""
+    _shape(monkeypatch, wide)
     g = golden("bnmf_vb.npz").case("toy")
     t = golden("toy_data.npz").case("bnmf")
     I, J = t["R"].shape; K = 10
@@ -40,11 +51,14 @@ def test_toy_trajectory_matches_reference(golden):
     assert len(b.all_times) == 20
 
 
-def test_ragged_case_matches_reference(golden):
+@SHAPES
+def test_ragged_case_matches_reference(golden, monkeypatch, wide):
+    _shape(monkeypatch, wide)
     g = golden("bnmf_vb.npz").case("r31x23")
     K = 4
     b = bnmf_vb_optimised(g["R"], g["M"], K, dict(alpha=2., beta=.5, lambdaU=g["lambdaU"], lambdaV=g["lambdaV"]), verbose=False)
     b.initialise('exp', {"tauU": g["tauU0"], "tauV": g["tauV0"]})
+    assert ("sweep_nw=16" in b.describe()) == (wide == "1")
     b.run(10)
     np.testing.assert_allclose(b.all_performances['MSE'], g["mse"], rtol=1e-3)
     np.testing.assert_allclose(b.all_elbo, g["elbo"], rtol=1e-4)
@@ -105,10 +119,12 @@ def test_large_shape_identity():
     assert abs(p["MSE"] - mse[-1]) < 1e-4 * mse[-1]
 
 
-def test_fast_vb_sweep_equals_generic_sweep(monkeypatch):
+@SHAPES
+def test_fast_vb_sweep_equals_generic_sweep(monkeypatch, wide):
     """The register/LDS-resident VB sweep (kernel_sweep_vb.hip + vb_pieces_kernel) against the generic kernel on a
     ragged problem: same fixed-point iteration, fp32 rounding differences only."""
     from bnmtf_amd.synthetic import generate_bnmf
+    _shape(monkeypatch, wide)
     I, J, K = 600, 500, 20
     R, M, _, _ = generate_bnmf(I, J, K, 0.15, seed_data=3, seed_mask=4)
     pri = dict(alpha=1., beta=1., lambdaU=0.1, lambdaV=0.1)
@@ -118,6 +134,7 @@ def test_fast_vb_sweep_equals_generic_sweep(monkeypatch):
             monkeypatch.setenv("BNMTF_VB_GENERIC", "1")
         b = bnmf_vb_optimised(R, M, K, pri, verbose=False)
         b.initialise('exp')
+        assert ("sweep_nw=16" in b.describe()) == (wide == "1")
         b.run(6)
         res[mode] = (np.array(b.all_performances['MSE']), np.array(b.all_exp_tau), np.array(b.all_elbo), b.expU.copy(), b.varU.copy(), b.tauV.copy())
     f, g = res["fast"], res["generic"]

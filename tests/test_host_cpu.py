@@ -158,3 +158,37 @@ def test_masked_kmeans_helper():
     assert km.clustering_results.shape == (60, 3) and (km.clustering_results.sum(axis=1) == 1).all()
     lab = km.clustering_results.argmax(axis=1)
     assert len(set(lab[:20])) == 1 and len(set(lab[20:40])) == 1 and len(set(lab[40:])) == 1 and len(set(lab)) == 3
+
+
+def test_sharded_model_without_seed_gets_one_shared_key_and_one_shared_initialisation():
+    """Every rank of a sharded model must run the same chain: with seed=None the Philox key is derived from the
+    communicator id all ranks hold (not from each process' own NumPy stream), and initialise('random') draws from a
+    stream seeded with it, so the replicated U, V are the same on every rank.  (bnmtf_create re-checks the key across
+    the ranks through the communicator.)"""
+    R = np.ones((6, 5)); M = np.ones((6, 5))
+    pri = dict(alpha=1, beta=1, lambdaU=1., lambdaV=1.)
+    cid = bytes(range(128))
+    ranks = []
+    for r in range(2):
+        np.random.seed(100 + r)                       # the processes' own global streams differ
+        ranks.append(bnmf_gibbs_optimised(R, M, 3, pri, verbose=False, rank=r, world=2, comm_id=cid))
+    assert ranks[0]._seed == ranks[1]._seed and ranks[0]._seed is not None
+    a, b = ranks[0]._rng().exponential(size=(6, 3)), ranks[1]._rng().exponential(size=(6, 3))
+    assert np.array_equal(a, b)
+    other = bnmf_gibbs_optimised(R, M, 3, pri, verbose=False, rank=0, world=2, comm_id=bytes(128))
+    assert other._seed != ranks[0]._seed
+    single = bnmf_gibbs_optimised(R, M, 3, pri, verbose=False)
+    assert single._rng() is np.random                 # single GPU: the reference's global stream
+    with pytest.raises(AssertionError):
+        bnmf_gibbs_optimised(R, M, 3, pri, verbose=False, rank=0, world=2)
+    explicit = bnmf_gibbs_optimised(R, M, 3, pri, verbose=False, seed=5, rank=1, world=2, comm_id=cid)
+    assert explicit._seed == 5
+
+
+def test_non_binary_mask_is_rejected_before_the_device_sees_it():
+    R = np.ones((4, 3)); M = np.ones((4, 3)); M[1, 1] = 0.5
+    b = bnmf_gibbs_optimised(R, M, 2, dict(alpha=1, beta=1, lambdaU=1., lambdaV=1.), verbose=False)
+    b.U = np.ones((4, 2)); b.V = np.ones((3, 2)); b.tau = 1.0
+    with pytest.raises(AssertionError) as e:
+        b.run(1)
+    assert str(e.value) == "The indicator matrix M must contain only 0 and 1."
