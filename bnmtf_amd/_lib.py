@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # BNMTF_LIB: load another build of the library (tools/: the phase-timing or an A/B build) without touching the shipped one
 LIB_PATH = os.environ.get("BNMTF_LIB") or os.path.join(_HERE, "lib", "libbnmtf_hip.so")
 
-KERNEL_GEMM_ROWS, KERNEL_GEMM_COLS, KERNEL_SWEEP_ROWS, KERNEL_SWEEP_COLS = 0, 1, 2, 3
+KERNEL_GEMM_ROWS, KERNEL_GEMM_COLS, KERNEL_SWEEP_ROWS, KERNEL_SWEEP_COLS, KERNEL_SWEEP_S = 0, 1, 2, 3, 4
 UPDATE_DRAW, UPDATE_MODE, UPDATE_ICM = 0, 1, 2
 
 
