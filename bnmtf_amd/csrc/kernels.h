@@ -199,6 +199,39 @@ struct SDrawArgs {
 };
 void launch_srow_draw(const SDrawArgs& a, hipStream_t st);
 
+// ---------------------------------------------------------------------------
+// BNMTF S step as a dense K.L x K.L system (kernel_ssys.hip); K, L <= 32
+// ---------------------------------------------------------------------------
+struct SColGramArgs {       // W~_j = C~f - sum_{i in miss(j)} (F_i F_i^T + diag varF_i) for the local columns
+  int n, K;
+  const float* F;                      // [I+][32] row major, padding slots of idx point at a zero row
+  const float* varF;                   // [I+][32] or null (Gibbs)
+  const double* Cf64;                  // F^T F [32][32]
+  const double* cf_diag_extra;         // sum_i varF_ik [32] or null
+  const uint32_t* slot_ptr; const uint32_t* idx;   // 64-wide slots of the cols direction
+  float* Wt;                           // [n][32*32]
+};
+void launch_scol_gram(const SColGramArgs& a, hipStream_t st);
+struct SSysGemmArgs {       // slabs[s][(k,l)][(k',l')] = sum_{j in range s} W~_j[k][k'] (G_jl G_jl' + [l = l'] varG_jl)
+  int n, n0, K, L, nsplit;
+  const float* Wt; const float* G; const float* varG;   // G, varG [J][32] (global rows n0 + j)
+  float* slabs;                        // [nsplit][K L][K L]
+};
+void launch_ssys_gemm(const SSysGemmArgs& a, hipStream_t st);
+struct SSysBArgs { int n, n0, K, L; const float* slabs; int split, n_pad; const float* G; float* b; };   // b[block][K L]: per 64-column block partials of sum_j Pv_jk G_jl
+inline int ssys_b_blocks(int n) { return (n + 63) / 64 > 0 ? (n + 63) / 64 : 1; }
+void launch_ssys_b(const SSysBArgs& a, hipStream_t st);
+void launch_ssys_reduce(const float* slabs, int nsplit, size_t n, float* A, hipStream_t st);
+void launch_ssys_residual(const float* A, const float* b, const float* S, int n2, float* r, hipStream_t st);
+struct SSysChainArgs {
+  int K, L, update, cond;              // update: 0 draw, else mode (clamped from below by min_x); cond >= 0: evaluate entry cond only
+  float min_x;
+  const float* A; const float* r0; float* S; const float* lambdaS; const float* tau;
+  uint32_t key0, key1, it;
+  double* numer_out; double* tau_out;
+};
+void launch_ssys_chain(const SSysChainArgs& a, hipStream_t st);
+
 // small helpers
 void launch_sum_stats(const double* stats, int nblocks, double* acc, hipStream_t st);   // acc[0..2] += column sums of stats
 void launch_sum_cols(const double* stats, int nrows, int ld, int ncols, double* out, hipStream_t st);        // out[c] += column sums, ncols <= 8

@@ -95,6 +95,7 @@ struct bnmtf_model {
   double* rec = nullptr; size_t rec_cap = 0;
   bool have_state = false, vb_ready = false;
   double *A2d = nullptr, *B2d = nullptr, *vb_rec = nullptr; size_t vb_rec_cap = 0;
+  double* vbred = nullptr;               // VB over several GPUs: the 20 sums exchanged per iteration
   bool use_fast = true, last_sweep_fast = false;   // fast sweep kernel when the shape allows it
   // BNMTF extras
   float* S = nullptr;            // [K][L] on device (row major, unpadded)
@@ -102,6 +103,9 @@ struct bnmtf_model {
   float *slabsS = nullptr, *CfS = nullptr, *deltaS = nullptr, *s_partial = nullptr, *s_w = nullptr, *s_omp = nullptr, *lambdaS = nullptr;
   double *s_numer = nullptr, *s_taup = nullptr;
   int s_blocks = 0;
+  // dense S system (kernel_ssys.hip), K, L <= 32
+  bool ssys = false; int ss_nsplit = 1;
+  float *ss_Wt = nullptr, *ss_slabs = nullptr, *ss_AB = nullptr, *ss_r = nullptr, *ss_bpart = nullptr;   // AB = [A (n2 x n2) | b (n2)]: one buffer, one all-reduce
   // profiling
   double* gunit = nullptr;               // [rec_cap] Gamma(alpha_s, 1) variates staged by run()
   std::vector<double> gunit_host;

@@ -60,3 +60,95 @@ def test_sharded_run_equals_single_rank_run(I, J, K, world):
         np.testing.assert_allclose(ranks[0][2], stau, rtol=1e-9)
         np.testing.assert_allclose(ranks[0][3], smse, rtol=1e-6)
         assert np.abs(ranks[0][0][-1] - sU[-1]).max() <= 1e-4 * np.abs(sU[-1]).max()
+
+
+def _threads(world, work):
+    out, err = [None] * world, [None] * world
+
+    def run(rank):
+        try:
+            out[rank] = work(rank)
+        except Exception as e:      # noqa: BLE001 -- reported by the main thread
+            err[rank] = e
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in ts), "a rank hung"
+    assert all(e is None for e in err), err
+    return out
+
+
+@pytest.mark.parametrize("I,J,K,world", [(640, 512, 24, 2), (515, 389, 40, 3)])
+def test_sharded_vb_run_equals_single_rank_run(I, J, K, world):
+    """BNMF VB, rows / columns sharded (BASELINE configs[4] "1 vs 8 GPUs"): (E, S2) blocks gathered after each half sweep,
+    the SSE-identity sums and the ELBO pieces exchanged as 20 doubles; deterministic, so every rank holds the single-rank
+    trajectory (sums are formed in a different order: 1e-9 on the scalars, fp32 noise on the factors)."""
+    from bnmtf_amd import bnmf_vb_optimised
+    R, M, _, _ = generate_bnmf(I, J, K, 0.12, seed_data=5, seed_mask=6)
+    pri = dict(alpha=1., beta=1., lambdaU=0.1, lambdaV=0.1)
+    single = bnmf_vb_optimised(R, M, K, pri, verbose=False)
+    single.initialise("exp")
+    single.run(8)
+    cid = (b"BNMTFLOC" + b"vb%d" % world).ljust(128, b"\0")
+
+    def work(rank):
+        b = bnmf_vb_optimised(R, M, K, pri, verbose=False, rank=rank, world=world, comm_id=cid)
+        b.initialise("exp")
+        b.run(8)
+        res = (np.array(b.all_exp_tau), np.array(b.all_performances["MSE"]), np.array(b.all_elbo), b.expU.copy(), b.expV.copy(),
+               b.muU.copy(), b.tauV.copy(), b.varU.copy())
+        b.close()
+        return res
+
+    ranks = _threads(world, work)
+    for r in range(1, world):
+        for a, b in zip(ranks[0], ranks[r]):
+            assert np.array_equal(a, b)
+    np.testing.assert_allclose(ranks[0][0], single.all_exp_tau, rtol=1e-6)
+    np.testing.assert_allclose(ranks[0][1], single.all_performances["MSE"], rtol=1e-6)
+    np.testing.assert_allclose(ranks[0][2], single.all_elbo, rtol=1e-6)
+    for got, ref in zip(ranks[0][3:], (single.expU, single.expV, single.muU, single.tauV, single.varU)):
+        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("I,J,K,L,world", [(512, 640, 12, 9, 2), (389, 515, 20, 32, 3)])
+def test_sharded_bnmtf_run_equals_single_rank_run(I, J, K, L, world):
+    """BNMTF Gibbs sharded: F rows / G columns drawn by their owners and gathered; the S step's (A, b) summed over the
+    ranks' column ranges with one all-reduce (the K.L Gram exchange), then every rank walks the same K.L conditionals."""
+    from bnmtf_amd import bnmtf_gibbs_optimised
+    from bnmtf_amd.synthetic import generate_bnmtf
+    R, M, _, _, _ = generate_bnmtf(I, J, K, L, 0.12, seed_data=5, seed_mask=6)
+    pri = dict(alpha=1., beta=1., lambdaF=0.1, lambdaS=0.1, lambdaG=0.1)
+    rs = np.random.RandomState(3)
+    F0 = rs.exponential(1.0, (I, K)); S0 = rs.exponential(1.0, (K, L)); G0 = rs.exponential(1.0, (J, L)); tau0 = 0.7
+    for update in ("mode", "draw"):
+        single = bnmtf_gibbs_optimised(R, M, K, L, pri, verbose=False, seed=7)
+        single.F, single.S, single.G, single.tau = F0.copy(), S0.copy(), G0.copy(), tau0
+        single.run(4, update=update)
+        cid = (b"BNMTFLOC" + ("tri%d%s" % (world, update)).encode()).ljust(128, b"\0")
+
+        def work(rank):
+            b = bnmtf_gibbs_optimised(R, M, K, L, pri, verbose=False, seed=7, rank=rank, world=world, comm_id=cid)
+            b.F, b.S, b.G, b.tau = F0.copy(), S0.copy(), G0.copy(), tau0
+            b.run(4, update=update)
+            res = (b.all_F.copy(), b.all_S.copy(), b.all_G.copy(), b.all_tau.copy(), np.array(b.all_performances["MSE"]))
+            b.close()
+            return res
+
+        ranks = _threads(world, work)
+        for r in range(1, world):
+            for a, b in zip(ranks[0], ranks[r]):
+                assert np.array_equal(a, b)
+        # F of the first sweep: same operation order in every kernel -> bit-identical; S goes through sums over column
+        # ranges whose order depends on the split (fp32 rounding), everything after it inherits that
+        assert np.array_equal(ranks[0][0][0], single.all_F[0])
+        # (a draw whose acceptance test sits within that rounding of its threshold takes the next candidate: rare)
+        close = np.abs(ranks[0][1][0] - single.all_S[0]) <= 2e-4 * np.abs(single.all_S[0]).max()
+        assert close.all() if update == "mode" else close.mean() > 0.97
+        np.testing.assert_allclose(ranks[0][4][:2], np.array(single.all_performances["MSE"])[:2], rtol=2e-3)
+        if update == "mode":
+            np.testing.assert_allclose(ranks[0][3], single.all_tau, rtol=1e-3)
+            assert np.abs(ranks[0][2][-1] - single.all_G[-1]).max() <= 5e-3 * np.abs(single.all_G[-1]).max()
