@@ -60,66 +60,83 @@ void launch_scol_gram(const SColGramArgs& a, hipStream_t st) {
   if (a.n > 0) hipLaunchKernelGGL(scol_gram_kernel, dim3((a.n + 3) / 4), dim3(256), 0, st, a);
 }
 
-// A-slab[s][(k,l)][(k',l')] = sum_{j in range s} W~_j[k][k'] (G_jl G_jl' + [l = l'] varG_jl).
-// One MFMA tile (rows k', columns l') is one row a = (k, l) of A.  Block: 4 waves, k in {k0, k0+1}, wave w takes
-// l in {l0 + 2w, l0 + 2w + 1}: four accumulator tiles per wave; grid (k pairs, l octets, column ranges).
+// pair number p = 0 .. K(K+1)/2 - 1 of (k, k'), k <= k', row by row
+__host__ __device__ inline void ssys_pair(int p, int K, int* k, int* kp) {
+  int kk = 0;
+  while (p >= K - kk) { p -= K - kk; ++kk; }
+  *k = kk; *kp = kk + p;
+}
+
+// A-slab[s][(k,l)][(k',l')] = sum_{j in range s} W~_j[k][k'] G_jl G_jl'  for the block pairs k <= k' (A is symmetric:
+// the lower blocks are mirrored by ssys_reduce_kernel).  One MFMA tile (rows l, columns l') is one K-pair (k, k'):
+// the A operand is W~_j[k][k'] G_jl (a broadcast scalar times the lane's G), the B operand G_jl'.  Four tiles per wave,
+// sixteen per block; grid (pair groups, column ranges).  (The [l = l'] varG_jl term of the variational version is not
+// an outer product: ssys_vardiag_kernel adds it.)
 __global__ __launch_bounds__(256) void ssys_gemm_kernel(SSysGemmArgs a) {
   const int lane = threadIdx.x & 63, half = lane >> 5, c = lane & 31, wave = threadIdx.x >> 6;
-  const int k0 = 2 * blockIdx.x, l0 = 8 * blockIdx.y + 2 * wave, sp = blockIdx.z;
+  const int P = a.K * (a.K + 1) / 2, p0 = (blockIdx.x * 4 + wave) * 4, sp = blockIdx.y;
   const int per = ((a.n + a.nsplit - 1) / a.nsplit + 1) & ~1;      // columns per range (even: two per MFMA step)
   const int jbeg = sp * per, jend = min(a.n, jbeg + per);
-  f32x16 acc[2][2];
+  int wo[4];                                                        // offset of W~[k][k'] inside a column's 32 x 32 block (pairs past P: any valid one, not stored)
 #pragma unroll
-  for (int x = 0; x < 2; ++x)
+  for (int x = 0; x < 4; ++x) { int k, kp; ssys_pair(min(p0 + x, P - 1), a.K, &k, &kp); wo[x] = k * 32 + kp; }
+  f32x16 acc[4];
 #pragma unroll
-    for (int y = 0; y < 2; ++y)
+  for (int x = 0; x < 4; ++x)
 #pragma unroll
-      for (int t = 0; t < 16; ++t) acc[x][y][t] = 0.f;
-  const bool kon1 = k0 + 1 < a.K;
-  constexpr int NS = 8;                                             // steps of two columns in flight (covers the L2 latency of the operand loads)
+    for (int t = 0; t < 16; ++t) acc[x][t] = 0.f;
+  constexpr int NS = 4;                                             // steps of two columns in flight
   for (int j0 = jbeg; j0 < jend; j0 += 2 * NS) {
-    float w0[NS], w1[NS], g[NS], gv[NS];
+    float w[NS][4], g[NS];
 #pragma unroll
     for (int t = 0; t < NS; ++t) {
       const int j = j0 + 2 * t + half;
       const bool on = j < jend;
-      const float* w = a.Wt + (size_t)(on ? j : 0) * 1024;
-      w0[t] = on ? w[k0 * 32 + c] : 0.f;
-      w1[t] = (on && kon1) ? w[(k0 + 1) * 32 + c] : 0.f;
+      const float* wj = a.Wt + (size_t)(on ? j : 0) * 1024;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) w[t][x] = wj[wo[x]];
       g[t] = on ? a.G[(size_t)(a.n0 + j) * 32 + c] : 0.f;
-      gv[t] = (on && a.varG) ? a.varG[(size_t)(a.n0 + j) * 32 + c] : 0.f;
     }
 #pragma unroll
-    for (int t = 0; t < NS; ++t) {
+    for (int t = 0; t < NS; ++t)
 #pragma unroll
-      for (int y = 0; y < 2; ++y) {
-        const int l = l0 + y;                                        // (lanes of a half share column j: broadcast G_jl inside the half)
-        const float gl = __shfl(g[t], (lane & 32) + (l & 31), 64);
-        const float b = fmaf(g[t], gl, c == l ? gv[t] : 0.f);
-        acc[0][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[t], b, acc[0][y], 0, 0, 0);
-        acc[1][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[t], b, acc[1][y], 0, 0, 0);
-      }
-    }
+      for (int x = 0; x < 4; ++x) acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t][x] * g[t], g[t], acc[x], 0, 0, 0);
   }
   const int n2 = a.K * a.L;
   float* slab = a.slabs + (size_t)sp * n2 * n2;
 #pragma unroll
-  for (int x = 0; x < 2; ++x)
+  for (int x = 0; x < 4; ++x) {
+    if (p0 + x >= P) continue;
+    int k, kp; ssys_pair(p0 + x, a.K, &k, &kp);
 #pragma unroll
-    for (int y = 0; y < 2; ++y) {
-      const int k = k0 + x, l = l0 + y;
-      if (k >= a.K || l >= a.L) continue;
-      float* row = slab + (size_t)(k * a.L + l) * n2;
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const int kp = (t & 3) + 8 * (t >> 2) + 4 * half;           // k' = tile row, l' = tile column = c
-        if (kp < a.K && c < a.L) row[kp * a.L + c] = acc[x][y][t];
-      }
+    for (int t = 0; t < 16; ++t) {
+      const int l = (t & 3) + 8 * (t >> 2) + 4 * half;              // l = tile row, l' = tile column = c
+      if (l < a.L && c < a.L) slab[(size_t)(k * a.L + l) * n2 + kp * a.L + c] = acc[x][t];
     }
+  }
 }
 void launch_ssys_gemm(const SSysGemmArgs& a, hipStream_t st) {
-  dim3 grid((a.K + 1) / 2, (a.L + 7) / 8, a.nsplit);
-  hipLaunchKernelGGL(ssys_gemm_kernel, grid, dim3(256), 0, st, a);
+  const int P = a.K * (a.K + 1) / 2;
+  hipLaunchKernelGGL(ssys_gemm_kernel, dim3((P + 15) / 16, a.nsplit), dim3(256), 0, st, a);
+}
+
+// A = sum of the column-range slabs (in range order) on the block pairs k <= k', mirrored into k > k': one block per pair
+__global__ __launch_bounds__(1024) void ssys_reduce_kernel(const float* slabs, int nsplit, int K, int L, float* A) {
+  __shared__ float tile[32][33];
+  int k, kp; ssys_pair(blockIdx.x, K, &k, &kp);
+  const int l = threadIdx.x >> 5, lp = threadIdx.x & 31, n2 = K * L;
+  float v = 0.f;
+  if (l < L && lp < L) {
+    const size_t e = (size_t)(k * L + l) * n2 + kp * L + lp;
+    for (int t = 0; t < nsplit; ++t) v += slabs[(size_t)t * n2 * n2 + e];
+    A[e] = v;
+  }
+  tile[l][lp] = v;
+  __syncthreads();
+  if (k != kp && l < L && lp < L) A[(size_t)(kp * L + l) * n2 + k * L + lp] = tile[lp][l];
+}
+void launch_ssys_reduce(const float* slabs, int nsplit, int K, int L, float* A, hipStream_t st) {
+  hipLaunchKernelGGL(ssys_reduce_kernel, dim3(K * (K + 1) / 2), dim3(1024), 0, st, slabs, nsplit, K, L, A);
 }
 
 // b[k][l] = sum_j Pv_jk G_jl over the local columns (Pv = the contraction's partial slabs, summed in slab order).
@@ -148,16 +165,16 @@ void launch_ssys_b(const SSysBArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(ssys_b_kernel, dim3(ssys_b_blocks(a.n)), dim3(1024), 0, st, a);
 }
 
-// A = sum of the column-range slabs, in range order
-__global__ void ssys_reduce_kernel(const float* slabs, int nsplit, size_t n, float* A) {
+// out = sum of the per-block partial vectors, in block order
+__global__ void ssys_sum_parts_kernel(const float* slabs, int nsplit, size_t n, float* A) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   float s = 0.f;
   for (int t = 0; t < nsplit; ++t) s += slabs[(size_t)t * n + e];
   A[e] = s;
 }
-void launch_ssys_reduce(const float* slabs, int nsplit, size_t n, float* A, hipStream_t st) {
-  hipLaunchKernelGGL(ssys_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slabs, nsplit, n, A);
+void launch_ssys_sum_parts(const float* slabs, int nsplit, size_t n, float* A, hipStream_t st) {
+  hipLaunchKernelGGL(ssys_sum_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slabs, nsplit, n, A);
 }
 
 // r = b - A S (fp64 accumulation: b and A S nearly cancel at convergence), one wave per row

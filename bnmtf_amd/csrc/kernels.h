@@ -212,7 +212,7 @@ struct SColGramArgs {       // W~_j = C~f - sum_{i in miss(j)} (F_i F_i^T + diag
   float* Wt;                           // [n][32*32]
 };
 void launch_scol_gram(const SColGramArgs& a, hipStream_t st);
-struct SSysGemmArgs {       // slabs[s][(k,l)][(k',l')] = sum_{j in range s} W~_j[k][k'] (G_jl G_jl' + [l = l'] varG_jl)
+struct SSysGemmArgs {       // slabs[s][(k,l)][(k',l')] = sum_{j in range s} W~_j[k][k'] G_jl G_jl' on the block pairs k <= k'
   int n, n0, K, L, nsplit;
   const float* Wt; const float* G; const float* varG;   // G, varG [J][32] (global rows n0 + j)
   float* slabs;                        // [nsplit][K L][K L]
@@ -221,7 +221,8 @@ void launch_ssys_gemm(const SSysGemmArgs& a, hipStream_t st);
 struct SSysBArgs { int n, n0, K, L; const float* slabs; int split, n_pad; const float* G; float* b; };   // b[block][K L]: per 64-column block partials of sum_j Pv_jk G_jl
 inline int ssys_b_blocks(int n) { return (n + 63) / 64 > 0 ? (n + 63) / 64 : 1; }
 void launch_ssys_b(const SSysBArgs& a, hipStream_t st);
-void launch_ssys_reduce(const float* slabs, int nsplit, size_t n, float* A, hipStream_t st);
+void launch_ssys_reduce(const float* slabs, int nsplit, int K, int L, float* A, hipStream_t st);   // sum the slabs on k <= k', mirror
+void launch_ssys_sum_parts(const float* parts, int nparts, size_t n, float* out, hipStream_t st);
 void launch_ssys_residual(const float* A, const float* b, const float* S, int n2, float* r, hipStream_t st);
 struct SSysChainArgs {
   int K, L, update, cond;              // update: 0 draw, else mode (clamped from below by min_x); cond >= 0: evaluate entry cond only

@@ -326,6 +326,105 @@ def make_icm():
     np.savez_compressed(os.path.join(HERE, "icm.npz"), **out)
 
 
+def make_bnmtf_vb():
+    """bnmtf_vb_optimised (tests/code/test_bnmtf_vb_optimised.py's inputs, the toy set, a ragged case): single updates
+    from hand-set states, and whole runs.  run() shuffles its three index lists with Python's `random.shuffle`
+    (bnmtf_vb_optimised.py:52,172-186): `random.seed` before each run pins the orders, and they are stored too."""
+    import itertools
+    import random
+    from BNMTF.code.models.bnmtf_vb_optimised import bnmtf_vb_optimised
+    out = {}
+    rs = np.random.RandomState(777)
+
+    def record_updates(tag, b):
+        """update_F(k) / update_S(k,l) / update_G(l) each from the SAME state (restored in between) + esd, elbo pieces"""
+        names = ["muF", "tauF", "expF", "varF", "muS", "tauS", "expS", "varS", "muG", "tauG", "expG", "varG"]
+        state = {n: getattr(b, n).copy() for n in names}
+        for n in names:
+            out["%s/state/%s" % (tag, n)] = state[n]
+        out[tag + "/state/exptau"] = np.float64(b.exptau)
+        out[tag + "/esd"] = np.float64(b.exp_square_diff())
+        tF, mF = np.zeros((b.I, b.K)), np.zeros((b.I, b.K))
+        for k in range(b.K):
+            b.update_F(k); tF[:, k], mF[:, k] = b.tauF[:, k], b.muF[:, k]
+            b.tauF, b.muF = state["tauF"].copy(), state["muF"].copy()
+        tS, mS = np.zeros((b.K, b.L)), np.zeros((b.K, b.L))
+        for k, l in itertools.product(range(b.K), range(b.L)):
+            b.update_S(k, l); tS[k, l], mS[k, l] = b.tauS[k, l], b.muS[k, l]
+            b.tauS, b.muS = state["tauS"].copy(), state["muS"].copy()
+        tG, mG = np.zeros((b.J, b.L)), np.zeros((b.J, b.L))
+        for l in range(b.L):
+            b.update_G(l); tG[:, l], mG[:, l] = b.tauG[:, l], b.muG[:, l]
+            b.tauG, b.muG = state["tauG"].copy(), state["muG"].copy()
+        for n, v in (("tauF", tF), ("muF", mF), ("tauS", tS), ("muS", mS), ("tauG", tG), ("muG", mG)):
+            out["%s/upd/%s" % (tag, n)] = v
+
+    def record_run(tag, b, iters, seed):
+        random.seed(seed)
+        state = random.getstate()
+        orders = []
+        for it in range(iters):          # the three shuffles of every iteration, as run() will make them
+            oS = list(itertools.product(range(b.K), range(b.L))); random.shuffle(oS)
+            oF = list(range(b.K)); random.shuffle(oF)
+            oG = list(range(b.L)); random.shuffle(oG)
+            orders.append((oS, oF, oG))
+        random.setstate(state)
+        mse, exptau, elbo = [], [], []
+        for it in range(iters):
+            with quiet():
+                b.run(1)
+            mse.append(b.all_performances["MSE"][0]); exptau.append(b.exptau); elbo.append(b.elbo())
+        out[tag + "/seed"] = np.int64(seed)
+        out[tag + "/order_S"] = np.array([[k * b.L + l for k, l in o[0]] for o in orders], dtype=np.int32)
+        out[tag + "/order_F"] = np.array([o[1] for o in orders], dtype=np.int32)
+        out[tag + "/order_G"] = np.array([o[2] for o in orders], dtype=np.int32)
+        out[tag + "/mse"], out[tag + "/exptau"], out[tag + "/elbo"] = np.array(mse), np.array(exptau), np.array(elbo)
+        for n in ["muF", "tauF", "expF", "varF", "muS", "tauS", "expS", "varS", "muG", "tauG", "expG", "varG"]:
+            out["%s/final/%s" % (tag, n)] = getattr(b, n).copy()
+        p = b.predict(b.M)
+        out[tag + "/final_perf"] = np.array([p["MSE"], p["R^2"], p["Rp"]])
+        out[tag + "/quality"] = np.array([b.quality(m) for m in ["loglikelihood", "BIC", "AIC", "MSE", "ELBO"]])
+
+    # the reference tests' 5 x 3 matrix and hand-set state (test_bnmtf_vb_optimised.py:283-300)
+    I, J, K, L = 5, 3, 2, 4
+    R = np.ones((I, J)); M = np.ones((I, J)); M[0, 0] = M[2, 2] = M[3, 1] = 0
+    pri = dict(alpha=3, beta=1, lambdaF=2 * np.ones((I, K)), lambdaS=3 * np.ones((K, L)), lambdaG=4 * np.ones((J, L)))
+    b = bnmtf_vb_optimised(R, M, K, L, pri)
+    b.muF = rs.uniform(0.1, 2, (I, K)); b.muS = rs.uniform(0.1, 2, (K, L)); b.muG = rs.uniform(0.1, 2, (J, L))
+    b.tauF = rs.uniform(0.5, 3, (I, K)); b.tauS = rs.uniform(0.5, 3, (K, L)); b.tauG = rs.uniform(0.5, 3, (J, L))
+    b.expF = 1. / pri["lambdaF"]; b.expS = 1. / pri["lambdaS"]; b.expG = 1. / pri["lambdaG"]
+    b.varF = np.ones((I, K)) * 2; b.varS = np.ones((K, L)) * 3; b.varG = np.ones((J, L)) * 4
+    b.exptau = 3.
+    record_updates("t5x3", b)
+    # a ragged random case, non-constant lambdas, random q state
+    I, J, K, L = 33, 27, 5, 4
+    R = rs.exponential(1.0, (I, K)) @ rs.exponential(1.0, (K, L)) @ rs.exponential(1.0, (J, L)).T + rs.normal(0, 1, (I, J))
+    Mr = rand_mask(rs, I, J, 0.25)
+    pri = dict(alpha=2.0, beta=0.5, lambdaF=rs.uniform(0.1, 2, (I, K)), lambdaS=rs.uniform(0.1, 2, (K, L)), lambdaG=rs.uniform(0.1, 2, (J, L)))
+    out["r33x27/R"], out["r33x27/M"] = R, Mr
+    for n in ("lambdaF", "lambdaS", "lambdaG"):
+        out["r33x27/" + n] = pri[n]
+    b = bnmtf_vb_optimised(R, Mr, K, L, pri)
+    b.initialise("exp", "exp", {"tauF": rs.uniform(0.5, 3, (I, K)), "tauS": rs.uniform(0.5, 3, (K, L)), "tauG": rs.uniform(0.5, 3, (J, L))})
+    out["r33x27/init/tauF"], out["r33x27/init/tauS"], out["r33x27/init/tauG"] = b.tauF.copy(), b.tauS.copy(), b.tauG.copy()
+    out["r33x27/init_exptau"] = np.float64(b.exptau)
+    record_updates("r33x27", b)
+    record_run("r33x27", b, 10, seed=11)
+    # the toy set (data_toy/bnmtf: 100 x 80, K = L = 5), init exp / exp
+    R = np.loadtxt(REF + "/data_toy/bnmtf/R.txt"); M = np.loadtxt(REF + "/data_toy/bnmtf/M.txt")
+    I, J = R.shape; K = L = 5
+    pri = dict(alpha=1.0, beta=1.0, lambdaF=0.1 * np.ones((I, K)), lambdaS=0.1 * np.ones((K, L)), lambdaG=0.1 * np.ones((J, L)))
+    b = bnmtf_vb_optimised(R, M, K, L, pri)
+    np.random.seed(5)
+    b.initialise("random", "random")
+    for n in ("muF", "muS", "muG"):
+        out["toy/init/" + n] = getattr(b, n).copy()
+    out["toy/init_exptau"] = np.float64(b.exptau); out["toy/init_esd"] = np.float64(b.exp_square_diff())
+    out["toy/init_elbo"] = np.float64(b.elbo())
+    record_run("toy", b, 20, seed=3)
+    np.savez_compressed(os.path.join(HERE, "bnmtf_vb.npz"), **out)
+
+
 def make_toy_data():
     """The reference's toy inputs (data files its own tests/experiments hold) as one fixture."""
     out = {}
@@ -338,7 +437,7 @@ def make_toy_data():
 
 if __name__ == "__main__":
     import_reference()
-    which = sys.argv[1:] or ["toy", "bnmf", "bnmtf", "vb", "tn", "traj", "icm"]
+    which = sys.argv[1:] or ["toy", "bnmf", "bnmtf", "vb", "tn", "traj", "icm", "trivb"]
     if "toy" in which: make_toy_data()
     if "bnmf" in which: make_bnmf_cond()
     if "bnmtf" in which: make_bnmtf_cond()
@@ -346,6 +445,7 @@ if __name__ == "__main__":
     if "tn" in which: make_tn()
     if "traj" in which: make_trajectories()
     if "icm" in which: make_icm()
+    if "trivb" in which: make_bnmtf_vb()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))
