@@ -55,6 +55,11 @@ _SIGS = {
     "bnmf_vb_update": ([_P, C.c_int, C.c_int, C.c_int], C.c_int),
     "bnmf_vb_exp_square_diff": ([_P, C.POINTER(C.c_double)], C.c_int),
     "bnmf_vb_run": ([_P, C.c_int, _P, _P, _P, _P], C.c_int),
+    "bnmtf_vb_set_state": ([_P] + [_P] * 12 + [C.c_double], C.c_int),
+    "bnmtf_vb_get_state": ([_P] + [_P] * 12, C.c_int),
+    "bnmtf_vb_update": ([_P, C.c_int, C.c_int, C.c_int, C.c_int], C.c_int),
+    "bnmtf_vb_exp_square_diff": ([_P, C.POINTER(C.c_double), _P], C.c_int),
+    "bnmtf_vb_run": ([_P, C.c_int, _P, _P, _P, _P, _P], C.c_int),
     "bnmtf_metric_sums": ([_P, _P, _P, _P, _P, _P], C.c_int),
     "bnmtf_tn_sample": ([_P, _P, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, _P], C.c_int),
     "bnmtf_tn_moments": ([_P, _P, C.c_size_t, C.c_int, _P, _P], C.c_int),

@@ -701,6 +701,7 @@ int bnmtf_destroy(bnmtf_handle h) {
   if (h->comm) comm_destroy(h->comm);
   free_dir(h->rows); free_dir(h->cols); free_dir(h->reff); free_dir(h->ceff);
   dfree(h->slabsS); dfree(h->CfS); dfree(h->deltaS); dfree(h->s_partial); dfree(h->s_w); dfree(h->s_omp); dfree(h->lambdaS); dfree(h->s_numer); dfree(h->s_taup);
+  dfree(h->muS); dfree(h->tauS); dfree(h->varS); dfree(h->mv_rows); dfree(h->mv_cols); dfree(h->ss_vd); dfree(h->tri_order); dfree(h->tri_sums);
   dfree(h->ss_Wt); dfree(h->ss_slabs); dfree(h->ss_AB); dfree(h->ss_r); dfree(h->ss_bpart);
   dfree(h->Rfull); dfree(h->Mtrain); dfree(h->Mscratch); dfree(h->Ad); dfree(h->Bd); dfree(h->out6);
   dfree(h->A2d); dfree(h->B2d); dfree(h->vb_rec); dfree(h->vbred);
@@ -996,3 +997,4 @@ int bnmtf_gamma_sample(double alpha, double beta, uint64_t seed, uint64_t it, in
 }  // extern "C"
 
 #include "api_models.inc"
+#include "api_trivb.inc"

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void scol_gram_kernel(SColGramArgs a) {
     const int row = (t & 3) + 8 * (t >> 2) + 4 * half;             // C/D layout of the 32 x 32 tile: column on the lane
     float cf = (float)a.Cf64[(size_t)row * 32 + c];
     float m = acc[t];
-    if (row == c) { cf += a.cf_diag_extra ? (float)a.cf_diag_extra[c] : 0.f; m += dv; }
+    if (row == c) { if (a.cf_diag_extra) cf = (float)a.cf_diag_extra[c]; m += dv; }      // VB: C~f_kk = sum_i (E[F_ik]^2 + varF_ik) = the column sum of the second moments
     w[row * 32 + c] = (row < a.K && c < a.K) ? cf - m : 0.f;
   }
 }

@@ -67,7 +67,15 @@ __global__ __launch_bounds__(256) void sweep_generic_kernel(SweepArgs a) {
   const int only = a.cond_k >= 0 ? a.cond_k : a.only_k;
   const int kbeg = only >= 0 ? only : 0, kend = only >= 0 ? only + 1 : K;
   double e_quad = 0.0, e_lerfc = 0.0, e_ltau = 0.0, e_lamx = 0.0, e_q2 = 0.0, e_q3 = 0.0;   // VB: ELBO / exp_square_diff pieces
-  for (int k = kbeg; k < kend; ++k) {
+  // tri-factorisation VB: fs_t = sum_c x_c S(c,t) (lane = inner index t) and the masked variance sums of the other factor
+  float fs = 0.f, mvl = 0.f;
+  const bool cov_on = MODE == kSweepVB && a.cov_S != nullptr, cov_lane = cov_on && lane < a.cov_n;
+  if (cov_on) {
+    for (int c = 0; c < K; ++c) fs = fmaf(__shfl(x, c, 64), cov_lane ? a.cov_S[c * a.cov_sc + lane * a.cov_st] : 0.f, fs);
+    mvl = cov_lane ? a.cov_mv[(size_t)u * 32 + lane] : 0.f;
+  }
+  for (int kk = kbeg; kk < kend; ++kk) {
+    const int k = (MODE == kSweepVB && a.order && only < 0) ? a.order[kk] : kk;
     const float xk = __shfl(x, k, 64);
     const float* vcol = a.XoT + (size_t)k * a.ldT_o;
     float corr = 0.f, asq = 0.f, vsq = 0.f;
@@ -86,6 +94,11 @@ __global__ __launch_bounds__(256) void sweep_generic_kernel(SweepArgs a) {
     asq = wave_sum(asq);
     const float ckk = __shfl(ckl, k, 64);
     const float aik = (MODE == kSweepVB ? (float)a.colsum2_o[k] : ckk) - asq;
+    float sc = 0.f;
+    if (cov_on) {                                   // bnmtf_vb_optimised.py:246 / :269: sum_t S(k,t) mv_t (fs_t - x_k S(k,t))
+      sc = cov_lane ? a.cov_S[k * a.cov_sc + lane * a.cov_st] : 0.f;
+      corr -= wave_sum(sc * mvl * fmaf(-xk, sc, fs));
+    }
     const float num = __shfl(p, k, 64) + corr;
     const float tau_p = tau * aik;
     const float numer = fmaf(tau, num, -__shfl(lam, k, 64));
@@ -125,6 +138,7 @@ __global__ __launch_bounds__(256) void sweep_generic_kernel(SweepArgs a) {
     }
     const float delta = xnew - xk;
     if (lane == k) x = xnew;
+    if (cov_on) fs = fmaf(delta, sc, fs);
     for (int e = 0; e < E; ++e) {
       const uint32_t j = idx[e * 64];
       q[e * 64] = fmaf(delta, vcol[j], q[e * 64]);

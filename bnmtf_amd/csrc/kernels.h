@@ -70,6 +70,11 @@ struct SweepArgs {
   // VB extras (mode == kSweepVB)
   float* mu_self; float* tau_self; float* var_self; float* S2self; float* S2selfT;
   const float* S2oT; const double* colsum2_o;   // other's var+exp^2 (transposed) and its column sums
+  // variational tri-factorisation (kernel_trivb.hip): covariance term of update_F / update_G and the column order
+  const float* cov_S;        // E[S]; element (column c of this factor, inner t) at cov_S[c * cov_sc + t * cov_st]; null: no term
+  int cov_sc, cov_st, cov_n; // strides and inner extent (L for the F step, K for the G step)
+  const float* cov_mv;       // [n][32] masked variance sums of the other factor (mvG / mvF), local units
+  const int* order;          // K column indices in update order, or null (0 .. K-1)
 };
 void launch_sweep(const SweepArgs& a, hipStream_t st);
 
@@ -207,7 +212,7 @@ struct SColGramArgs {       // W~_j = C~f - sum_{i in miss(j)} (F_i F_i^T + diag
   const float* F;                      // [I+][32] row major, padding slots of idx point at a zero row
   const float* varF;                   // [I+][32] or null (Gibbs)
   const double* Cf64;                  // F^T F [32][32]
-  const double* cf_diag_extra;         // sum_i varF_ik [32] or null
+  const double* cf_diag_extra;         // VB: sum_i (E[F_ik]^2 + varF_ik) [32] (replaces the diagonal of Cf64), or null
   const uint32_t* slot_ptr; const uint32_t* idx;   // 64-wide slots of the cols direction
   float* Wt;                           // [n][32*32]
 };
@@ -232,6 +237,29 @@ struct SSysChainArgs {
   double* numer_out; double* tau_out;
 };
 void launch_ssys_chain(const SSysChainArgs& a, hipStream_t st);
+
+// ---------------------------------------------------------------------------
+// variational tri-factorisation (kernel_trivb.hip); K, L <= 32
+// ---------------------------------------------------------------------------
+struct SmallProductVbArgs {  // effective factor: mean out = X.S (or X.S^T) and its second moment outS2
+  const float* X; const float* varX; int rows; const float* S; const float* varS; int K, L, transposeS; float* out; float* outS2;
+};
+void launch_small_product_vb(const SmallProductVbArgs& a, hipStream_t st);
+struct MaskedColsumArgs {    // out[u][c] = sum over the unit's observed inner indices of V[.][c]
+  int n; const uint32_t* slot_ptr; const uint32_t* idx; const float* V; const double* colsum2; const double* C64; float* out;
+};
+void launch_masked_colsum(const MaskedColsumArgs& a, hipStream_t st);
+void launch_ssys_vardiag(const SSysGemmArgs& a, float* vd_slabs, float* A, hipStream_t st);   // A[(k,l)][(k',l)] += sum_j W~_j[k][k'] varG_jl
+struct SSysChainVbArgs {
+  int K, L, n_order, only_params;
+  const int* order;                    // entries a = k L + l in update order
+  const float* A; const float* r0; const float* lambdaS; const float* tau;
+  float* E; float* var; float* mu; float* tauq;     // q(S): expS (in/out), varS, muS, tauS  [K L]
+};
+void launch_ssys_chain_vb(const SSysChainVbArgs& a, hipStream_t st);
+struct TriFactorArgs { int which, side, rows, K, L; const float* X; const float* varX; const float* S; const float* varS; double* out; };
+void launch_tri_factors(const TriFactorArgs& a, hipStream_t st);
+void launch_tri_vb_finish(const double* sums, double alpha, double beta, double* tau_d, float* tau_f, double* rec, hipStream_t st);
 
 // small helpers
 void launch_sum_stats(const double* stats, int nblocks, double* acc, hipStream_t st);   // acc[0..2] += column sums of stats

@@ -151,6 +151,28 @@ int bnmf_vb_exp_square_diff(bnmtf_handle h, double* out);
 int bnmf_vb_run(bnmtf_handle h, int n_iter, double* exptau_out, double* perf_out,
                 double* elbo_terms_out, double* times_out);
 
+/* ---- BNMTF VB (bnmtf_vb_optimised.py); K, L <= 32, one GPU ---------------- */
+/* the twelve q-parameter matrices (F: I x K, S: K x L, G: J x L) + exptau; any pointer may be NULL (left as is) */
+int bnmtf_vb_set_state(bnmtf_handle h, const double* muF, const double* tauF, const double* expF, const double* varF,
+                       const double* muS, const double* tauS, const double* expS, const double* varS,
+                       const double* muG, const double* tauG, const double* expG, const double* varG, double exptau);
+int bnmtf_vb_get_state(bnmtf_handle h, double* muF, double* tauF, double* expF, double* varF,
+                       double* muS, double* tauS, double* expS, double* varS,
+                       double* muG, double* tauG, double* expG, double* varG);
+/* update_F(k) (which = 0, :241-250), update_S(k,l) (which = 1, :252-262), update_G(l) (which = 2, :264-273) for the
+ * current state; moments != 0 also runs the matching update_exp_* (:276-285). */
+int bnmtf_vb_update(bnmtf_handle h, int which, int k, int l, int moments);
+/* exp_square_diff() (:235-239); sums_out (may be NULL): n, sum R, sum R^2, sum P, sum P^2, sum R P over the training
+ * mask with P = E[F] E[S] E[G]^T */
+int bnmtf_vb_exp_square_diff(bnmtf_handle h, double* esd_out, double sums_out[6]);
+/* run(iterations) (:160-205).  orders [n_iter][K L + K + L]: per iteration the update order of the S entries (k L + l),
+ * the F columns and the G columns (the reference shuffles them with random.shuffle, :171-186; the host class draws the
+ * same shuffles).  exptau_out [n_iter]; perf_out [n_iter][3]; times_out [n_iter]; elbo_terms_out [n_iter][10] =
+ * {exp_square_diff, beta_s, then for F and for G: sum tau/2 (var+(exp-mu)^2), sum log(0.5 erfc(-mu sqrt(tau/2))),
+ * sum log tau, sum lambda exp} -- the K L terms of S and the scalar algebra are the host's. */
+int bnmtf_vb_run(bnmtf_handle h, int n_iter, const int32_t* orders, double* exptau_out, double* perf_out,
+                 double* elbo_terms_out, double* times_out);
+
 /* ---- metrics: predict()/predict_while_running()/quality('MSE')/log_likelihood
  *      (:191-223,247-251).  Six fp64 sums over mask Mp (I x J bytes; NULL = the
  *      training mask): n, sum R, sum R^2, sum P, sum P^2, sum R*P with

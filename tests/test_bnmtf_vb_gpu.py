@@ -1,0 +1,155 @@
+"""bnmtf_vb_optimised on the device against the reference's own outputs (tests/golden/bnmtf_vb.npz: single updates from
+hand-set states, whole runs with the reference's random.shuffle orders) and the known answers of
+tests/code/test_bnmtf_vb_optimised.py.  q-parameters live on the device in fp32, reductions in fp64."""
+import itertools
+import random
+
+import numpy as np
+import pytest
+
+from bnmtf_amd import bnmtf_vb_optimised
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ["muF", "tauF", "expF", "varF", "muS", "tauS", "expS", "varS", "muG", "tauG", "expG", "varG"]
+
+
+def _t5x3():
+    I, J, K, L = 5, 3, 2, 4
+    R = np.ones((I, J)); M = np.ones((I, J)); M[0, 0] = M[2, 2] = M[3, 1] = 0
+    pri = dict(alpha=3, beta=1, lambdaF=2 * np.ones((I, K)), lambdaS=3 * np.ones((K, L)), lambdaG=4 * np.ones((J, L)))
+    return R, M, K, L, pri
+
+
+def _case(golden, tag):
+    g = golden("bnmtf_vb.npz").case(tag)
+    if tag == "t5x3":
+        R, M, K, L, pri = _t5x3()
+    else:
+        R, M = g["R"], g["M"]
+        K, L = g["lambdaS"].shape
+        pri = dict(alpha=2.0, beta=0.5, lambdaF=g["lambdaF"], lambdaS=g["lambdaS"], lambdaG=g["lambdaG"])
+    return g, R, M, K, L, pri
+
+
+def test_known_answers_of_the_reference_tests():
+    """test_bnmtf_vb_optimised.py:281-300."""
+    R, M, K, L, pri = _t5x3()
+    I, J = R.shape
+    b = bnmtf_vb_optimised(R, M, K, L, pri, verbose=False)
+    b.expF = 1. / pri["lambdaF"]; b.expS = 1. / pri["lambdaS"]; b.expG = 1. / pri["lambdaG"]
+    b.varF = np.ones((I, K)) * 2; b.varS = np.ones((K, L)) * 3; b.varG = np.ones((J, L)) * 4
+    assert abs(b.exp_square_diff() - (2749 + 5. / 6.)) < 2e-6 * 2749           # 1/3 is rounded to fp32 on the device
+    b.update_tau()
+    assert b.alpha_s == 3 + 12. / 2. and abs(b.beta_s - (1 + (2749 + 5. / 6.) / 2.)) < 2e-6 * 1375
+    with pytest.raises(AssertionError) as e:
+        b.quality('FAIL')
+    assert str(e.value) == "Unrecognised metric for model quality: FAIL."
+
+
+@pytest.mark.parametrize("tag", ["t5x3", "r33x27"])
+def test_single_updates_match_the_reference(golden, tag):
+    """update_F(k), update_S(k,l), update_G(l) (bnmtf_vb_optimised.py:241-273), each from the same hand-set state."""
+    g, R, M, K, L, pri = _case(golden, tag)
+
+    def fresh():
+        b = bnmtf_vb_optimised(R, M, K, L, pri, verbose=False)
+        for n in NAMES:
+            setattr(b, n, g["state/" + n].copy())
+        b.exptau = float(g["state/exptau"])
+        return b
+
+    b = fresh()
+    assert abs(b.exp_square_diff() - float(g["esd"])) < 5e-6 * float(g["esd"])
+    for k in range(K):
+        b = fresh(); b.update_F(k)
+        np.testing.assert_allclose(b.tauF[:, k], g["upd/tauF"][:, k], rtol=5e-6)
+        scale = np.abs(g["upd/muF"][:, k]).max() + 1.0
+        assert np.abs(b.muF[:, k] - g["upd/muF"][:, k]).max() < 2e-5 * scale
+    for l in range(L):
+        b = fresh(); b.update_G(l)
+        np.testing.assert_allclose(b.tauG[:, l], g["upd/tauG"][:, l], rtol=5e-6)
+        scale = np.abs(g["upd/muG"][:, l]).max() + 1.0
+        assert np.abs(b.muG[:, l] - g["upd/muG"][:, l]).max() < 2e-5 * scale
+    for k, l in itertools.product(range(K), range(L)):
+        b = fresh(); b.update_S(k, l)
+        assert abs(b.tauS[k, l] - g["upd/tauS"][k, l]) < 5e-6 * g["upd/tauS"][k, l]
+        assert abs(b.muS[k, l] - g["upd/muS"][k, l]) < 2e-5 * (np.abs(g["upd/muS"]).max() + 1.0)
+        others = np.ones((K, L), dtype=bool); others[k, l] = False
+        assert np.array_equal(b.muS[others], g["state/muS"][others].astype(np.float32).astype(np.float64))
+
+
+def test_ragged_run_matches_the_reference(golden):
+    """Ten iterations with the reference's shuffles: once handed over, once re-drawn from Python's random stream."""
+    g, R, M, K, L, pri = _case(golden, "r33x27")
+    orders = np.concatenate([g["order_S"], g["order_F"], g["order_G"]], axis=1)
+    for mode in ("stored", "stream"):
+        b = bnmtf_vb_optimised(R, M, K, L, pri, verbose=False)
+        b.initialise("exp", "exp", {"tauF": g["init/tauF"], "tauS": g["init/tauS"], "tauG": g["init/tauG"]})
+        assert abs(b.exptau - float(g["init_exptau"])) < 5e-6 * b.exptau
+        if mode == "stored":
+            b.run(10, orders=orders)
+        else:
+            random.seed(int(g["seed"]))
+            b.run(10)
+        np.testing.assert_allclose(b.all_performances["MSE"], g["mse"], rtol=1e-3)
+        np.testing.assert_allclose(b.all_performances["MSE"][:3], g["mse"][:3], rtol=5e-5)
+        np.testing.assert_allclose(b.all_exp_tau, g["exptau"], rtol=1e-3)
+        assert abs(b.elbo() - g["elbo"][-1]) < 2e-4 * abs(g["elbo"][-1])
+        for n in ("expF", "expS", "expG", "muF", "tauG"):
+            ref = g["final/" + n]
+            assert np.abs(getattr(b, n) - ref).max() < 3e-3 * np.abs(ref).max(), n
+        np.testing.assert_allclose([b.quality(m) for m in ["loglikelihood", "BIC", "AIC", "MSE", "ELBO"]], g["quality"], rtol=1e-3)
+        assert len(b.all_times) == 10
+
+
+def test_toy_run_matches_the_reference(golden):
+    """data_toy/bnmtf, K = L = 5, init random / random under numpy.random.seed(5), 20 iterations under random.seed(3)."""
+    t = golden("toy_data.npz").case("bnmtf")
+    g = golden("bnmtf_vb.npz").case("toy")
+    I, J = t["R"].shape; K = L = 5
+    pri = dict(alpha=1.0, beta=1.0, lambdaF=0.1 * np.ones((I, K)), lambdaS=0.1 * np.ones((K, L)), lambdaG=0.1 * np.ones((J, L)))
+    b = bnmtf_vb_optimised(t["R"], t["M"], K, L, pri, verbose=False)
+    np.random.seed(5)
+    b.initialise("random", "random")
+    for n in ("muF", "muS", "muG"):                      # same NumPy stream as the reference's scalar draws
+        np.testing.assert_allclose(getattr(b, n), g["init/" + n], rtol=1e-12)
+    assert abs(b.exptau - float(g["init_exptau"])) < 5e-6 * b.exptau
+    assert abs(b.exp_square_diff() - float(g["init_esd"])) < 5e-6 * float(g["init_esd"])
+    assert abs(b.elbo() - float(g["init_elbo"])) < 2e-5 * abs(float(g["init_elbo"]))
+    random.seed(int(g["seed"]))
+    b.run(20)
+    np.testing.assert_allclose(b.all_performances["MSE"], g["mse"], rtol=2e-3)
+    np.testing.assert_allclose(b.all_performances["MSE"][:5], g["mse"][:5], rtol=1e-4)
+    np.testing.assert_allclose(b.all_exp_tau, g["exptau"], rtol=2e-3)
+    assert abs(b.elbo() - g["elbo"][-1]) < 5e-4 * abs(g["elbo"][-1])
+    p = b.predict(t["M"])
+    np.testing.assert_allclose([p["MSE"], p["R^2"], p["Rp"]], g["final_perf"], rtol=2e-3)
+
+
+def test_larger_shape_properties():
+    """700 x 560, K = 12, L = 9: coordinate ascent in shuffled order does not lower the bound; beta_s is the direct
+    exp_square_diff; every q parameter stays finite and non-negative; the fit keeps improving."""
+    from bnmtf_amd.synthetic import generate_bnmtf
+    I, J, K, L = 700, 560, 12, 9
+    R, M, _, _, _ = generate_bnmtf(I, J, K, L, 0.15, seed_data=3, seed_mask=4)
+    pri = dict(alpha=1., beta=1., lambdaF=0.1, lambdaS=0.1, lambdaG=0.1)
+    b = bnmtf_vb_optimised(R, M, K, L, pri, verbose=False)
+    np.random.seed(1); random.seed(1)
+    b.initialise("random", "random")
+    elbo = [b.elbo()]
+    mse = []
+    for _ in range(6):
+        b.run(5)
+        elbo.append(b.elbo())
+        mse += b.all_performances["MSE"]
+        assert abs(b.beta_s - (1. + 0.5 * b.exp_square_diff())) < 5e-5 * b.beta_s
+    elbo = np.array(elbo)
+    fin = np.isfinite(elbo)
+    assert np.all(np.diff(elbo[fin]) > -1e-6 * np.abs(elbo[fin][1:]))
+    assert mse[-1] < 0.2 * mse[0] and np.all(np.isfinite(mse))
+    for n in NAMES:
+        X = getattr(b, n)
+        assert np.isfinite(X).all()
+        if not n.startswith("mu"):
+            assert X.min() >= 0
