@@ -131,6 +131,29 @@ class DeviceModel(object):
         except Exception:
             pass
 
+    # -- posterior means on the device ------------------------------------------
+    def _set_expectation(self, expectation, iterations):
+        """Before a run(): switch the device-side accumulation of approx_expectation(burn_in, thinning) on or off."""
+        self._dev_expect = None
+        if expectation is None:
+            _lib.check(_lib.lib().bnmtf_set_expectation(self._handle(), -1, 1))
+            return
+        burn_in, thinning = int(expectation[0]), int(expectation[1])
+        assert 0 <= burn_in < iterations and thinning >= 1, "expectation=(burn_in, thinning) needs 0 <= burn_in < iterations, thinning >= 1"
+        _lib.check(_lib.lib().bnmtf_set_expectation(self._handle(), burn_in, thinning))
+        self._dev_expect = (burn_in, thinning)
+
+    def _device_expectation(self, burn_in, thinning):
+        """(exp_A, exp_S or None, exp_B, exp_tau) from the device sums when the last run() accumulated exactly this
+        (burn_in, thinning); None otherwise (the caller then averages the stored samples)."""
+        if getattr(self, "_dev_expect", None) != (int(burn_in), int(thinning)):
+            return None
+        L = getattr(self, "L", 0)
+        A = np.zeros((self.I, self.K)); B = np.zeros((self.J, L if L else self.K)); S = np.zeros((self.K, L)) if L else None
+        tau = C.c_double(); cnt = C.c_uint64()
+        _lib.check(_lib.lib().bnmtf_get_expectation(self._handle(), _lib.ptr(A), _lib.ptr(S), _lib.ptr(B), C.byref(tau), C.byref(cnt)))
+        return (A, S, B, tau.value)
+
     # -- device facts ---------------------------------------------------------
     def omega_counts(self):
         """(size_Omega, per-row, per-column observed counts) as the device holds them."""

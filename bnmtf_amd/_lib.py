@@ -39,6 +39,8 @@ _SIGS = {
     "bnmtf_host_alloc": ([C.c_size_t, C.POINTER(_P)], C.c_int),
     "bnmtf_host_free": ([_P], C.c_int),
     "bnmtf_omega_counts": ([_P, C.POINTER(C.c_uint64), _P, _P], C.c_int),
+    "bnmtf_set_expectation": ([_P, C.c_int, C.c_int], C.c_int),
+    "bnmtf_get_expectation": ([_P, _P, _P, _P, C.POINTER(C.c_double), C.POINTER(C.c_uint64)], C.c_int),
     "bnmtf_set_iteration": ([_P, C.c_uint64], C.c_int),
     "bnmtf_get_iteration": ([_P, C.POINTER(C.c_uint64)], C.c_int),
     "bnmf_set_state": ([_P, _P, _P, C.c_double], C.c_int),

@@ -67,12 +67,16 @@ class bnmf_gibbs_optimised(DeviceModel):
         _lib.check(_lib.lib().bnmf_get_state(self._handle(), _lib.ptr(U), _lib.ptr(V), C.byref(tau)))
         self.U, self.V, self.tau = U, V, tau.value
 
-    def run(self, iterations, update='draw', store_samples=True):
+    def run(self, iterations, update='draw', store_samples=True, expectation=None):
         """:121-157.  One device call runs all iterations; samples, tau, metrics and
         cumulative times come back afterwards.  store_samples=False skips the all_U/all_V
-        hand-off (device-resident benchmark mode); update='mode' runs the ICM harness."""
+        hand-off (device-resident benchmark mode); update='mode' runs the ICM harness;
+        expectation=(burn_in, thinning) also accumulates the posterior means of exactly that
+        approx_expectation(burn_in, thinning) on the device (what the model-selection drivers
+        need: with store_samples=False no sample ever crosses to the host)."""
         it = int(iterations)
         self._push()
+        self._set_expectation(expectation, it)
         # page-locked sample arrays: the device-to-host copy of iteration t overlaps the sweeps of iteration t+1
         U_out = _lib.sample_buffer((it, self.I, self.K)) if store_samples else None
         V_out = _lib.sample_buffer((it, self.J, self.K)) if store_samples else None
@@ -122,6 +126,9 @@ class bnmf_gibbs_optimised(DeviceModel):
 
     # Posterior means from the stored samples (:182-187); host fp64, accepts lists
     def approx_expectation(self, burn_in, thinning):
+        dev = self._device_expectation(burn_in, thinning)
+        if dev is not None:
+            return (dev[0], dev[2], dev[3])
         indices = range(burn_in, len(self.all_U), thinning)
         exp_U = np.array([self.all_U[i] for i in indices], dtype=np.float64).sum(axis=0) / float(len(indices))
         exp_V = np.array([self.all_V[i] for i in indices], dtype=np.float64).sum(axis=0) / float(len(indices))

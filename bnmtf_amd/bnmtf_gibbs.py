@@ -73,10 +73,11 @@ class bnmtf_gibbs_optimised(DeviceModel):
         _lib.check(_lib.lib().bnmtf_get_state(self._handle(), _lib.ptr(F), _lib.ptr(S), _lib.ptr(G), C.byref(tau)))
         self.F, self.S, self.G, self.tau = F, S, G, tau.value
 
-    def run(self, iterations, update='draw', store_samples=True):
-        """:138-180."""
+    def run(self, iterations, update='draw', store_samples=True, expectation=None):
+        """:138-180.  expectation=(burn_in, thinning): posterior means accumulated on the device (see bnmf_gibbs_optimised.run)."""
         it = int(iterations)
         self._push()
+        self._set_expectation(expectation, it)
         F_out = _lib.sample_buffer((it, self.I, self.K)) if store_samples else None
         S_out = _lib.sample_buffer((it, self.K, self.L)) if store_samples else None
         G_out = _lib.sample_buffer((it, self.J, self.L)) if store_samples else None
@@ -135,6 +136,9 @@ class bnmtf_gibbs_optimised(DeviceModel):
 
     def approx_expectation(self, burn_in, thinning):
         """:216-223."""
+        dev = self._device_expectation(burn_in, thinning)
+        if dev is not None:
+            return dev
         indices = range(burn_in, len(self.all_F), thinning)
         exp_F = np.array([self.all_F[i] for i in indices], dtype=np.float64).sum(axis=0) / float(len(indices))
         exp_S = np.array([self.all_S[i] for i in indices], dtype=np.float64).sum(axis=0) / float(len(indices))

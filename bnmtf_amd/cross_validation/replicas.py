@@ -1,0 +1,137 @@
+"""Independent models on device replicas: a list of jobs (one model fit each) is dealt to worker processes, one per
+GPU slot; a worker builds its models with device=<its GPU>.  The parent never touches a GPU.
+
+    pool = ReplicaPool()                 # one worker per visible GPU (in-process when there is a single slot)
+    results = pool.map(fit_model, jobs)  # jobs: list of dicts (see fit_model); results in job order
+
+The reference runs its folds in `multiprocessing.Pool(P)` on CPU cores (parallel_matrix_cross_validation.py:52-65);
+here the unit of parallelism is a GPU."""
+import inspect
+import multiprocessing as mp
+import os
+import traceback
+
+import numpy as np
+
+_worker_device = [0]
+_worker_shared = {}
+
+
+def visible_devices():
+    """Number of GPUs, asked of a short-lived child so that this process never initialises one."""
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(1) as p:
+        return p.apply(_count_devices)
+
+
+def _count_devices():
+    import bnmtf_amd
+    return bnmtf_amd.device_count()
+
+
+def _init_worker(device_queue, shared):
+    _worker_device[0] = device_queue.get()
+    _worker_shared.clear()
+    _worker_shared.update(shared)
+
+
+def _call(args):
+    fn, job = args
+    try:
+        return ("ok", fn(dict(job, device=_worker_device[0]), _worker_shared))
+    except Exception as e:      # noqa: BLE001 -- re-raised in the parent with the worker's traceback
+        return ("error", "%s: %s\n%s" % (type(e).__name__, e, traceback.format_exc()))
+
+
+class ReplicaPool(object):
+    def __init__(self, devices=None, shared=None):
+        """devices: list of device ordinals, one worker each (repeat an ordinal to run several models on one GPU at
+        once); default: every visible GPU once.  shared: dict handed to every worker once (e.g. the data matrix R),
+        so that jobs only carry what differs between them."""
+        if devices is None:
+            n = visible_devices()
+            devices = list(range(max(n, 1)))
+        self.devices = list(devices)
+        self.shared = dict(shared or {})
+        self._pool = None
+
+    def _start(self):
+        if self._pool is None and len(self.devices) > 1:
+            ctx = mp.get_context("spawn")
+            q = ctx.Queue()
+            for d in self.devices:
+                q.put(d)
+            self._pool = ctx.Pool(len(self.devices), initializer=_init_worker, initargs=(q, self.shared))
+
+    def map(self, fn, jobs):
+        """fn(job, shared) -> result for every job, results in job order; job gets a 'device' entry.  An exception in
+        any job is raised here (after all jobs have run) with the worker's traceback."""
+        jobs = list(jobs)
+        if len(self.devices) <= 1:                      # single slot: in this process, like the reference's serial loops
+            _worker_device[0] = self.devices[0] if self.devices else 0
+            _worker_shared.clear(); _worker_shared.update(self.shared)
+            out = [_call((fn, j)) for j in jobs]
+        else:
+            self._start()
+            out = self._pool.map(_call, [(fn, j) for j in jobs], chunksize=1)
+        errs = [r[1] for r in out if r[0] == "error"]
+        if errs:
+            raise RuntimeError("%d of %d replica jobs failed; first:\n%s" % (len(errs), len(jobs), errs[0]))
+        return [r[1] for r in out]
+
+    def close(self):
+        if self._pool is not None:
+            self._pool.close(); self._pool.join()
+            self._pool = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def _accepts(fn, name):
+    try:
+        return name in inspect.signature(fn).parameters
+    except (TypeError, ValueError):
+        return False
+
+
+def fit_model(job, shared):
+    """One candidate model, start to finish, on the worker's GPU.  job:
+        classifier   the model class (bnmf_gibbs_optimised, nmf_icm, bnmtf_vb_optimised, ...)
+        args         positional arguments after (R, M): (K, priors) or (K, L, priors)
+        init         kwargs of initialise()
+        iterations, burn_in, thinning, minimum_TN (the last three may be None)
+        M            training mask;  test: mask to predict on, or None;  R: data matrix, or absent (then shared['R'])
+        seed         optional (numpy / random / sampler seed of this candidate)
+    Returns {'quality': {metric: value}, 'performance': predict(test) or None}."""
+    import random
+    R = job["R"] if job.get("R") is not None else shared["R"]
+    cls = job["classifier"]
+    kw = {}
+    if _accepts(cls.__init__, "device"):
+        kw["device"] = job.get("device", 0)
+    if _accepts(cls.__init__, "verbose"):
+        kw["verbose"] = False
+    if job.get("seed") is not None:
+        np.random.seed(job["seed"] % (2 ** 32)); random.seed(job["seed"])
+        if _accepts(cls.__init__, "seed"):
+            kw["seed"] = job["seed"]
+    model = cls(R, np.asarray(job["M"], dtype=float), *job["args"], **kw)
+    model.initialise(**job["init"])
+    burn_in, thinning = job.get("burn_in"), job.get("thinning")
+    sampled = burn_in is not None and thinning is not None
+    run_kw = {"iterations": job["iterations"]}
+    if job.get("minimum_TN") is not None:
+        run_kw["minimum_TN"] = job["minimum_TN"]
+    if sampled and _accepts(model.run, "expectation"):          # posterior means on the device, no sample hand-off
+        run_kw["expectation"] = (burn_in, thinning); run_kw["store_samples"] = False
+    model.run(**run_kw)
+    q_args = (burn_in, thinning) if sampled else ()
+    quality = {m: model.quality(m, *q_args) for m in job.get("metrics", ["loglikelihood"])}
+    perf = model.predict(np.asarray(job["test"], dtype=float), *q_args) if job.get("test") is not None else None
+    if hasattr(model, "close"):
+        model.close()
+    return {"quality": quality, "performance": perf}

@@ -554,6 +554,30 @@ static int stage_gamma_variates(bnmtf_model* h, int n) {
   return BNMTF_OK;
 }
 
+// approx_expectation on the device: reset at the start of a run() call, add the sample of iteration `it` of that call
+static int expectation_begin(bnmtf_model* h) {
+  if (h->exp_burn < 0) return BNMTF_OK;
+  if (!h->exp_rows) {
+    CHK(dalloc(&h->exp_rows, (size_t)h->rows.xrows * h->rows.KP));
+    CHK(dalloc(&h->exp_cols, (size_t)h->cols.xrows * h->cols.KP));
+    CHK(dalloc(&h->exp_S, (size_t)std::max(h->K * h->L, 1)));
+    CHK(dalloc(&h->exp_tau, 1));
+  }
+  HIPCHK(hipMemsetAsync(h->exp_rows, 0, sizeof(double) * h->rows.nglob * h->rows.KP, h->stream));
+  HIPCHK(hipMemsetAsync(h->exp_cols, 0, sizeof(double) * h->cols.nglob * h->cols.KP, h->stream));
+  HIPCHK(hipMemsetAsync(h->exp_S, 0, sizeof(double) * std::max(h->K * h->L, 1), h->stream));
+  HIPCHK(hipMemsetAsync(h->exp_tau, 0, sizeof(double), h->stream));
+  h->exp_count = 0;
+  return BNMTF_OK;
+}
+static void expectation_add(bnmtf_model* h, int it) {
+  if (h->exp_burn < 0 || it < h->exp_burn || (it - h->exp_burn) % h->exp_thin != 0) return;
+  launch_accumulate(h->rows.X, (size_t)h->rows.nglob * h->rows.KP, h->exp_rows, h->tau_d, h->exp_tau, h->stream);
+  launch_accumulate(h->cols.X, (size_t)h->cols.nglob * h->cols.KP, h->exp_cols, nullptr, nullptr, h->stream);
+  if (h->L > 0) launch_accumulate(h->S, (size_t)h->K * h->L, h->exp_S, nullptr, nullptr, h->stream);
+  h->exp_count++;
+}
+
 }  // namespace bnmtf
 
 using namespace bnmtf;
@@ -701,6 +725,7 @@ int bnmtf_destroy(bnmtf_handle h) {
   if (h->comm) comm_destroy(h->comm);
   free_dir(h->rows); free_dir(h->cols); free_dir(h->reff); free_dir(h->ceff);
   dfree(h->slabsS); dfree(h->CfS); dfree(h->deltaS); dfree(h->s_partial); dfree(h->s_w); dfree(h->s_omp); dfree(h->lambdaS); dfree(h->s_numer); dfree(h->s_taup);
+  dfree(h->exp_rows); dfree(h->exp_cols); dfree(h->exp_S); dfree(h->exp_tau);
   dfree(h->muS); dfree(h->tauS); dfree(h->varS); dfree(h->mv_rows); dfree(h->mv_cols); dfree(h->ss_vd); dfree(h->tri_order); dfree(h->tri_sums);
   dfree(h->ss_Wt); dfree(h->ss_slabs); dfree(h->ss_AB); dfree(h->ss_r); dfree(h->ss_bpart);
   dfree(h->Rfull); dfree(h->Mtrain); dfree(h->Mscratch); dfree(h->Ad); dfree(h->Bd); dfree(h->out6);
@@ -740,6 +765,30 @@ int bnmtf_host_alloc(size_t bytes, void** out) {
 }
 int bnmtf_host_free(void* p) {
   if (p) HIPCHK(hipHostFree(p));
+  return BNMTF_OK;
+}
+
+int bnmtf_set_expectation(bnmtf_handle h, int burn_in, int thinning) {
+  if (burn_in >= 0 && thinning < 1) { set_error("thinning must be >= 1"); return BNMTF_EINVAL; }
+  h->exp_burn = burn_in; h->exp_thin = thinning < 1 ? 1 : thinning;
+  return BNMTF_OK;
+}
+int bnmtf_get_expectation(bnmtf_handle h, double* A, double* S, double* B, double* tau, uint64_t* count) {
+  if (!h->exp_rows || h->exp_count == 0) { set_error("no samples accumulated (bnmtf_set_expectation before run, burn_in < iterations)"); return BNMTF_ESTATE; }
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const double inv = 1.0 / (double)h->exp_count;
+  auto fetch = [&](const double* dev, int rows, int W, int KP, double* dst) -> int {
+    std::vector<double> tmp((size_t)rows * KP);
+    HIPCHK(hipMemcpy(tmp.data(), dev, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int r = 0; r < rows; ++r) for (int k = 0; k < W; ++k) dst[(size_t)r * W + k] = tmp[(size_t)r * KP + k] * inv;
+    return BNMTF_OK;
+  };
+  if (A) CHK(fetch(h->exp_rows, h->I, h->rows.W, h->rows.KP, A));
+  if (B) CHK(fetch(h->exp_cols, h->J, h->cols.W, h->cols.KP, B));
+  if (S && h->L > 0) CHK(fetch(h->exp_S, h->K, h->L, h->L, S));
+  if (tau) { double t; HIPCHK(hipMemcpy(&t, h->exp_tau, sizeof(double), hipMemcpyDeviceToHost)); *tau = t * inv; }
+  if (count) *count = h->exp_count;
   return BNMTF_OK;
 }
 
@@ -833,6 +882,7 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
   sink.add(r.X, h->I, r.W, r.KP, U_out);
   sink.add(c.X, h->J, c.W, c.KP, V_out);
   CHK(sink.begin(h, n_iter));
+  CHK(expectation_begin(h));
   if (times_out) HIPCHK(hipEventRecord(ev[0], h->stream));
 
   for (int it = 0; it < n_iter; ++it) {
@@ -875,6 +925,7 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
     f.gunit = mode == kSweepDraw ? h->gunit + it : nullptr;
     f.tau_d = h->tau_d; f.tau_f = h->tau_f; f.rec = h->rec + (size_t)it * 5;
     launch_finish(f, h->stream);
+    expectation_add(h, it);
     if (times_out) HIPCHK(hipEventRecord(ev[it + 1], h->stream));
     h->iteration++;
   }

@@ -287,6 +287,18 @@ void launch_sum_cols(const double* stats, int nrows, int ld, int ncols, double* 
   hipLaunchKernelGGL(sum_cols_kernel, dim3(1), dim3(256), 0, st, stats, nrows, ld, ncols, out);
 }
 
+// posterior-mean accumulation on the device (approx_expectation, bnmf_gibbs_optimised.py:182-187): sum[e] += X[e] in fp64;
+// the last element (e == n) takes the scalar *tau.  One pass over a factor: 2-4 MB.
+__global__ __launch_bounds__(256) void accumulate_kernel(const float* X, size_t n, double* sum, const double* tau, double* tausum) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < n) sum[e] += (double)X[e];
+  if (e == 0 && tau) *tausum += *tau;
+}
+void launch_accumulate(const float* X, size_t n, double* sum, const double* tau, double* tausum, hipStream_t st) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, X, n, sum, tau, tausum);
+}
+
 // sample hand-off: the W true columns of X [rows][KP] packed into dst [rows][W] (what all_U[it] holds)
 __global__ __launch_bounds__(256) void compact_rows_kernel(const float* X, int rows, int W, int KP, float* dst) {
   const size_t n = (size_t)rows * W;

@@ -240,6 +240,9 @@ __global__ __launch_bounds__(1024) void ssys_chain_kernel(SSysChainArgs a) {
     }
   }
   if (tid < 64) { delta[0][tid & 31] = 0.f; delta[1][tid & 31] = 0.f; }
+  for (int t = tid; t < 2 * 33 * 33; t += 1024) (&Om[0][0])[t] = 0.f;      // lanes beyond L read (and discard) these: keep them finite
+  for (int t = tid; t < 3 * 32 * 33; t += 1024) (&Od[0][0])[t] = 0.f;
+  __syncthreads();
   stage_blocks(0, tid, 1024);
   __syncthreads();
   float prev_delta = 0.f;                                           // wave 0: delta of the previous row, by lane
@@ -251,10 +254,10 @@ __global__ __launch_bounds__(1024) void ssys_chain_kernel(SSysChainArgs a) {
       float my_eta = r[k * L + (on ? lane : 0)];
       if (k > 0) {                                                  // the previous row's deltas, which the background pass has not folded in yet
         const float* od = Od[(k - 1) % 3];
-        for (int l0 = 0; l0 < L; l0 += 8) {                         // eight LDS reads in flight (rows >= L of the block hold stale numbers: their delta is 0)
+        for (int l0 = 0; l0 < L; l0 += 8) {                         // eight LDS reads in flight
           float ov[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) ov[j] = od[((l0 + j) & 31) * 33 + l32];
+          for (int j = 0; j < 8; ++j) ov[j] = (l0 + j < L && on) ? od[((l0 + j) & 31) * 33 + l32] : 0.f;   // rows >= L were never staged: 0 * (stale Inf / NaN) is a NaN
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float dl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, prev_delta), (l0 + j) & 63));

@@ -265,6 +265,7 @@ void launch_tri_vb_finish(const double* sums, double alpha, double beta, double*
 void launch_sum_stats(const double* stats, int nblocks, double* acc, hipStream_t st);   // acc[0..2] += column sums of stats
 void launch_sum_cols(const double* stats, int nrows, int ld, int ncols, double* out, hipStream_t st);        // out[c] += column sums, ncols <= 8
 void launch_compact_rows(const float* X, int rows, int W, int KP, float* dst, hipStream_t st);               // [rows][KP] -> [rows][W]
+void launch_accumulate(const float* X, size_t n, double* sum, const double* tau, double* tausum, hipStream_t st);   // sum += X (fp64), *tausum += *tau
 void launch_transpose(const float* X, int rows, int KP, float* XT, int ldT, hipStream_t st);
 void launch_tn_sample(const double* mu, const double* tau, size_t n, uint64_t seed, uint32_t it, uint32_t col,
                       uint32_t elem0, double* out, hipStream_t st);

@@ -96,6 +96,14 @@ int bnmtf_omega_counts(bnmtf_handle h, uint64_t* total, uint32_t* row, uint32_t*
 int bnmtf_host_alloc(size_t bytes, void** out);
 int bnmtf_host_free(void* p);
 
+/* approx_expectation(burn_in, thinning) (bnmf_gibbs_optimised.py:182-187, bnmtf_gibbs_optimised.py:216-223) on the
+ * device: with burn_in >= 0 every *_gibbs_run call sums (fp64) the samples of its iterations burn_in, burn_in +
+ * thinning, ... and bnmtf_get_expectation returns their means -- no iterations x I x K array crosses to the host (the
+ * model-selection drivers of code/cross_validation/ only need these means).  burn_in < 0 switches it off (default).
+ * A: I x K, S: K x L (BNMTF, else ignored), B: J x K (or J x L); any may be NULL. */
+int bnmtf_set_expectation(bnmtf_handle h, int burn_in, int thinning);
+int bnmtf_get_expectation(bnmtf_handle h, double* A, double* S, double* B, double* tau, uint64_t* count);
+
 /* Gibbs iteration counter = RNG counter word 2 (continues across run calls). */
 int bnmtf_set_iteration(bnmtf_handle h, uint64_t it);
 int bnmtf_get_iteration(bnmtf_handle h, uint64_t* it);

@@ -425,6 +425,30 @@ def make_bnmtf_vb():
     np.savez_compressed(os.path.join(HERE, "bnmtf_vb.npz"), **out)
 
 
+def make_masks():
+    """code/cross_validation/mask.py under random.seed: the masks / folds the reference draws (the vectorised
+    bnmtf_amd.cross_validation.mask consumes the same random stream)."""
+    import random
+    sys.path.insert(0, TMP + "/BNMTF/code/cross_validation")
+    import mask as ref_mask
+    out = {}
+    random.seed(1); out["generate_M"] = ref_mask.generate_M(7, 5, 0.3)
+    M = np.ones((9, 6)); M[0, 1] = M[3, 3] = M[8, 5] = M[4, 0] = 0
+    out["M"] = M
+    random.seed(2); out["folds"] = np.array(ref_mask.compute_folds(9, 6, 4, M))
+    random.seed(3); out["folds_attempts"] = np.array(ref_mask.compute_folds_attempts(9, 6, 3, 50, M))
+    out["Ms"] = np.array(ref_mask.compute_Ms(list(out["folds"])))
+    random.seed(4); tr, te = ref_mask.generate_M_from_M(M, 0.3); out["split_train"], out["split_test"] = tr, te
+    random.seed(5); tr, te = ref_mask.try_generate_M_from_M(M, 0.4, 20); out["try_train"], out["try_test"] = tr, te
+    random.seed(6); rows = ref_mask.compute_crossval_folds_rows_attempts(M, 5, 3, 50)
+    out["rows_train"] = np.array([a for a, b in rows]); out["rows_test"] = np.array([b for a, b in rows])
+    random.seed(7); cols = ref_mask.compute_crossval_folds_columns_attempts(M, 4, 2, 50)
+    out["cols_train"] = np.array([a for a, b in cols]); out["cols_test"] = np.array([b for a, b in cols])
+    out["inverse"] = ref_mask.calc_inverse_M(M)
+    out["nz"] = np.array(ref_mask.nonzero_indices(M))
+    np.savez_compressed(os.path.join(HERE, "masks.npz"), **out)
+
+
 def make_toy_data():
     """The reference's toy inputs (data files its own tests/experiments hold) as one fixture."""
     out = {}
@@ -437,7 +461,7 @@ def make_toy_data():
 
 if __name__ == "__main__":
     import_reference()
-    which = sys.argv[1:] or ["toy", "bnmf", "bnmtf", "vb", "tn", "traj", "icm", "trivb"]
+    which = sys.argv[1:] or ["toy", "bnmf", "bnmtf", "vb", "tn", "traj", "icm", "trivb", "masks"]
     if "toy" in which: make_toy_data()
     if "bnmf" in which: make_bnmf_cond()
     if "bnmtf" in which: make_bnmtf_cond()
@@ -446,6 +470,7 @@ if __name__ == "__main__":
     if "traj" in which: make_trajectories()
     if "icm" in which: make_icm()
     if "trivb" in which: make_bnmtf_vb()
+    if "masks" in which: make_masks()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

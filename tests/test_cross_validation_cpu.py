@@ -1,0 +1,101 @@
+"""bnmtf_amd.cross_validation without a GPU: the vectorised mask helpers against masks the reference drew
+(tests/golden/masks.npz), and the replica scheduling / selection logic of the search and cross-validation drivers with a
+stand-in classifier (tests/cv_fakes.py)."""
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+os.environ["PYTHONPATH"] = os.pathsep.join([HERE, os.path.dirname(HERE), os.environ.get("PYTHONPATH", "")])   # for spawned workers
+
+from bnmtf_amd.cross_validation import (GreedySearch, GridSearch, LineSearch, LineSearchCrossValidation, MatrixCrossValidation,
+                                         ParallelMatrixCrossValidation, ReplicaPool, mask)
+from bnmtf_amd.cross_validation.replicas import fit_model
+from cv_fakes import FakeModel, FakeTri
+
+
+def test_masks_and_folds_are_the_reference_s_under_random_seed(golden):
+    g = golden("masks.npz")._z
+    M = g["M"]
+    random.seed(1); assert np.array_equal(mask.generate_M(7, 5, 0.3), g["generate_M"])
+    random.seed(2); folds = mask.compute_folds(9, 6, 4, M); assert np.array_equal(np.array(folds), g["folds"])
+    assert np.array_equal(np.array(mask.compute_Ms(folds)), g["Ms"])
+    random.seed(3); assert np.array_equal(np.array(mask.compute_folds_attempts(9, 6, 3, 50, M)), g["folds_attempts"])
+    random.seed(4); tr, te = mask.generate_M_from_M(M, 0.3); assert np.array_equal(tr, g["split_train"]) and np.array_equal(te, g["split_test"])
+    random.seed(5); tr, te = mask.try_generate_M_from_M(M, 0.4, 20); assert np.array_equal(tr, g["try_train"]) and np.array_equal(te, g["try_test"])
+    random.seed(6); rows = mask.compute_crossval_folds_rows_attempts(M, 5, 3, 50)
+    assert np.array_equal(np.array([a for a, b in rows]), g["rows_train"]) and np.array_equal(np.array([b for a, b in rows]), g["rows_test"])
+    random.seed(7); cols = mask.compute_crossval_folds_columns_attempts(M, 4, 2, 50)
+    assert np.array_equal(np.array([a for a, b in cols]), g["cols_train"]) and np.array_equal(np.array([b for a, b in cols]), g["cols_test"])
+    assert np.array_equal(mask.calc_inverse_M(M), g["inverse"]) and np.array_equal(np.array(mask.nonzero_indices(M)), g["nz"])
+    assert mask.check_empty_rows_columns(M) and not mask.check_empty_rows_columns(np.zeros((3, 3)))
+    assert mask.nonzero_row_indices(M)[0] == [0, 2, 3, 4, 5] and mask.nonzero_column_indices(M)[0] == [0, 1, 2, 3, 5, 6, 7, 8]
+    assert len(mask.recover_predictions(M, np.ones((9, 6)), np.zeros((9, 6)))) == 4
+
+
+def test_replica_pool_deals_jobs_to_worker_processes_and_reports_failures():
+    R = np.ones((6, 5)); M = np.ones((6, 5))
+    jobs = [dict(classifier=FakeModel, args=(K, {}), init={"init": "random"}, iterations=5, burn_in=2, thinning=1, minimum_TN=None,
+                 M=M, test=M, metrics=["loglikelihood", "MSE"], seed=K) for K in range(1, 9)]
+    with ReplicaPool(devices=[0, 1, 0], shared={"R": R}) as pool:
+        res = pool.map(fit_model, jobs)
+        assert [r["quality"]["MSE"] for r in res] == [FakeModel(R, M, K, {}, seed=K).quality("MSE") for K in range(1, 9)]   # job order kept
+        assert {r["performance"]["device"] for r in res} <= {0, 1} and len({r["performance"]["pid"] for r in res}) >= 2
+        assert all(r["performance"]["expectation_burn_in"] == 2 for r in res)          # sampled models accumulate on the device
+        assert os.getpid() not in {r["performance"]["pid"] for r in res}
+        with pytest.raises(RuntimeError) as e:
+            pool.map(fit_model, jobs + [dict(jobs[0], args=(13, {}))])
+        assert "unlucky K" in str(e.value) and "1 of 9" in str(e.value)
+    serial = ReplicaPool(devices=[0], shared={"R": R}).map(fit_model, jobs[:2])      # one slot: in this process
+    assert serial[0]["performance"]["pid"] == os.getpid()
+
+
+def test_line_grid_and_greedy_search_select_like_the_reference():
+    R = np.ones((6, 5)); M = np.ones((6, 5))
+    ls = LineSearch(FakeModel, [2, 3, 4, 5, 6], R, M, {"alpha": 1}, "random", iterations=10, restarts=3, seed=0)
+    ls.search(burn_in=3, thinning=2)
+    assert ls.best_value("BIC") == 4 and ls.best_value("MSE") == 4 and len(ls.all_values("AIC")) == 5
+    # of the three restarts (seeds s, s+1, s+2) the one with the largest log-likelihood (seed % 3 == 2) is kept
+    assert ls.all_values("loglikelihood")[2] == 2.0
+    with pytest.raises(AssertionError) as e:
+        ls.all_values("FAIL")
+    assert str(e.value) == "Unrecognised metric name: FAIL."
+    pri = {"alpha": 1, "lambdaF": 0.1, "lambdaS": 0.2, "lambdaG": 0.3}
+    gs = GridSearch(FakeTri, [1, 2, 3, 4], [4, 5, 6], R, M, pri, "random", "random", iterations=5)
+    gs.search()
+    assert gs.best_value("BIC") == (3, 5) and gs.all_values("MSE").shape == (4, 3) and gs.all_values("MSE")[0, 0] == 5
+    gr = GreedySearch(FakeTri, [1, 2, 3, 4, 5], [3, 4, 5, 6, 7], R, M, pri, "random", "random", iterations=5)
+    gr.search("AIC")
+    assert gr.best_value("AIC") == (3, 5)
+    tried = {(K, L) for K, L, _ in gr.all_values("AIC")}
+    assert (1, 3) in tried and (5, 7) not in tried and len(tried) < 25          # a walk, not the whole grid
+
+
+def test_line_search_cross_validation_and_matrix_cross_validation(tmp_path):
+    rs = np.random.RandomState(0)
+    R = rs.rand(12, 10); M = np.ones((12, 10)); M[0, 0] = M[5, 5] = 0
+    random.seed(0)
+    f = str(tmp_path / "perf.txt")
+    with ReplicaPool(devices=[0, 0], shared={"R": R}) as pool:
+        cv = LineSearchCrossValidation(FakeModel, R, M, [3, 4, 5], folds=3, priors={}, init_UV="random", iterations=8, restarts=2,
+                                       quality_metric="AIC", file_performance=f, pool=pool, seed=1)
+        cv.run(burn_in=2, thinning=2)
+    txt = open(f).read()
+    assert txt.count("Best K for fold") == 3 and "Best K for fold 1: 4." in txt and "Average performance:" in txt
+    assert abs(cv.average_performance["MSE"] - 0.504) < 1e-12 and len(cv.performances["Rp"]) == 3
+    # parameter search over K with the serial and the parallel driver: same folds (same random seed), same numbers
+    out = []
+    for cls, extra in ((MatrixCrossValidation, {}), (ParallelMatrixCrossValidation, {"P": 2, "devices": [0, 0]})):
+        random.seed(5)
+        f2 = str(tmp_path / (cls.__name__ + ".txt"))
+        c = cls(FakeModel, R, M, 4, [{"K": 2, "priors": {}}, {"K": 6, "priors": {}}], {"iterations": 3}, f2, **extra)
+        c.run()
+        best = c.find_best_parameters("MSE", low_better=True)
+        assert best[0] == {"K": 2, "priors": {}} and abs(best[1] - 0.502) < 1e-12
+        out.append((c.performances["MSE"], c.all_performances[c.JSON({"K": 6, "priors": {}})]["n_test"]))
+        assert "Best performances" in open(f2).read()
+    assert out[0] == out[1]

@@ -1,0 +1,87 @@
+"""Model selection on the device: the posterior means accumulated on the GPU (run(..., expectation=(burn_in, thinning)))
+equal approx_expectation() of the stored samples (bnmf_gibbs_optimised.py:182-187, bnmtf_gibbs_optimised.py:216-223), and
+the search / cross-validation drivers run real classifiers on replica slots of the one GPU of this box."""
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+
+from bnmtf_amd import bnmf_gibbs_optimised, bnmtf_gibbs_optimised, bnmf_vb_optimised, nmf_icm
+from bnmtf_amd.cross_validation import LineSearch, LineSearchCrossValidation, ParallelMatrixCrossValidation, ReplicaPool
+from bnmtf_amd.synthetic import generate_bnmf, generate_bnmtf
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["PYTHONPATH"] = os.pathsep.join([ROOT, os.environ.get("PYTHONPATH", "")])      # for spawned workers
+PRI = dict(alpha=1., beta=1., lambdaU=0.1, lambdaV=0.1)
+
+
+def test_device_expectation_equals_the_mean_of_the_stored_samples():
+    I, J, K = 300, 260, 7
+    R, M, _, _ = generate_bnmf(I, J, K, 0.15, seed_data=1, seed_mask=2)
+    b = bnmf_gibbs_optimised(R, M, K, PRI, verbose=False, seed=3)
+    np.random.seed(0); b.initialise("random")
+    b.run(40, expectation=(10, 3))                       # samples stored AND accumulated
+    dev = b.approx_expectation(10, 3)
+    b._dev_expect = None                                 # force the host path over the same samples
+    host = b.approx_expectation(10, 3)
+    for d, h in zip(dev[:2], host[:2]):
+        assert np.abs(d - h).max() <= 1e-6 * np.abs(h).max()
+    assert abs(dev[2] - host[2]) < 1e-12 * host[2]
+    assert b.approx_expectation(5, 2)[0].shape == (I, K)  # a different (burn_in, thinning): from the stored samples
+    # without any stored sample: quality / predict work from the device means alone
+    c = bnmf_gibbs_optimised(R, M, K, PRI, verbose=False, seed=3)
+    np.random.seed(0); c.initialise("random")
+    c.run(40, expectation=(10, 3), store_samples=False)
+    assert len(c.all_U) == 0
+    np.testing.assert_allclose(c.quality("loglikelihood", 10, 3), b.quality("loglikelihood", 10, 3), rtol=1e-9)
+    np.testing.assert_allclose(c.predict(M, 10, 3)["MSE"], b.predict(M, 10, 3)["MSE"], rtol=1e-9)
+    # tri-factorisation
+    K, L = 5, 4
+    R3, M3, _, _, _ = generate_bnmtf(I, J, K, L, 0.15, seed_data=4, seed_mask=5)
+    t = bnmtf_gibbs_optimised(R3, M3, K, L, dict(alpha=1., beta=1., lambdaF=0.1, lambdaS=0.1, lambdaG=0.1), verbose=False, seed=6)
+    np.random.seed(1); t.initialise("random", "random")
+    t.run(30, expectation=(8, 2))
+    dev = t.approx_expectation(8, 2)
+    t._dev_expect = None
+    host = t.approx_expectation(8, 2)
+    for d, h in zip(dev[:3], host[:3]):
+        assert np.abs(d - h).max() <= 1e-6 * np.abs(h).max()
+    assert abs(dev[3] - host[3]) < 1e-12 * host[3]
+
+
+def test_line_search_finds_the_rank_of_synthetic_data_on_two_replica_slots():
+    I, J, K = 120, 90, 4
+    R, M, _, _ = generate_bnmf(I, J, K, 0.1, tau=4.0, seed_data=7, seed_mask=8)
+    R = R.astype(np.float64); M = M.astype(np.float64)
+    with ReplicaPool(devices=[0, 0], shared={"R": R}) as pool:                 # two worker processes sharing this box's GPU
+        for cls, kw in ((bnmf_gibbs_optimised, dict(burn_in=60, thinning=2)), (bnmf_vb_optimised, {}), (nmf_icm, dict(minimum_TN=0.1))):
+            ls = LineSearch(cls, [2, 4, 7], R, M, PRI, "random" if cls is not bnmf_vb_optimised else "exp", iterations=100, restarts=2, pool=pool, seed=11)
+            ls.search(**kw)
+            assert ls.best_value("BIC") == 4, (cls.__name__, ls.all_values("BIC"))
+            assert ls.all_values("MSE")[0] > ls.all_values("MSE")[1]
+
+
+def test_cross_validation_drivers_run_real_models(tmp_path):
+    I, J, K = 100, 80, 3
+    R, M, _, _ = generate_bnmf(I, J, K, 0.1, tau=4.0, seed_data=9, seed_mask=10)
+    R = R.astype(np.float64); M = M.astype(np.float64)
+    random.seed(0)
+    f = str(tmp_path / "lscv.txt")
+    with ReplicaPool(devices=[0, 0], shared={"R": R}) as pool:
+        cv = LineSearchCrossValidation(bnmf_gibbs_optimised, R, M, [2, 3, 5], folds=3, priors=PRI, init_UV="random", iterations=80, restarts=1,
+                                       quality_metric="BIC", file_performance=f, pool=pool, seed=2)
+        cv.run(burn_in=40, thinning=2)
+    txt = open(f).read()
+    assert txt.count("Best K for fold") == 3 and txt.count(": 3.") >= 2
+    assert cv.average_performance["MSE"] < 1.0 and cv.average_performance["R^2"] > 0.8
+    random.seed(1)
+    f2 = str(tmp_path / "pmcv.txt")
+    pri1 = dict(alpha=1., beta=1., lambdaU=1., lambdaV=1.)         # initial factors at the data's scale (ICM started far off collapses to zero)
+    c = ParallelMatrixCrossValidation(nmf_icm, R, M, 3, [{"K": 3, "priors": pri1}, {"K": 1, "priors": pri1}], {"init": "random", "iterations": 60}, f2, P=2, devices=[0, 0])
+    c.run()
+    best = c.find_best_parameters("MSE", low_better=True)
+    assert best[0]["K"] == 3 and best[1] < c.performances["MSE"][1]
