@@ -62,6 +62,10 @@ _SIGS = {
     "bnmtf_vb_update": ([_P, C.c_int, C.c_int, C.c_int, C.c_int], C.c_int),
     "bnmtf_vb_exp_square_diff": ([_P, C.POINTER(C.c_double), _P], C.c_int),
     "bnmtf_vb_run": ([_P, C.c_int, _P, _P, _P, _P, _P], C.c_int),
+    "bnmtf_kmeans_create": ([_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)], C.c_int),
+    "bnmtf_kmeans_destroy": ([_P], C.c_int),
+    "bnmtf_kmeans_assign": ([_P, _P, _P, _P, _P], C.c_int),
+    "bnmtf_kmeans_sums": ([_P, _P, _P, _P], C.c_int),
     "bnmtf_metric_sums": ([_P, _P, _P, _P, _P, _P], C.c_int),
     "bnmtf_tn_sample": ([_P, _P, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, _P], C.c_int),
     "bnmtf_tn_moments": ([_P, _P, C.c_size_t, C.c_int, _P, _P], C.c_int),

@@ -133,3 +133,39 @@ def test_factors_wider_than_32_take_the_64_wide_paths(K, L):
         assert np.abs(b.muG(t, l) - o.muG(to, l)).max() < 2e-4 * np.abs(o.muG(to, l)).max()
     b.run(5)
     assert np.isfinite(b.S).all() and b.S.min() >= 0 and b.S.shape == (K, L)
+
+
+def test_device_kmeans_equals_host_kmeans():
+    """bnmtf_amd.kmeans.KMeans with the assignment / sums passes on the GPU against the NumPy path (code/models/kmeans/
+    kmeans.py semantics: MSE over shared observed coordinates, ties to the lowest index, 'singleton' refill of an empty
+    cluster), same `random.seed` -> same starting centroids -> same clustering, on clustered data with 30 % missing."""
+    import random
+    from bnmtf_amd.kmeans import KMeans
+    rs = np.random.RandomState(5)
+    n, d, K = 700, 90, 6
+    centres = rs.normal(0, 4, (K, d))
+    lab = rs.randint(K, size=n)
+    X = centres[lab] + rs.normal(0, 0.5, (n, d))
+    M = (rs.rand(n, d) > 0.3).astype(float)
+    M[np.arange(n), rs.randint(d, size=n)] = 1
+    res = {}
+    for dev in (None, 0):
+        km = KMeans(X, M, K, device=dev)
+        km.initialise(seed=11)
+        km.cluster()
+        res[dev] = (km.clustering_results.copy(), km.centroids.copy(), km.mask_centroids.copy())
+    assert np.array_equal(res[None][0], res[0][0])
+    assert np.abs(res[None][1] - res[0][1]).max() < 1e-5 * np.abs(res[None][1]).max()
+    assert np.array_equal(res[None][2], res[0][2])
+    # each true group ends in one cluster
+    rows = res[0][0].argmax(axis=1)
+    assert all(len(set(rows[lab == g])) == 1 for g in range(K))
+    # more clusters than natural groups: the empty-cluster rule runs on both paths alike
+    out = []
+    for dev in (None, 0):
+        km = KMeans(X[:60], M[:60], 9, device=dev)
+        km.initialise(seed=3)
+        km.cluster()
+        out.append(km.clustering_results.copy())
+        assert out[-1].sum(axis=0).min() >= 1
+    assert np.array_equal(out[0], out[1])
