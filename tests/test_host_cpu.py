@@ -192,3 +192,15 @@ def test_non_binary_mask_is_rejected_before_the_device_sees_it():
     with pytest.raises(AssertionError) as e:
         b.run(1)
     assert str(e.value) == "The indicator matrix M must contain only 0 and 1."
+
+
+def test_gdsc_text_loader_round_trip(tmp_path):
+    """bnmtf_amd.data: the drug-sensitivity text format of data_drug_sensitivity/gdsc/load_data.py:15-86."""
+    from bnmtf_amd import data
+    f = str(tmp_path / "gdsc.txt")
+    X = np.array([[1.5, 0.0, -2.0], [0.0, 3.25, 4.0]]); M = np.array([[1., 0., 1.], [0., 1., 1.]])
+    data.store_gdsc(f, X, M, ["d1", "d2", "d3"], ["c1", "c2"], ["t1", "t2"], ["s1", "s2"])
+    X2, Xmin, M2, drugs, cells, cancers, tissues = data.load_gdsc(f, sep="\t")
+    assert np.array_equal(M2, M) and np.array_equal(X2, X * M) and drugs == ["d1", "d2", "d3"] and cells == ["c1", "c2"] and tissues == ["s1", "s2"]
+    assert np.array_equal(Xmin, np.where(M == 1, X - (-2.0 - 1), 0.0))
+    assert np.array_equal(data.negate_gdsc(X2, M2), np.where(M == 1, -X + 4.0, 0.0))
