@@ -104,3 +104,82 @@ def test_two_rank_sharded_sweep_reproduces_single_process_chain():
     np.testing.assert_allclose(V, o.V, rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(taus, o.all_tau, rtol=1e-9)
     np.testing.assert_allclose(mses, o.all_performances["MSE"], rtol=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BNMF VB and BNMTF Gibbs over ranks (api_models.inc): what is exchanged, checked with the oracle's arithmetic
+# ---------------------------------------------------------------------------------------------------------------
+def _vb_and_tri_run(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    R, M, K, pri, U0, V0 = _problem()
+    I, J = R.shape
+    r0, nr = shard_range(I, rank, world); c0, nc = shard_range(J, rank, world)
+    rows = slice(r0, r0 + nr); cols = slice(c0, c0 + nc)
+    # ---- BNMF VB: rank r updates q(U) of its rows, q(V) of its columns; (E, S2) blocks are gathered after each half
+    # sweep; exp_square_diff (bnmf_vb_optimised.py:185-187) is the all-reduced sum of the ranks' masked pieces
+    v = O.BNMFVBOracle(R, M, K, pri)
+    v.initialise("exp")
+    full = O.BNMFVBOracle(R, M, K, pri); full.initialise("exp")
+    for it in range(3):
+        for k in range(K):
+            v.update_U(k); v.update_exp_U(k)         # (the oracle updates every row; a rank keeps its own block ...)
+        for name in ("muU", "tauU", "expU", "varU"):
+            blk = getattr(v, name)[rows].copy()
+            setattr(v, name, _gather_blocks(blk, I, K, rank, world))          # ... and receives the others' blocks
+        for k in range(K):
+            v.update_V(k); v.update_exp_V(k)
+        for name in ("muV", "tauV", "expV", "varV"):
+            blk = getattr(v, name)[cols].copy()
+            setattr(v, name, _gather_blocks(blk, J, K, rank, world))
+        S2U, S2V = v.varU + v.expU ** 2, v.varV + v.expV ** 2
+        piece = (M[rows] * ((R[rows] - v.expU[rows] @ v.expV.T) ** 2 + S2U[rows] @ S2V.T - (v.expU[rows] ** 2) @ (v.expV ** 2).T)).sum()
+        t = torch.tensor([piece], dtype=torch.float64)
+        dist.all_reduce(t)
+        v.alpha_s = v.alpha + v.size_Omega / 2.0; v.beta_s = v.beta + 0.5 * float(t.item()); v.update_exp_tau()
+        full.sweep()
+        assert abs(v.exptau - full.exptau) < 1e-12 * full.exptau
+        assert np.abs(v.expU - full.expU).max() < 1e-12 and np.abs(v.varV - full.varV).max() < 1e-12
+    # ---- BNMTF: the S step's dense system.  A[(k,l),(k',l')] = sum_ij M_ij F_ik G_jl F_ik' G_jl' and b = sum_ij M_ij R_ij
+    # F_ik G_jl are sums over columns j: a rank forms them over ITS columns, one all-reduce gives every rank the whole system
+    rs = np.random.RandomState(5)
+    Kt, Lt = 3, 4
+    F = rs.exponential(1.0, (I, Kt)); S = rs.exponential(1.0, (Kt, Lt)); G = rs.exponential(1.0, (J, Lt))
+    def system(jsl):
+        A = np.zeros((Kt * Lt, Kt * Lt)); b = np.zeros(Kt * Lt)
+        for j in range(*jsl.indices(J)):
+            W = (F * M[:, j:j + 1]).T @ F                          # W_j[k][k'] = sum_i M_ij F_ik F_ik'
+            A += np.kron(W, np.outer(G[j], G[j]))
+            b += np.kron((M[:, j] * R[:, j]) @ F, G[j])
+        return A, b
+    A_loc, b_loc = system(cols)
+    t = torch.tensor(np.concatenate([A_loc.ravel(), b_loc]), dtype=torch.float64)
+    dist.all_reduce(t)                                             # the "K x L Gram" exchange: one all-reduce of (A, b)
+    A = t.numpy()[:A_loc.size].reshape(A_loc.shape); b = t.numpy()[A_loc.size:]
+    A_full, b_full = system(slice(0, J))
+    assert np.allclose(A, A_full, rtol=1e-12) and np.allclose(b, b_full, rtol=1e-12)
+    # the coordinate step on (A, b) is the reference's tauS / muS (bnmtf_gibbs_optimised.py:201-205)
+    tri = O.BNMTFGibbsOracle(R, M, Kt, Lt, dict(alpha=1., beta=1., lambdaF=0.3, lambdaS=0.2, lambdaG=0.6))
+    tri.F, tri.S, tri.G, tri.tau = F, S.copy(), G, 0.7
+    s = S.ravel()
+    for (k, l) in [(0, 0), (1, 2), (2, 3)]:
+        a = k * Lt + l
+        tauS = tri.tau * A[a, a]
+        muS = (-0.2 + tri.tau * (b[a] - A[a] @ s + A[a, a] * s[a])) / tauS
+        assert abs(tauS - tri.tauS(k, l)) < 1e-10 * tauS and abs(muS - tri.muS(tri.tauS(k, l), k, l)) < 1e-9 * (abs(muS) + 1)
+    q.put((rank, True))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_vb_and_tri_factorisation_exchanges():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_vb_and_tri_run, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(q.get(timeout=5)[0] for _ in range(2)) == [0, 1]
