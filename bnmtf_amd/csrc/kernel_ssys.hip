@@ -36,12 +36,19 @@ __global__ __launch_bounds__(256) void scol_gram_kernel(SColGramArgs a) {
 #pragma unroll
   for (int t = 0; t < 16; ++t) acc[t] = 0.f;
   float dv = 0.f;                                                   // sum_miss varF_i[c] (diagonal, VB)
-  for (uint32_t e0 = s0; e0 < s1; e0 += 16) {                       // eight MFMA steps (sixteen entries) in flight
+  uint32_t in[8];                                                   // the NEXT batch's row indices: the row loads of a batch wait for its indices only once, ahead of the loop
+#pragma unroll
+  for (int t = 0; t < 8; ++t) in[t] = s0 + 2u * t + half < s1 ? a.idx[s0 + 2u * t + half] : 0u;
+  for (uint32_t e0 = s0; e0 < s1; e0 += 16) {                       // eight MFMA steps (sixteen entries) per batch
     uint32_t ii[8]; float fv[8], vv[8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) ii[t] = a.idx[e0 + 2u * t + half];
+    for (int t = 0; t < 8; ++t) ii[t] = in[t];
 #pragma unroll
     for (int t = 0; t < 8; ++t) { fv[t] = a.F[(size_t)ii[t] * 32 + c]; vv[t] = a.varF ? a.varF[(size_t)ii[t] * 32 + c] : 0.f; }
+    if (e0 + 16 < s1) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) in[t] = a.idx[e0 + 16 + 2u * t + half];
+    }
 #pragma unroll
     for (int t = 0; t < 8; ++t) { acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[t], fv[t], acc, 0, 0, 0); dv += vv[t]; }
   }
@@ -170,7 +177,13 @@ __global__ void ssys_sum_parts_kernel(const float* slabs, int nsplit, size_t n, 
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   float s = 0.f;
-  for (int t = 0; t < nsplit; ++t) s += slabs[(size_t)t * n + e];
+  for (int t0 = 0; t0 < nsplit; t0 += 8) {                         // eight loads in flight, added in part order
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = t0 + j < nsplit ? slabs[(size_t)(t0 + j) * n + e] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+  }
   A[e] = s;
 }
 void launch_ssys_sum_parts(const float* slabs, int nsplit, size_t n, float* A, hipStream_t st) {
@@ -284,6 +297,8 @@ __global__ __launch_bounds__(1024) void ssys_chain_kernel(SSysChainArgs a) {
         const float tau_p = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_taup), l));
         float snew = 0.f;
         if (UPDATE == 0) {
+          // (the entry's constants through LDS, read a step ahead with a uniform address, measured slower than these
+          // readlanes: 267 vs 221 us -- the extra LDS waits land on the chain)
           const float irt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_pre.irt), l));
           const float rcp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_pre.rcp), l));
           const float tpirt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_pre.tpirt), l));
