@@ -17,6 +17,7 @@
 // summed with ONE all-reduce -- the "K x L Gram" exchange -- after which every rank walks the same chain.
 // K, L <= 32 (one 32 x 32 MFMA tile per column / per row of A); larger ranks keep the per-row path of kernel_bnmtf.hip.
 #include <algorithm>
+#include <type_traits>
 
 #include "sweep_common.h"
 
@@ -204,35 +205,45 @@ void launch_ssys_residual(const float* A, const float* b, const float* S, int n2
   hipLaunchKernelGGL(ssys_residual_kernel, dim3((n2 + 3) / 4), dim3(256), 0, st, A, b, S, n2, r);
 }
 
-// The K.L sequential conditionals, row-major (k, l) (bnmtf_gibbs_optimised.py:157-160), one block of 16 waves.
-//   * the residual r = b - A S lives in LDS.  Row k of S is walked by wave 0, lane l owning entry (k, l): its numerator is
-//     -lambda + tau (r_l + S_kl A_ll - sum_{l'' < l} delta_l'' A_l''l), the running sum one FMA per step against the row's
-//     L x L diagonal block of A (LDS); a step is one readlane, the sampler on wave-uniform values, a ballot.
-//   * everything that does not depend on the chain is off it: the first four candidates of EVERY entry are made by the
-//     1024 threads before the first row (word-only halves: log, sqrt, cos), waves 1-15 stage the next row's blocks of A
-//     while wave 0 walks the current one, and fold the previous row's deltas into the residual of the rows still to come
-//     (A is symmetric: a column is read as a coalesced row); the one row that cannot wait for that -- the next one --
-//     gets the last deltas from wave 0 itself, out of registers, against the staged off-diagonal block.
-//   * the proposal is chosen by a branch (the parameters are wave-uniform): the common normal regime skips the
-//     translated-exponential constants.  Same candidate sequence and acceptance rule as oracle/rng.py.
+// The K.L sequential conditionals, row-major (k, l) (bnmtf_gibbs_optimised.py:157-160), one block of 8 waves.
+// Measured with -DCHAIN_CLOCK (tools/variant.sh): a lone wave issues an instruction every ~9 cycles, so the chain's cost is
+// its instruction count: ~195 cycles a step in the normal regime, ~280 more in the translated-exponential one.
+//   * the residual r = b - A S lives in LDS.  Row k of S is walked by wave 0, lane l owning entry (k, l).  Its numerator is
+//       -lambda + tau (r_l + sum_{l'' <= l} Sold_l'' A_l''l  -  sum_{l'' < l} Snew_l'' A_l''l):
+//     the first sum (the row's own old values put back into the residual) does not depend on the chain and is made by a
+//     background wave a row ahead; the second is ONE FMA per step against the row's diagonal block, staged in LDS
+//     already multiplied by -tau.
+//   * everything else that does not depend on the chain is off it too: the first four candidates of EVERY entry are made
+//     by the whole block before the first row, already scaled by the entry's sigma (tau_p = tau A_aa is known up front),
+//     so that in the normal regime a step is: readlane (numerator) -> one FMA per candidate lane (x = numer / tau_p +
+//     z sigma) -> class test (accepted iff x is a non-negative finite number: the event z >= -mu sqrt(tau_p) of
+//     oracle/rng.py, stated on x) -> ballot -> readlane -> the FMA above; its LDS operands are read two steps ahead.
+//     The regime test is a compare of the numerator with a per-entry threshold (-A0 sqrt(tau_p)); the translated-
+//     exponential regime, dead entries and a whole batch of rejections leave through ONE wave-uniform branch.
+//   * the other waves run a row ahead of the chain and never wait for memory inside a row: the loads they issue while wave 0
+//     walks row k (blocks of A for row k+2, the rows of A that fold row k's deltas into the residual of rows >= k+2)
+//     are consumed during row k+1, when the deltas exist.  A is symmetric: a column is read as a coalesced row, 16 bytes
+//     per lane.  The one row that cannot wait for the fold -- the next one -- gets the last deltas from wave 0 itself,
+//     out of registers, against the staged off-diagonal block.
 //   cond >= 0: only evaluate entry `cond` (numer, tau_p) and change nothing -- the tauS / muS hook.
 template <int UPDATE>      // 0: draws, 1: mode updates (ICM / the deterministic harness)
-__global__ __launch_bounds__(1024) void ssys_chain_kernel(SSysChainArgs a) {
+__global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
 #pragma clang fp contract(off)
   constexpr int NH = 4;                                            // hoisted candidates per entry
-  // Od(k, k+1) is staged during row k-1 and read during row k+1: three buffers.  One spare row / entry behind Om and
-  // cands: the one-step-ahead reads of the chain run one past the end.
-  __shared__ float r[1024], Om[2][33 * 33], Od[3][32 * 33], delta[2][32];
-  __shared__ float cands[(1024 + 1) * NH * 3];
-  const int K = a.K, L = a.L, n2 = K * L, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // Od(k, k+1) is staged during row k-1 and read during row k+1: three buffers.  Spare rows / entries behind Om and the
+  // candidate records: the two-steps-ahead reads of the chain run past the end.
+  __shared__ __align__(16) float r[1024];
+  __shared__ __align__(16) float delta[2][32];
+  __shared__ float snl[32 + 4];
+  __shared__ float Sl[1024], laml[1024], Om[2][35 * 33], Od[3][32 * 33], Tn[2][32];
+  __shared__ float4 recA[(1024 + 3) * NH];                         // {z sigma, 1 / tau_p, regime threshold, sigma}
+  __shared__ float2 recB[(1024 + 3) * NH];                         // {-log u1, u2}: the translated-exponential regime
+  const int K = a.K, L = a.L, n2 = K * L, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // in an SGPR: the role branches below are jumps, not exec masks
   const float tau = *a.tau;
-  auto stage_blocks = [&](int k, int t0, int nt) {                 // diagonal block of row k and the block (k, k+1) -> LDS
-    for (int t = t0; t < L * L; t += nt) {
-      const int l1 = t / L, l2 = t % L;
-      Om[k & 1][l1 * 33 + l2] = a.A[(size_t)(k * L + l1) * n2 + k * L + l2];
-      if (k + 1 < K) Od[k % 3][l1 * 33 + l2] = a.A[(size_t)(k * L + l1) * n2 + (k + 1) * L + l2];
-    }
-  };
+#ifdef CHAIN_CLOCK
+  const unsigned long long c_k0 = __builtin_amdgcn_s_memtime();
+#endif
   if (a.cond >= 0) {                                               // tauS(k,l) / muS(k,l) hook: the residual already holds everything
     if (tid == 0) {
       const float aaa = a.A[(size_t)a.cond * n2 + a.cond];
@@ -241,128 +252,255 @@ __global__ __launch_bounds__(1024) void ssys_chain_kernel(SSysChainArgs a) {
     }
     return;
   }
-  if (tid < n2) {
-    r[tid] = a.r0[tid];
-    if (UPDATE == 0) {
+  // ---- background register pipeline: issued in one row, consumed in the next.  Eight waves (256 VGPRs each: the
+  // pipeline is held in registers); wave 4 shares wave 0's SIMD (waves of a workgroup go round the four SIMDs) and
+  // stays idle -- whatever it issued would take issue slots from the chain.  That leaves 6 waves, 384 threads.
+  constexpr int NT = 512, NB = 384, QB = 3, QF = 5;                // block elements / fold items per thread: L.L <= QB NB, 2 (n2 - 2 L) <= QF NB
+  const bool bg = (wave & 3) != 0;
+  const int bt = (wave - 1 - (wave >> 2)) * 64 + lane;
+  float sm[QB], sd[QB], own[16];            // blocks of the row after next; its own-row operands (wave 1: 16 per half)
+  float4 fold[QF][4];                                                // A[(k, h + 8 j)][4 columns]: the rows that fold row k's deltas, QF items a thread
+  const bool vec = (L & 3) == 0;
+  auto issue_blocks = [&](int kk) {                                // diagonal block of row kk and block (kk, kk+1) -> registers
 #pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      const int t = bt + q * NB;
+      if (t < L * L) {
+        const int l1 = t / L, l2 = t % L;
+        sm[q] = a.A[(size_t)(kk * L + l1) * n2 + kk * L + l2];
+        if (kk + 1 < K) sd[q] = a.A[(size_t)(kk * L + l1) * n2 + (kk + 1) * L + l2];
+      }
+    }
+    if (wave == 1) {
+      const int lp = lane & 31, lb = lane & 32 ? 16 : 0;
+#pragma unroll
+      for (int l = 0; l < 16; ++l) own[l] = (lb + l <= lp && lp < L) ? a.A[(size_t)(kk * L + lb + l) * n2 + kk * L + lp] : 0.f;
+    }
+  };
+  auto store_blocks = [&](int kk) {
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      const int t = bt + q * NB;
+      if (t < L * L) {
+        const int l1 = t / L, l2 = t % L;
+        Om[kk & 1][l1 * 33 + l2] = -tau * sm[q];
+        if (kk + 1 < K) Od[kk % 3][l1 * 33 + l2] = sd[q];
+      }
+    }
+    if (wave == 1) {                                                // sum_{l <= lp} S_(kk,l) A[(kk,l)][(kk,lp)], row kk not walked yet
+      const int lb = lane & 32 ? 16 : 0;
+      float s = 0.f;
+#pragma unroll
+      for (int l = 0; l < 16; ++l) s = fmaf(Sl[kk * L + (lb + l < L ? lb + l : 0)], own[l], s);
+      s += __shfl_xor(s, 32, 64);
+      if (lane < 32) Tn[kk & 1][lane] = lane < L ? s : 0.f;
+    }
+  };
+  auto issue_fold = [&](int kk) {                                  // rows of A for the deltas of row kk, columns of rows >= kk+2
+    const int t0 = (kk + 2) * L, items = 2 * (n2 - t0);            // (n2 - t0) / 4 column groups x 8 residues of l
+    if (vec) {
+#pragma unroll
+      for (int q = 0; q < QF; ++q) {
+        const int w = bt + q * NB;
+        if (w < items) {
+          const int g = w >> 3, h = w & 7;
+          const float* col = a.A + (size_t)(kk * L + h) * n2 + t0 + 4 * g;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) fold[q][j] = h + 8 * j < L ? *reinterpret_cast<const float4*>(col + (size_t)(8 * j) * n2) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    }
+  };
+  // ---- prologue
+  for (int e = tid; e < n2; e += NT) {
+    r[e] = a.r0[e]; Sl[e] = a.S[e]; laml[e] = a.lambdaS[e];
+    if (UPDATE == 0) {
+      const TnPre pre = tn_fast_pre(tau * a.A[(size_t)e * n2 + e]);
+      const float thr = pre.live ? -kTnA0 * pre.tpirt : __builtin_inff();    // a dead entry always leaves through the slow branch
       for (int c = 0; c < NH; ++c) {
-        const U4 rr = philox4x32_10(0u, (uint32_t)tid, a.it, kStreamS + 16u * (uint32_t)c, a.key0, a.key1);
+        const U4 rr = philox4x32_10(0u, (uint32_t)e, a.it, kStreamS + 16u * (uint32_t)c, a.key0, a.key1);
         const TnCand cd = tn_cand_pre(rr.x, rr.y);
-        cands[(tid * NH + c) * 3 + 0] = cd.nl; cands[(tid * NH + c) * 3 + 1] = cd.z; cands[(tid * NH + c) * 3 + 2] = cd.u2;
+        recA[e * NH + c] = make_float4(cd.z * pre.irt, pre.rcp, thr, pre.irt);
+        recB[e * NH + c] = make_float2(cd.nl, cd.u2);
       }
     }
   }
   if (tid < 64) { delta[0][tid & 31] = 0.f; delta[1][tid & 31] = 0.f; }
-  for (int t = tid; t < 2 * 33 * 33; t += 1024) (&Om[0][0])[t] = 0.f;      // lanes beyond L read (and discard) these: keep them finite
-  for (int t = tid; t < 3 * 32 * 33; t += 1024) (&Od[0][0])[t] = 0.f;
+  for (int t = tid; t < 2 * 35 * 33; t += NT) (&Om[0][0])[t] = 0.f;      // lanes beyond L read (and discard) these: keep them finite
+  for (int t = tid; t < 3 * 32 * 33; t += NT) (&Od[0][0])[t] = 0.f;
   __syncthreads();
-  stage_blocks(0, tid, 1024);
+  if (bg) { issue_blocks(0); store_blocks(0); if (K > 1) { issue_blocks(1); store_blocks(1); } }
   __syncthreads();
-  float prev_delta = 0.f;                                           // wave 0: delta of the previous row, by lane
-  for (int k = 0; k < K; ++k) {
-    const int cur = k & 1;
-    if (wave == 0) {
+#ifdef CHAIN_CLOCK
+  unsigned long long c_pro = 0, c_steps = 0, c_wait = 0, c_slow = 0, c_t0 = __builtin_amdgcn_s_memtime(), c_begin = c_t0; int n_slow = 0;
+#endif
+  // two loops, one per role, meeting at the same K barriers: the register allocation is the larger of the two roles, not their sum
+  if (wave == 0) {
+    for (int k = 0; k < K; ++k) {
+      const int cur = k & 1;
+      {
       const bool on = lane < L;
       const int l32 = lane & 31;                                    // lanes >= 32 mirror lanes 0-31: every LDS address below is valid, no exec juggling
-      float my_eta = r[k * L + (on ? lane : 0)];
+      const int me = k * L + (on ? lane : 0);
+      float my_eta = r[me];
       if (k > 0) {                                                  // the previous row's deltas, which the background pass has not folded in yet
-        const float* od = Od[(k - 1) % 3];
-        for (int l0 = 0; l0 < L; l0 += 8) {                         // eight LDS reads in flight
-          float ov[8];
+        // (a lone wave issues an instruction every ~7 cycles: what counts here is the number of instructions.  Each half
+        // of the wave takes 16 of the 32 rows; rows and columns beyond L hold zeros, no predicates.)
+        const float* od = Od[(k - 1) % 3] + (lane & 32 ? 16 * 33 : 0) + l32;
+        const float* dq = delta[cur ^ 1] + (lane & 32 ? 16 : 0);
+        float acc = 0.f;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) ov[j] = (l0 + j < L && on) ? od[((l0 + j) & 31) * 33 + l32] : 0.f;   // rows >= L were never staged: 0 * (stale Inf / NaN) is a NaN
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float dl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, prev_delta), (l0 + j) & 63));
-            my_eta = fmaf(-dl, ov[j], my_eta);
-          }
-        }
+        for (int j = 0; j < 16; ++j) acc = fmaf(dq[j], od[j * 33], acc);
+        acc += __shfl_xor(acc, 32, 64);
+        my_eta -= acc;
       }
       const float* om = Om[cur];
-      const float my_oll = om[l32 * 33 + l32], my_lam = a.lambdaS[k * L + (on ? lane : 0)];
-      float my_s = a.S[k * L + (on ? lane : 0)], my_delta = 0.f, corr = 0.f;
-      const float c0 = fmaf(tau, my_eta + my_s * my_oll, -my_lam);  // numerator before the row's own deltas
-      const float my_taup = tau * my_oll;
-      const TnPre my_pre = tn_fast_pre(my_taup);                    // tau_p of every entry is known before the chain starts
-      const float* cbase = &cands[(k * L * NH + (lane & (NH - 1))) * 3];
-      float row_n = om[l32];                                        // A[(k,l)][(k,lane)] and candidate `lane` of entry l: one step ahead
-      float cnl_n = cbase[0], cz_n = cbase[1], cu2_n = cbase[2];
-      for (int l = 0; l < L; ++l) {
-        const float row = row_n, cnl = cnl_n, cz = cz_n, cu2 = cu2_n;
-        row_n = om[(l + 1) * 33 + l32];
-        cnl_n = cbase[(l + 1) * NH * 3 + 0]; cz_n = cbase[(l + 1) * NH * 3 + 1]; cu2_n = cbase[(l + 1) * NH * 3 + 2];
-        const float numer_v = fmaf(-tau, corr, c0);
+      const float my_taup = -om[l32 * 33 + l32], my_sold = Sl[me];
+      float numer_v = fmaf(tau, my_eta + Tn[cur][l32], -laml[me]);  // every old value of the row put back; the new ones enter as the chain walks
+      const int cbase = k * L * NH + (lane & (NH - 1));
+      // -tau A[(k,l)][(k,lane)] and candidate `lane & 3` of entry l: three steps ahead, in four register sets
+      const float* omp = om + l32; const float4* pa = recA + cbase; const float2* pb = recB + cbase;
+      float rowq[4]; float4 raq[4]; float2 rbq[4];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { rowq[q] = omp[q * 33]; raq[q] = pa[q * NH]; rbq[q] = pb[q * NH]; }
+      float* snp = snl;                                             // the row's new values, by entry (every lane writes the same word)
+      auto step = [&](int l, int q, float row, float4 ra, float2 rb) {
         const float numer = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, numer_v), l));
-        const float sold = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_s), l));
-        const float tau_p = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_taup), l));
-        float snew = 0.f;
+        float snew;
         if (UPDATE == 0) {
-          // (the entry's constants through LDS, read a step ahead with a uniform address, measured slower than these
-          // readlanes: 267 vs 221 us -- the extra LDS waits land on the chain)
-          const float irt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_pre.irt), l));
-          const float rcp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_pre.rcp), l));
-          const float tpirt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_pre.tpirt), l));
-          // both proposals evaluated, the regime and the live test are selects (every value here is wave-uniform except the
-          // candidate words): one branch per step, for the rare whole-batch rejection
-          const float mu = numer * rcp;
-          const float av = -mu * tpirt;                             // -mu sqrt(tau_p)
-          const bool live = tau_p > 0.0f && isfinite(av);
-          const bool tail = av >= kTnA0;
-          float d = 0.f, ilam = 0.f, xc = fmaf(cz, irt, mu);
-          bool acc = cz >= av;
-          if (__builtin_amdgcn_readfirstlane((int)tail)) {         // wave-uniform: the normal regime skips the translated-exponential constants
-            d = 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(av, av, 4.0f)) + av);
-            ilam = __builtin_amdgcn_rcpf(av + d);
-            const float e = cnl * ilam, t = e - d;
-            acc = cu2 <= __builtin_amdgcn_exp2f(-0.72134752f * t * t);
-            xc = e * irt;
-          }
-          unsigned long long m = __ballot(acc && live) & ((1ull << NH) - 1ull);
-          if (__builtin_expect(m == 0ull && __ballot(live) != 0ull, 0)) {   // candidates NH + 64 round + lane
-            TnFast tp; tp.mu = mu; tp.irt = irt; tp.a = av; tp.live = true; tp.tail = tail;
-            tp.d = 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(av, av, 4.0f)) + av); tp.ilam = __builtin_amdgcn_rcpf(av + tp.d);
-            for (uint32_t round = 0; m == 0ull && round < 64u; ++round) {
-              const U4 rr = philox4x32_10(0u, (uint32_t)(k * L + l), a.it, kStreamS + 16u * ((uint32_t)NH + round * 64u + (uint32_t)lane), a.key0, a.key1);
-              m = __ballot(tn_eval_fast(tp, rr.x, rr.y, &xc));
+          float xc = fmaf(numer, ra.y, ra.x);                       // normal regime, live entry: accepted iff x is +0, +denormal or +normal
+          unsigned long long mc;
+          asm("v_cmp_class_f32 %0, %1, %2" : "=s"(mc) : "v"(xc), "s"(0x1C0));
+          unsigned long long m = (mc & ~__builtin_amdgcn_ballot_w64(numer <= ra.z)) & ((1ull << NH) - 1ull);
+          if (__builtin_expect(m == 0ull, 0)) {
+#ifdef CHAIN_CLOCK
+            ++n_slow; const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
+            // translated-exponential regime, a dead entry, or the whole batch rejected.  The entry's constants are in the
+            // record: sigma, 1 / tau_p, sqrt(tau_p) = -thr / A0 (thr = +inf marks a dead entry)
+            const float irt = ra.w, rcp = ra.y, tpirt = -4.0f * ra.z;
+            static_assert(kTnA0 == 0.25f, "tpirt above is -thr / A0");
+            TnFast tp; tp.mu = numer * rcp; tp.irt = irt; tp.a = -tp.mu * tpirt; tp.live = true; tp.tail = tp.a >= kTnA0;
+            tp.d = 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(tp.a, tp.a, 4.0f)) + tp.a); tp.ilam = __builtin_amdgcn_rcpf(tp.a + tp.d);
+            if (__builtin_amdgcn_ballot_w64(ra.z < __builtin_inff() && isfinite(tp.a)) != 0ull) {
+              if (__builtin_amdgcn_ballot_w64(tp.tail) != 0ull) {   // the hoisted candidates, in this regime
+                const float e = rb.x * tp.ilam, t = e - tp.d;
+                xc = e * irt;
+                unsigned long long mt;
+                asm("v_cmp_class_f32 %0, %1, %2" : "=s"(mt) : "v"(xc), "s"(0x1C0));
+                m = (mt & __builtin_amdgcn_ballot_w64(rb.y <= __builtin_amdgcn_exp2f(-0.72134752f * t * t))) & ((1ull << NH) - 1ull);
+              }                                                     // (normal regime here: the threshold compare and tp.tail disagree in the last bit, or all four were rejected)
+              for (uint32_t round = 0; m == 0ull && round < 64u; ++round) {   // candidates NH + 64 round + lane
+                const U4 rr = philox4x32_10(0u, (uint32_t)(k * L + l), a.it, kStreamS + 16u * ((uint32_t)NH + round * 64u + (uint32_t)lane), a.key0, a.key1);
+                const bool acc = tn_eval_fast(tp, rr.x, rr.y, &xc);
+                m = __builtin_amdgcn_ballot_w64(acc && isfinite(xc) && xc >= 0.0f);
+              }
             }
+            if (m == 0ull) { xc = 0.f; m = 1ull; }                  // dead entry, or 4100 rejections
+#ifdef CHAIN_CLOCK
+            c_slow += __builtin_amdgcn_s_memtime() - ts0;
+#endif
           }
-          const float xs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xc), m ? __ffsll((long long)m) - 1 : 0));
-          snew = m ? tn_guard(xs) : 0.f;
+          snew = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xc), __builtin_ctzll(m)));
         } else {
+          const float tau_p = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_taup), l));
           const float mu = numer / tau_p;
           snew = fmaxf((tau_p > 0.f && mu > 0.f) ? mu : 0.f, a.min_x);
         }
-        const float dl = snew - sold;
-        if (lane == l) { my_s = snew; my_delta = dl; }
-        corr = fmaf(dl, row, corr);                                  // what lanes l' > l subtract when their turn comes
-      }
+        snp[q] = snew;
+        numer_v = fmaf(snew, row, numer_v);                          // what lanes l' > l see when their turn comes
+      };
+#ifdef CHAIN_CLOCK
+      { const unsigned long long tt = __builtin_amdgcn_s_memtime(); c_pro += tt - c_t0; c_t0 = tt; }
+#endif
+      auto quad = [&](int l, auto guarded) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (!decltype(guarded)::value || l + q < L) {
+            rowq[(q + 3) & 3] = omp[(q + 3) * 33];
+            if (UPDATE == 0) { raq[(q + 3) & 3] = pa[(q + 3) * NH]; rbq[(q + 3) & 3] = pb[(q + 3) * NH]; }
+            step(l + q, q, rowq[q], raq[q], rbq[q]);
+          }
+        }
+        omp += 4 * 33; pa += 4 * NH; pb += 4 * NH; snp += 4;
+      };
+      if ((L & 3) == 0) for (int l = 0; l < L; l += 4) quad(l, std::false_type{});
+      else              for (int l = 0; l < L; l += 4) quad(l, std::true_type{});
+#ifdef CHAIN_CLOCK
+      { const unsigned long long tt = __builtin_amdgcn_s_memtime(); c_steps += tt - c_t0; c_t0 = tt; }
+#endif
+      const float my_s = snl[l32];
+      const float my_delta = on ? my_s - my_sold : 0.f;
       if (on) { a.S[k * L + lane] = my_s; delta[cur][lane] = my_delta; }
-      prev_delta = my_delta;
-    } else {
-      // waves 1-15, beside the chain: the next row's blocks of A, and the deltas of row k-1 folded into rows >= k+1
-      if (k + 1 < K) stage_blocks(k + 1, tid - 64, 960);
+      }
+      __syncthreads();
+#ifdef CHAIN_CLOCK
+      { const unsigned long long tt = __builtin_amdgcn_s_memtime(); c_wait += tt - c_t0; c_t0 = tt; }
+#endif
+    }
+  } else {
+    for (int k = 0; k < K; ++k) {
+      const int cur = k & 1;
+      if (bg) {
+      // ---- consume what was issued during the previous row
+      if (k >= 1 && k + 1 < K) store_blocks(k + 1);
       if (k > 0) {
         const float* dp = delta[cur ^ 1];
-        for (int t = (k + 1) * L + (tid - 64); t < n2; t += 960) {
-          const float* col = a.A + (size_t)((k - 1) * L) * n2 + t;
-          float s = r[t];
-          for (int l0 = 0; l0 < L; l0 += 8) {
-            float av[8];
+        const int t0 = (k + 1) * L;
+        if (vec) {
+          const int items = 2 * (n2 - t0);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) av[j] = l0 + j < L ? col[(size_t)(l0 + j) * n2] : 0.f;
+          for (int q = 0; q < QF; ++q) {
+            const int w = bt + q * NB;
+            if (w < items) {                                         // item = (four columns, l mod 8)
+              const int g = w >> 3, h = w & 7;
+              float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s = fmaf(-dp[(l0 + j) & 31], av[j], s);
+              for (int j = 0; j < 4; ++j) {
+                const float d = dp[(h + 8 * j) & 31];
+                s.x = fmaf(d, fold[q][j].x, s.x); s.y = fmaf(d, fold[q][j].y, s.y); s.z = fmaf(d, fold[q][j].z, s.z); s.w = fmaf(d, fold[q][j].w, s.w);
+              }
+              // the eight residues sit in eight adjacent lanes (the item count is a multiple of eight): a fixed-order butterfly
+#pragma unroll
+              for (int mk = 1; mk <= 4; mk <<= 1) {
+                s.x += __shfl_xor(s.x, mk, 64); s.y += __shfl_xor(s.y, mk, 64); s.z += __shfl_xor(s.z, mk, 64); s.w += __shfl_xor(s.w, mk, 64);
+              }
+              if (h == 0) {
+                float4* rp = reinterpret_cast<float4*>(&r[t0 + 4 * g]);
+                float4 o = *rp;
+                o.x -= s.x; o.y -= s.y; o.z -= s.z; o.w -= s.w;
+                *rp = o;
+              }
+            }
           }
-          r[t] = s;
+        } else {
+          for (int t = t0 + bt; t < n2; t += NB) {
+            const float* col = a.A + (size_t)((k - 1) * L) * n2 + t;
+            float s = r[t];
+            for (int l0 = 0; l0 < L; l0 += 8) {
+              float av[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) av[j] = l0 + j < L ? col[(size_t)(l0 + j) * n2] : 0.f;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) s = fmaf(-dp[(l0 + j) & 31], av[j], s);
+            }
+            r[t] = s;
+          }
         }
       }
+      // ---- issue for the next row
+      if (k + 2 < K) { issue_blocks(k + 2); issue_fold(k); }
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
+#ifdef CHAIN_CLOCK
+  if (tid == 0 && (a.it == 30u || a.it == 31u)) printf("chain it %u: prologue %llu, row-pro %llu, steps %llu, barrier %llu cycles; slow %d taking %llu\n", a.it, c_begin - c_k0, c_pro, c_steps, c_wait, n_slow, c_slow);
+#endif
 }
 void launch_ssys_chain(const SSysChainArgs& a, hipStream_t st) {
-  if (a.update == 0) hipLaunchKernelGGL(ssys_chain_kernel<0>, dim3(1), dim3(1024), 0, st, a);
-  else               hipLaunchKernelGGL(ssys_chain_kernel<1>, dim3(1), dim3(1024), 0, st, a);
+  if (a.update == 0) hipLaunchKernelGGL(ssys_chain_kernel<0>, dim3(1), dim3(512), 0, st, a);
+  else               hipLaunchKernelGGL(ssys_chain_kernel<1>, dim3(1), dim3(512), 0, st, a);
 }
 
 }  // namespace bnmtf

@@ -61,13 +61,13 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
     const __amdgpu_buffer_rsrc_t rs2 = panel_rsrc(f.XoT2, (size_t)(KP / 2) * f.ld2_o * 8);
     const __amdgpu_buffer_rsrc_t rsx = panel_rsrc(f.XoS, (size_t)KP * f.ld2_o * 8);
     stage_panel_buf<(NS > 0 ? NS : 1)>(rs2, 0u, pan, chunks2, sid, lane * 16);
-    __syncthreads();
+    sync_with_dma();
     for (int kp = 0; kp < KP / 2; ++kp) {
       if (kp + 1 < KP / 2) stage_panel_buf<(NS > 0 ? NS : 1)>(rs2, (uint32_t)(kp + 1) * stride_b, pan + (size_t)((kp + 1) & 1) * 2 * PW, chunks2, sid, lane * 16);
-      __syncthreads();
+      sync_with_dma();
     }
     stage_panel_buf<(NS > 0 ? NS : 1)>(rsx, 0u, pan, chunks2, sid, lane * 16);
-    __syncthreads();
+    sync_with_dma();
 #ifdef BNMTF_PHASE_TIMING
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = tick(0.f);
 #endif
@@ -86,7 +86,7 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
         ret[lane] = ef;
       }
       TICK(2, ef);
-      __syncthreads();                   // lands the next panel (vmcnt) and releases the unit waves
+      sync_with_dma();                   // lands the next panel (vmcnt) and releases the unit waves
       TICK(3, ef);
       if (sid == 0 && lane < 2 * NW && mgi >= 0) {   // the seven stores per unit go out behind the barrier: nobody waits for them
         const size_t p = (size_t)mgi * KP + k;
@@ -98,7 +98,7 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
     if (blockIdx.x % 101 == 0 && lane == 0 && sid == 0)
       printf("vb block %d service wave: dma issue %llu  wait1 %llu  moments %llu  wait2 %llu (cycles, %d columns)\n", (int)blockIdx.x, ph[0], ph[1], ph[2], ph[3], K);
 #endif
-    if (f.stats) __syncthreads();
+    if (f.stats) sync_with_dma();
     return;
   }
   const int pair = blockIdx.x * NW + wave;
@@ -148,7 +148,7 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
     const uint32_t stride_b = (uint32_t)f.ld2_o * 8u;
     const __amdgpu_buffer_rsrc_t rs2 = panel_rsrc(f.XoT2, (size_t)(KP / 2) * f.ld2_o * 8);
     if (NS == 0) stage_panel_buf<NW>(rs2, 0u, pan, chunks2, wave, lane * 16);
-    __syncthreads();
+    sync_with_dma();
     const int npair = KP / 2;
     for (int kp = 0; kp < npair; ++kp) {
       if (NS == 0 && kp + 1 < npair) stage_panel_buf<NW>(rs2, (uint32_t)(kp + 1) * stride_b, pan + (size_t)((kp + 1) & 1) * 2 * PW, chunks2, wave, lane * 16);
@@ -164,7 +164,7 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
         q2[h] = pk_fma(va, x01, q2[h]);
         vp2[h] = pk_fma(vb, x01, vp2[h]);
       }
-      __syncthreads();
+      sync_with_dma();
     }
 #pragma unroll
     for (int h = 0; h < EH; ++h) { q2[h] = f32x2{q2[h].x + q2[h].y, vp2[h].x + vp2[h].y}; vp2[h] = f32x2{0.f, 0.f}; }
@@ -174,7 +174,7 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
   const __amdgpu_buffer_rsrc_t rsx = panel_rsrc(f.XoS, (size_t)KP * f.ld2_o * 8);
   const uint32_t cstride_b = (uint32_t)f.ld2_o * 8u;
   if (NS == 0) stage_panel_buf<NW>(rsx, 0u, pan, chunks2, wave, lane * 16);
-  __syncthreads();
+  sync_with_dma();
 #ifdef BNMTF_PHASE_TIMING
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = tick(q2[0].x);
 #endif
@@ -217,7 +217,7 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
       *reinterpret_cast<float4*>(&xch[(2 * wave + half) * 4]) = o;
     }
     TICK(2, numer);
-    __syncthreads();
+    sync_with_dma();
     TICK(3, numer);
     // between the two barriers of a column the block's moments are evaluated, one unit per lane: by the first service
     // wave, or (NS == 0) by wave 0.  The seven global stores per unit go out behind the second barrier, whose vmcnt(0)
@@ -230,7 +230,7 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
       if (mgi >= 0) tn_moments_f32(o.x, o.y, &ef, &vf);
       ret[lane] = ef;
     }
-    __syncthreads();                     // also lands the next panel (vmcnt) and retires this one
+    sync_with_dma();                     // also lands the next panel (vmcnt) and retires this one
     if (mom && mgi >= 0) {
       const size_t p = (size_t)mgi * KP + k;
       a.Xself[p] = ef; a.mu_self[p] = o.x; a.tau_self[p] = o.y; a.var_self[p] = vf; a.S2self[p] = vf + ef * ef;
@@ -261,7 +261,7 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
     px = half_sum_d(px); sq = half_sum_d(sq); sq2 = half_sum_d(sq2);
     double* red = reinterpret_cast<double*>(pan);      // panels are dead: reuse
     if (l5 == 0) { red[(wave * 2 + half) * 3 + 0] = valid ? px : 0.0; red[(wave * 2 + half) * 3 + 1] = sq; red[(wave * 2 + half) * 3 + 2] = sq2; }
-    __syncthreads();
+    sync_with_dma();
     if (tid < 3) {
       double s = 0.0;
       for (int w = 0; w < 2 * NW; ++w) s += red[w * 3 + tid];
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void vb_pieces_kernel(int n, int n0, int KP, i
   // one row of partial sums per block (4 units), in unit order
   __shared__ double red[4][6];
   if (lane == 0) for (int c = 0; c < 6; ++c) red[threadIdx.x >> 6][c] = p[c];
-  __syncthreads();
+  sync_with_dma();
   if (threadIdx.x < 6) out[(size_t)blockIdx.x * 8 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 

@@ -97,8 +97,8 @@ __device__ __forceinline__ bool tn_cand_post(const TnFast& p, const TnCand& c, f
 __device__ __forceinline__ bool tn_eval_fast(const TnFast& p, uint32_t r0, uint32_t r1, float* x) { return tn_cand_post(p, tn_cand_pre(r0, r1), x); }
 
 // LDS-direct staging of one panel: `chunks` pieces of 1 KiB (64 lanes x 16 B), wave w takes
-// chunks w, w+8, ...  No VGPRs, no ds_write; completion is covered by the vmcnt(0) that
-// __syncthreads() carries while an LDS-DMA is in flight.
+// chunks w, w+8, ...  No VGPRs, no ds_write; completion: the issuing wave's vmcnt(0), which
+// sync_with_dma() (below) waits for ahead of the barrier -- __syncthreads() alone does not.
 template <int NW>
 __device__ __forceinline__ void stage_panel(const float* src, float* dst, int chunks, int wave, int lane) {
   typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -119,6 +119,14 @@ __device__ __forceinline__ void stage_panel_buf(__amdgpu_buffer_rsrc_t rsrc, uin
   for (int c = wave; c < chunks; c += NW)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(dst + (size_t)c * 256), 16, lane16, (int)(byte_off + (uint32_t)c * 1024u), 0, 0);
 }
+
+// Workgroup barrier for kernels that stage through LDS-DMA.  __syncthreads() is a workgroup-scope fence + s_barrier; on
+// gfx950 that fence waits for the LDS counter only, and the compiler adds a vector-memory wait just where ITS alias
+// analysis sees one of this wave's LDS reads meet an LDS-DMA still in flight -- which says nothing about the OTHER
+// waves that gather from the piece this wave staged.  (Seen as wrong rows from some column on when three ranks shared one
+// GPU and the DMA took longer than a column: tools/stress_sharded.py.)  Every barrier that is meant to publish staged
+// pieces waits for vmcnt(0) explicitly.
+__device__ __forceinline__ void sync_with_dma() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 #ifdef BNMTF_PHASE_TIMING
 // debug build only (make timing): shader-clock stamps at the phase boundaries; a few blocks print their sums
