@@ -27,124 +27,197 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // W~_j = C~f - sum_{i in miss(j)} (F_i F_i^T + diag(varF_i)) for every local column j: one wave per column, the 32 x 32
 // tile in MFMA accumulators.  v_mfma_f32_32x32x2_f32 takes A[i][k] and B[k][j] from lane (i or j) + 32 k: for the Gram of
-// two entries e, e+1 both operands are the same register, F[idx[e + (lane >> 5)]][lane & 31].
+// two entries both operands are the same register, F[entry of this half][lane & 31] -- and since the Gram is a sum over
+// the entries, which entry goes to which (step, half) is free: each half takes four CONSECUTIVE slots per 16-byte index
+// load.  What the loop costs besides its MFMAs is what matters (a vector instruction between MFMAs adds its 4 cycles to
+// their 64, the texture path takes ~9 cycles per wave-level load): per step one shift-add (row offset), one row load.
+// Everything else sits in buffer descriptors, scalar offsets and immediates.  Rows are loaded a batch (8 steps) ahead,
+// indices two.
+template <int VB>
 __global__ __launch_bounds__(256) void scol_gram_kernel(SColGramArgs a) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & 63, half = lane >> 5, c = lane & 31;
-  const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int u = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (u >= a.n) return;
-  const uint32_t s0 = a.slot_ptr[u], s1 = a.slot_ptr[u + 1];       // 64-wide slots, padded with the zero row
-  f32x16 acc;
+  const uint32_t s0 = __builtin_amdgcn_readfirstlane(a.slot_ptr[u]), s1 = __builtin_amdgcn_readfirstlane(a.slot_ptr[u + 1]);   // 64-wide slots, padded with the zero row
+  const __amdgpu_buffer_rsrc_t rsI = panel_rsrc(reinterpret_cast<const float*>(a.idx), 0x7fffffffu);
+  const __amdgpu_buffer_rsrc_t rsF = panel_rsrc(a.F, 0x7fffffffu), rsV = panel_rsrc(VB ? a.varF : a.F, 0x7fffffffu);
+  const int hoff = half * 16, c4 = c * 4;
+  f32x16 acc, acc2;                                                 // two accumulators: an MFMA never waits for the one before it
 #pragma unroll
-  for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+  for (int t = 0; t < 16; ++t) { acc[t] = 0.f; acc2[t] = 0.f; }
   float dv = 0.f;                                                   // sum_miss varF_i[c] (diagonal, VB)
-  uint32_t in[8];                                                   // the NEXT batch's row indices: the row loads of a batch wait for its indices only once, ahead of the loop
+  struct Idx { u32x4 q[2]; };
+  struct Rows { float f[8], v[8]; };
+  auto load_idx = [&](uint32_t e, Idx& ix) {                        // slots e .. e + 15: half h takes e + 8 q + 4 h .. + 3
+    const int so = (int)((e < s1 ? e : s0) * 4u);                   // past the column's end: any valid slots (never multiplied)
+    ix.q[0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsI, hoff, so, 0));
+    ix.q[1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsI, hoff + 32, so, 0));
+  };
+  auto load_rows = [&](const Idx& ix, Rows& r) {
 #pragma unroll
-  for (int t = 0; t < 8; ++t) in[t] = s0 + 2u * t + half < s1 ? a.idx[s0 + 2u * t + half] : 0u;
-  for (uint32_t e0 = s0; e0 < s1; e0 += 16) {                       // eight MFMA steps (sixteen entries) per batch
-    uint32_t ii[8]; float fv[8], vv[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) ii[t] = in[t];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) { fv[t] = a.F[(size_t)ii[t] * 32 + c]; vv[t] = a.varF ? a.varF[(size_t)ii[t] * 32 + c] : 0.f; }
-    if (e0 + 16 < s1) {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) in[t] = a.idx[e0 + 16 + 2u * t + half];
+    for (int t = 0; t < 8; ++t) {
+      const int off = (int)(ix.q[t >> 2][t & 3] * 128u) + c4;
+      r.f[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsF, off, 0, 0));
+      if (VB) r.v[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsV, off, 0, 0));
     }
+  };
+  auto mfmas = [&](const Rows& r) {
 #pragma unroll
-    for (int t = 0; t < 8; ++t) { acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[t], fv[t], acc, 0, 0, 0); dv += vv[t]; }
+    for (int t = 0; t < 8; t += 2) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(r.f[t], r.f[t], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(r.f[t + 1], r.f[t + 1], acc2, 0, 0, 0);
+      if (VB) dv += r.v[t] + r.v[t + 1];
+    }
+  };
+  Idx ia, ib; Rows ra, rb;
+  load_idx(s0, ia); load_idx(s0 + 16, ib);
+  load_rows(ia, ra);
+  for (uint32_t e0 = s0; e0 < s1; e0 += 32) {                       // two batches per trip (the slot count is a multiple of 64): register sets alternate without copies
+    load_rows(ib, rb); load_idx(e0 + 32, ia);
+    mfmas(ra);
+    load_rows(ia, ra); load_idx(e0 + 48, ib);
+    mfmas(rb);
   }
+#pragma unroll
+  for (int t = 0; t < 16; ++t) acc[t] += acc2[t];
   dv += __shfl_xor(dv, 32, 64);
-  float* w = a.Wt + (size_t)u * 1024;
+  float* w = a.Wc + (size_t)u * tri_padded(a.K);
 #pragma unroll
   for (int t = 0; t < 16; ++t) {
     const int row = (t & 3) + 8 * (t >> 2) + 4 * half;             // C/D layout of the 32 x 32 tile: column on the lane
     float cf = (float)a.Cf64[(size_t)row * 32 + c];
     float m = acc[t];
     if (row == c) { if (a.cf_diag_extra) cf = (float)a.cf_diag_extra[c]; m += dv; }      // VB: C~f_kk = sum_i (E[F_ik]^2 + varF_ik) = the column sum of the second moments
-    w[row * 32 + c] = (row < a.K && c < a.K) ? cf - m : 0.f;
+    if (row <= c && c < a.K) w[tri_pos(tri_index(row, c, a.K))] = cf - m;    // the upper triangle, packed: what the S-system GEMM reads
   }
 }
 void launch_scol_gram(const SColGramArgs& a, hipStream_t st) {
-  if (a.n > 0) hipLaunchKernelGGL(scol_gram_kernel, dim3((a.n + 3) / 4), dim3(256), 0, st, a);
+  if (a.n <= 0) return;
+  if (a.varF) hipLaunchKernelGGL(scol_gram_kernel<1>, dim3((a.n + 3) / 4), dim3(256), 0, st, a);
+  else        hipLaunchKernelGGL(scol_gram_kernel<0>, dim3((a.n + 3) / 4), dim3(256), 0, st, a);
 }
 
-// pair number p = 0 .. K(K+1)/2 - 1 of (k, k'), k <= k', row by row
-__host__ __device__ inline void ssys_pair(int p, int K, int* k, int* kp) {
-  int kk = 0;
-  while (p >= K - kk) { p -= K - kk; ++kk; }
-  *k = kk; *kp = kk + p;
+// Gc[j][r(l, l')] = G_jl G_jl' (l <= l'), the packed second-moment matrix of column j's row of G.  Block = 16 columns.
+__global__ __launch_bounds__(256) void gamma_pack_kernel(GammaPackArgs a) {
+  __shared__ float g[16][32], v[16][32];
+  const int j0 = blockIdx.x * 16, PL = tri_count(a.L), PLp = tri_padded(a.L);
+  for (int e = threadIdx.x; e < 16 * 32; e += 256) {
+    const int j = j0 + (e >> 5);
+    g[e >> 5][e & 31] = j < a.n ? a.G[(size_t)(a.n0 + j) * 32 + (e & 31)] : 0.f;
+    v[e >> 5][e & 31] = (j < a.n && a.varG) ? a.varG[(size_t)(a.n0 + j) * 32 + (e & 31)] : 0.f;
+  }
+  __syncthreads();
+  for (int pos = threadIdx.x; pos < PLp; pos += 256) {             // by position in the row: contiguous stores
+    const int r = tri_unpos(pos);
+    if (r >= PL) continue;                                          // pads stay zero
+    int l, lp; tri_unindex(r, a.L, &l, &lp);
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+      if (j0 + t < a.n) a.Gc[(size_t)(j0 + t) * PLp + pos] = fmaf(g[t][l], g[t][lp], l == lp ? v[t][l] : 0.f);
+  }
+}
+void launch_gamma_pack(const GammaPackArgs& a, hipStream_t st) {
+  if (a.n > 0) hipLaunchKernelGGL(gamma_pack_kernel, dim3((a.n + 15) / 16), dim3(256), 0, st, a);
 }
 
-// A-slab[s][(k,l)][(k',l')] = sum_{j in range s} W~_j[k][k'] G_jl G_jl'  for the block pairs k <= k' (A is symmetric:
-// the lower blocks are mirrored by ssys_reduce_kernel).  One MFMA tile (rows l, columns l') is one K-pair (k, k'):
-// the A operand is W~_j[k][k'] G_jl (a broadcast scalar times the lane's G), the B operand G_jl'.  Four tiles per wave,
-// sixteen per block; grid (pair groups, column ranges).  (The [l = l'] varG_jl term of the variational version is not
-// an outer product: ssys_vardiag_kernel adds it.)
+// A on the packed pairs: slab[s][p][r] = sum_{j in range s} Wc[j][p] Gc[j][r], p = (k <= k'), r = (l <= l') -- with both
+// operands materialised the S system is a plain GEMM (M = N = K(K+1)/2 padded, reduction over the columns j), a quarter
+// of the K L x K L products by the two symmetries.  fp32 MFMA 32x32x2, a 2 x 2 block of tiles per wave: four loads for
+// four MFMAs, and nothing else in the loop -- on this chip a vector instruction between two MFMAs does not hide behind
+// them (tools/micro/mfma_rate.hip: +4 cycles each on the 64 of the MFMA), and the texture path takes ~9 cycles per
+// wave-level load whatever it fetches.  (The version that scaled G by W~_j[k][k'] on the fly ran at 2x its MFMA time.)
+// Base addresses advance in scalar registers; a range past its end reads the zero rows behind the arrays.
 __global__ __launch_bounds__(256) void ssys_gemm_kernel(SSysGemmArgs a) {
-  const int lane = threadIdx.x & 63, half = lane >> 5, c = lane & 31, wave = threadIdx.x >> 6;
-  const int P = a.K * (a.K + 1) / 2, p0 = (blockIdx.x * 4 + wave) * 4, sp = blockIdx.y;
+  const int lane = threadIdx.x & 63, half = lane >> 5, c = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int PKp = tri_padded(a.K), PLp = tri_padded(a.L), TR = PLp / 64;
+  const int wt = blockIdx.x * 4 + wave, sp = blockIdx.y;
+  if (wt >= (PKp / 64) * TR) return;
+  const int tp = wt / TR, tr = wt % TR;
   const int per = ((a.n + a.nsplit - 1) / a.nsplit + 1) & ~1;      // columns per range (even: two per MFMA step)
   const int jbeg = sp * per, jend = min(a.n, jbeg + per);
-  int wo[4];                                                        // offset of W~[k][k'] inside a column's 32 x 32 block (pairs past P: any valid one, not stored)
+  // operands through buffer descriptors: the lane's byte offset in a VGPR, the column's in an SGPR, the second tile in the
+  // instruction's immediate -- no vector address arithmetic at all
+    const int offA = 4 * (half * PKp + tp * 64 + 2 * c), offB = 4 * (half * PLp + tr * 64 + 2 * c);     // (tile 0, tile 1) of the lane's element: tri_pos
+  const __amdgpu_buffer_rsrc_t rsA = panel_rsrc(a.Wc, (size_t)(a.n + 2) * PKp * 4), rsB = panel_rsrc(a.Gc, (size_t)(a.n + 2) * PLp * 4);
+  f32x16 acc[2][2];
 #pragma unroll
-  for (int x = 0; x < 4; ++x) { int k, kp; ssys_pair(min(p0 + x, P - 1), a.K, &k, &kp); wo[x] = k * 32 + kp; }
-  f32x16 acc[4];
+  for (int x = 0; x < 2; ++x)
 #pragma unroll
-  for (int x = 0; x < 4; ++x)
+    for (int y = 0; y < 2; ++y)
 #pragma unroll
-    for (int t = 0; t < 16; ++t) acc[x][t] = 0.f;
-  constexpr int NS = 4;                                             // steps of two columns in flight
-  for (int j0 = jbeg; j0 < jend; j0 += 2 * NS) {
-    float w[NS][4], g[NS];
+      for (int t = 0; t < 16; ++t) acc[x][y][t] = 0.f;
+  constexpr int NS = 4;                                             // steps of two columns per batch; the next batch's operands load while this one's MFMAs run
+  struct Batch { float a0[NS], a1[NS], b0[NS], b1[NS]; };
+  auto fetch = [&](int j0, Batch& b) {
 #pragma unroll
     for (int t = 0; t < NS; ++t) {
-      const int j = j0 + 2 * t + half;
-      const bool on = j < jend;
-      const float* wj = a.Wt + (size_t)(on ? j : 0) * 1024;
-#pragma unroll
-      for (int x = 0; x < 4; ++x) w[t][x] = wj[wo[x]];
-      g[t] = on ? a.G[(size_t)(a.n0 + j) * 32 + c] : 0.f;
+      const int j = j0 + 2 * t < jend ? j0 + 2 * t : a.n;          // wave-uniform; rows n, n + 1 are zero
+      const int sa = j * PKp * 4, sb = j * PLp * 4;
+      const f32x2 av = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsA, offA, sa, 0));
+      const f32x2 bv = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsB, offB, sb, 0));
+      b.a0[t] = av.x; b.a1[t] = av.y; b.b0[t] = bv.x; b.b1[t] = bv.y;
     }
+  };
+  auto mfmas = [&](const Batch& b) {
 #pragma unroll
-    for (int t = 0; t < NS; ++t)
-#pragma unroll
-      for (int x = 0; x < 4; ++x) acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t][x] * g[t], g[t], acc[x], 0, 0, 0);
-  }
-  const int n2 = a.K * a.L;
-  float* slab = a.slabs + (size_t)sp * n2 * n2;
-#pragma unroll
-  for (int x = 0; x < 4; ++x) {
-    if (p0 + x >= P) continue;
-    int k, kp; ssys_pair(p0 + x, a.K, &k, &kp);
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int l = (t & 3) + 8 * (t >> 2) + 4 * half;              // l = tile row, l' = tile column = c
-      if (l < a.L && c < a.L) slab[(size_t)(k * a.L + l) * n2 + kp * a.L + c] = acc[x][t];
+    for (int t = 0; t < NS; ++t) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.a0[t], b.b0[t], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.a0[t], b.b1[t], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.a1[t], b.b0[t], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.a1[t], b.b1[t], acc[1][1], 0, 0, 0);
     }
+  };
+  Batch b0, b1;
+  fetch(jbeg, b0);
+  for (int j0 = jbeg; j0 < jend; j0 += 4 * NS) {                    // two batches per trip: the register sets alternate without copies
+    fetch(j0 + 2 * NS, b1);                                         // (a batch past the range multiplies zeros: no branch around MFMAs,
+    mfmas(b0);                                                      //  or the accumulators get copied between register files every trip)
+    fetch(j0 + 4 * NS, b0);
+    mfmas(b1);
   }
+  float* slab = a.slabs + (size_t)sp * PKp * PLp;
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int row = tp * 64 + 32 * x + (t & 3) + 8 * (t >> 2) + 4 * half;
+        slab[(size_t)row * PLp + tr * 64 + 32 * y + c] = acc[x][y][t];
+      }
 }
 void launch_ssys_gemm(const SSysGemmArgs& a, hipStream_t st) {
-  const int P = a.K * (a.K + 1) / 2;
-  hipLaunchKernelGGL(ssys_gemm_kernel, dim3((P + 15) / 16, a.nsplit), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(ssys_gemm_kernel, dim3((ssys_gemm_wave_tiles(a.K, a.L) + 3) / 4, a.nsplit), dim3(256), 0, st, a);
 }
 
-// A = sum of the column-range slabs (in range order) on the block pairs k <= k', mirrored into k > k': one block per pair
-__global__ __launch_bounds__(1024) void ssys_reduce_kernel(const float* slabs, int nsplit, int K, int L, float* A) {
-  __shared__ float tile[32][33];
-  int k, kp; ssys_pair(blockIdx.x, K, &k, &kp);
-  const int l = threadIdx.x >> 5, lp = threadIdx.x & 31, n2 = K * L;
-  float v = 0.f;
-  if (l < L && lp < L) {
-    const size_t e = (size_t)(k * L + l) * n2 + kp * L + lp;
-    for (int t = 0; t < nsplit; ++t) v += slabs[(size_t)t * n2 * n2 + e];
-    A[e] = v;
+// A[(k,l)][(k',l')] = sum of the column-range slabs (in range order) at (p(k,k'), r(l,l')).  One block per packed pair p:
+// its row of the slabs is summed 16 bytes per thread, the two halves of the ranges by two threads (combined in a fixed
+// order), goes through LDS and comes out as the full L x L blocks (k,k') and (k',k), rows contiguous.
+__global__ __launch_bounds__(320) void ssys_reduce_kernel(const float* slabs, int nsplit, int K, int L, float* A) {
+  __shared__ __align__(16) float v[2][640];
+  int k, kp; tri_unindex(blockIdx.x, K, &k, &kp);
+  const int PLp = tri_padded(L), n2 = K * L, nq = PLp / 4;         // nq <= 144 float4 per row
+  const size_t slab = (size_t)tri_padded(K) * PLp;
+  const int q = threadIdx.x % 160, hs = threadIdx.x / 160;         // 2 x 160 threads
+  if (q < nq) {
+    const int t0 = hs ? (nsplit + 1) / 2 : 0, t1 = hs ? nsplit : (nsplit + 1) / 2;
+    const float4* sp = reinterpret_cast<const float4*>(slabs + (size_t)blockIdx.x * PLp) + q;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = t0; t < t1; ++t) { const float4 x = sp[(size_t)t * (slab / 4)]; s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w; }
+    *reinterpret_cast<float4*>(&v[hs][4 * q]) = s;
   }
-  tile[l][lp] = v;
   __syncthreads();
-  if (k != kp && l < L && lp < L) A[(size_t)(kp * L + l) * n2 + k * L + lp] = tile[lp][l];
+  for (int e = threadIdx.x; e < L * L; e += 320) {
+    const int l = e / L, lp = e % L, pos = tri_index(min(l, lp), max(l, lp), L);      // (the slabs are indexed by the packed pair itself; only the GEMM's operands are tile-interleaved)
+    const float x = v[0][pos] + v[1][pos];
+    A[(size_t)(k * L + l) * n2 + kp * L + lp] = x;
+    if (k != kp) A[(size_t)(kp * L + l) * n2 + k * L + lp] = x;
+  }
 }
 void launch_ssys_reduce(const float* slabs, int nsplit, int K, int L, float* A, hipStream_t st) {
-  hipLaunchKernelGGL(ssys_reduce_kernel, dim3(K * (K + 1) / 2), dim3(1024), 0, st, slabs, nsplit, K, L, A);
+  hipLaunchKernelGGL(ssys_reduce_kernel, dim3(tri_count(K)), dim3(320), 0, st, slabs, nsplit, K, L, A);
 }
 
 // b[k][l] = sum_j Pv_jk G_jl over the local columns (Pv = the contraction's partial slabs, summed in slab order).

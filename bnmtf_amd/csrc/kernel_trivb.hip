@@ -70,49 +70,6 @@ void launch_masked_colsum(const MaskedColsumArgs& a, hipStream_t st) {
   if (a.n > 0) hipLaunchKernelGGL(masked_colsum_kernel, dim3((a.n + 3) / 4), dim3(256), 0, st, a);
 }
 
-// The [l = l'] part of the second-moment S system:  Vd-slab[s][k][k'][l] = sum_{j in range s} W~_j[k][k'] varG_jl.
-// One MFMA tile per k (rows k', columns l): A operand W~_j[k][lane], B operand varG_j[lane]; grid (K, column ranges).
-__global__ __launch_bounds__(64) void ssys_vardiag_kernel(SSysGemmArgs a, float* vd_slabs) {
-  const int lane = threadIdx.x & 63, half = lane >> 5, c = lane & 31;
-  const int k = blockIdx.x, sp = blockIdx.y;
-  const int per = ((a.n + a.nsplit - 1) / a.nsplit + 1) & ~1;
-  const int jbeg = sp * per, jend = min(a.n, jbeg + per);
-  f32x16 acc;
-#pragma unroll
-  for (int t = 0; t < 16; ++t) acc[t] = 0.f;
-  for (int j0 = jbeg; j0 < jend; j0 += 8) {
-    float w[4], g[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int j = j0 + 2 * t + half;
-      const bool on = j < jend;
-      w[t] = on ? a.Wt[(size_t)j * 1024 + k * 32 + c] : 0.f;
-      g[t] = on ? a.varG[(size_t)(a.n0 + j) * 32 + c] : 0.f;
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t], g[t], acc, 0, 0, 0);
-  }
-  float* out = vd_slabs + ((size_t)sp * a.K + k) * 1024;
-#pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    const int kp = (t & 3) + 8 * (t >> 2) + 4 * half;
-    out[kp * 32 + c] = acc[t];
-  }
-}
-// A[(k,l)][(k',l)] += sum_s Vd-slab[s][k][k'][l]
-__global__ void ssys_vardiag_add_kernel(const float* vd_slabs, int nsplit, int K, int L, float* A) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= K * K * L) return;
-  const int l = t % L, kp = (t / L) % K, k = t / (L * K);
-  float s = 0.f;
-  for (int sp = 0; sp < nsplit; ++sp) s += vd_slabs[((size_t)sp * K + k) * 1024 + kp * 32 + l];
-  A[(size_t)(k * L + l) * (K * L) + kp * L + l] += s;
-}
-void launch_ssys_vardiag(const SSysGemmArgs& a, float* vd_slabs, float* A, hipStream_t st) {
-  hipLaunchKernelGGL(ssys_vardiag_kernel, dim3(a.K, a.nsplit), dim3(64), 0, st, a, vd_slabs);
-  const int n = a.K * a.K * a.L;
-  hipLaunchKernelGGL(ssys_vardiag_add_kernel, dim3((n + 255) / 256), dim3(256), 0, st, vd_slabs, a.nsplit, a.K, a.L, A);
-}
 
 // update_S(k,l) + update_exp_S(k,l) for the entries order[0 .. n_order) in that order (bnmtf_vb_optimised.py:172-176):
 // one block, thread t owns entry t of the residual r = b - A~ E[S]; the owner of a step forms tauS = exptau A~_aa,

@@ -207,6 +207,20 @@ void launch_srow_draw(const SDrawArgs& a, hipStream_t st);
 // ---------------------------------------------------------------------------
 // BNMTF S step as a dense K.L x K.L system (kernel_ssys.hip); K, L <= 32
 // ---------------------------------------------------------------------------
+// packed upper triangle of a symmetric index pair (k <= k' < K): p = k K - k (k - 1) / 2 + (k' - k); rows of the packed
+// arrays are padded to a multiple of 64 (the GEMM's 2 x 2 MFMA tiles) with zeros
+__host__ __device__ inline int tri_count(int K) { return K * (K + 1) / 2; }
+__host__ __device__ inline int tri_padded(int K) { return (tri_count(K) + 63) / 64 * 64; }
+__host__ __device__ inline int tri_index(int k, int kp, int K) { return k * K - k * (k - 1) / 2 + (kp - k); }
+// where packed entry p sits in its row: the two 32-entry tiles of a 64-group are interleaved word by word, so that one
+// 8-byte load gives a lane its element of both tiles
+__host__ __device__ inline int tri_pos(int p) { return (p & ~63) + 2 * (p & 31) + ((p >> 5) & 1); }
+__host__ __device__ inline int tri_unpos(int pos) { return (pos & ~63) + 32 * (pos & 1) + ((pos & 63) >> 1); }   // inverse of tri_pos
+__host__ __device__ inline void tri_unindex(int p, int K, int* k, int* kp) {
+  int kk = 0;
+  while (p >= K - kk) { p -= K - kk; ++kk; }
+  *k = kk; *kp = kk + p;
+}
 struct SColGramArgs {       // W~_j = C~f - sum_{i in miss(j)} (F_i F_i^T + diag varF_i) for the local columns
   int n, K;
   const float* F;                      // [I+][32] row major, padding slots of idx point at a zero row
@@ -214,14 +228,21 @@ struct SColGramArgs {       // W~_j = C~f - sum_{i in miss(j)} (F_i F_i^T + diag
   const double* Cf64;                  // F^T F [32][32]
   const double* cf_diag_extra;         // VB: sum_i (E[F_ik]^2 + varF_ik) [32] (replaces the diagonal of Cf64), or null
   const uint32_t* slot_ptr; const uint32_t* idx;   // 64-wide slots of the cols direction
-  float* Wt;                           // [n][32*32]
+  float* Wc;                           // [n + 2][tri_padded(K)]: the packed upper triangle of W~_j (pads and the two extra rows stay zero)
 };
 void launch_scol_gram(const SColGramArgs& a, hipStream_t st);
-struct SSysGemmArgs {       // slabs[s][(k,l)][(k',l')] = sum_{j in range s} W~_j[k][k'] G_jl G_jl' on the block pairs k <= k'
-  int n, n0, K, L, nsplit;
-  const float* Wt; const float* G; const float* varG;   // G, varG [J][32] (global rows n0 + j)
-  float* slabs;                        // [nsplit][K L][K L]
+struct GammaPackArgs {      // Gc[j][r(l, l')] = G_jl G_jl' (+ varG_jl when l = l': the second moment, VB) for the local columns
+  int n, n0, L;
+  const float* G; const float* varG;   // [J][32] (global rows n0 + j); varG null for Gibbs
+  float* Gc;                           // [n + 2][tri_padded(L)]
 };
+void launch_gamma_pack(const GammaPackArgs& a, hipStream_t st);
+struct SSysGemmArgs {       // slabs[s][p][r] = sum_{j in range s} Wc[j][p] Gc[j][r]: A on the packed pairs p = (k <= k'), r = (l <= l')
+  int n, K, L, nsplit;
+  const float* Wc; const float* Gc;
+  float* slabs;                        // [nsplit][tri_padded(K)][tri_padded(L)]
+};
+inline int ssys_gemm_wave_tiles(int K, int L) { return (tri_padded(K) / 64) * (tri_padded(L) / 64); }
 void launch_ssys_gemm(const SSysGemmArgs& a, hipStream_t st);
 struct SSysBArgs { int n, n0, K, L; const float* slabs; int split, n_pad; const float* G; float* b; };   // b[block][K L]: per 64-column block partials of sum_j Pv_jk G_jl
 inline int ssys_b_blocks(int n) { return (n + 63) / 64 > 0 ? (n + 63) / 64 : 1; }
@@ -238,6 +259,7 @@ struct SSysChainArgs {
 };
 void launch_ssys_chain(const SSysChainArgs& a, hipStream_t st);
 
+
 // ---------------------------------------------------------------------------
 // variational tri-factorisation (kernel_trivb.hip); K, L <= 32
 // ---------------------------------------------------------------------------
@@ -249,7 +271,6 @@ struct MaskedColsumArgs {    // out[u][c] = sum over the unit's observed inner i
   int n; const uint32_t* slot_ptr; const uint32_t* idx; const float* V; const double* colsum2; const double* C64; float* out;
 };
 void launch_masked_colsum(const MaskedColsumArgs& a, hipStream_t st);
-void launch_ssys_vardiag(const SSysGemmArgs& a, float* vd_slabs, float* A, hipStream_t st);   // A[(k,l)][(k',l)] += sum_j W~_j[k][k'] varG_jl
 struct SSysChainVbArgs {
   int K, L, n_order, only_params;
   const int* order;                    // entries a = k L + l in update order

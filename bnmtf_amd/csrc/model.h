@@ -105,7 +105,7 @@ struct bnmtf_model {
   int s_blocks = 0;
   // dense S system (kernel_ssys.hip), K, L <= 32
   bool ssys = false; int ss_nsplit = 1;
-  float *ss_Wt = nullptr, *ss_slabs = nullptr, *ss_AB = nullptr, *ss_r = nullptr, *ss_bpart = nullptr;   // AB = [A (n2 x n2) | b (n2)]: one buffer, one all-reduce
+  float *ss_Wt = nullptr, *ss_Gc = nullptr, *ss_slabs = nullptr, *ss_AB = nullptr, *ss_r = nullptr, *ss_bpart = nullptr;   // AB = [A (n2 x n2) | b (n2)]: one buffer, one all-reduce
   // posterior means accumulated on the device (bnmtf_set_expectation): sums over the iterations burn_in, burn_in + thinning, ...
   int exp_burn = -1, exp_thin = 1; uint64_t exp_count = 0;
   double *exp_rows = nullptr, *exp_cols = nullptr, *exp_S = nullptr, *exp_tau = nullptr;
@@ -113,7 +113,6 @@ struct bnmtf_model {
   bool tri_ready = false;
   float *muS = nullptr, *tauS = nullptr, *varS = nullptr;   // q(S) beside expS = S   [K][L]
   float *mv_rows = nullptr, *mv_cols = nullptr;             // masked variance sums mvG [I_loc][32], mvF [J_loc][32]
-  float* ss_vd = nullptr;                                    // [nsplit][K][32*32] slabs of the [l = l'] part of the S system
   int* tri_order = nullptr; size_t tri_order_cap = 0;        // per iteration: K L entries of S, K columns of F, L columns of G
   double* tri_sums = nullptr;                                // 3 x 8 masked sums (metric_kernel passes)
   // profiling
