@@ -62,6 +62,24 @@ def test_sharded_run_equals_single_rank_run(I, J, K, world):
         assert np.abs(ranks[0][0][-1] - sU[-1]).max() <= 1e-4 * np.abs(sU[-1]).max()
 
 
+def test_sharded_chain_is_the_same_every_time():
+    """Three ranks share the one GPU, so every kernel runs beside two others and its LDS-DMA pieces take longer than
+    usual: a barrier that published a staged panel without waiting for the issuing wave's vector-memory counter showed
+    up here as a chain that left the single-rank one in 4 runs of 12 (fixed: sync_with_dma, sweep_common.h).  Mode
+    updates: nothing random, every run must give the same bits."""
+    I, J, K, world = 515, 389, 40, 3
+    R, M, _, _ = generate_bnmf(I, J, K, 0.12, seed_data=5, seed_mask=6)
+    rs = np.random.RandomState(3)
+    U0 = rs.exponential(1.0, (I, K)); V0 = rs.exponential(1.0, (J, K)); tau0 = 0.7
+    ref = None
+    for n in range(8):
+        ranks = _run_ranks(R, M, K, U0, V0, tau0, world, 5, "mode", ("rep%d" % n).encode())
+        if ref is None:
+            ref = ranks[0]
+        for a, b in zip(ref, ranks[0]):
+            assert np.array_equal(a, b), "run %d differs from run 0" % n
+
+
 def _threads(world, work):
     out, err = [None] * world, [None] * world
 
