@@ -265,17 +265,26 @@ void launch_ssys_sum_parts(const float* slabs, int nsplit, size_t n, float* A, h
 }
 
 // r = b - A S (fp64 accumulation: b and A S nearly cancel at convergence), one wave per row
-__global__ __launch_bounds__(256) void ssys_residual_kernel(const float* A, const float* b, const float* S, int n2, float* r) {
+// r = b - A S (fp64 dots), one wave per row.  Lanes 0-3 of the wave also make the first four sampler candidates of the
+// row's entry for the coming chain (random words only: they depend on (entry, iteration, key), not on A) -- a Philox call
+// each, hidden behind the dot product instead of standing at the head of the one-block chain kernel.
+__global__ __launch_bounds__(256) void ssys_residual_kernel(const float* A, const float* b, const float* S, int n2, float* r,
+                                                            float4* cands, uint32_t it, uint32_t key0, uint32_t key1) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n2) return;
+  if (cands && lane < 4) {
+    const U4 rr = philox4x32_10(0u, (uint32_t)row, it, kStreamS + 16u * (uint32_t)lane, key0, key1);
+    const TnCand cd = tn_cand_pre(rr.x, rr.y);
+    cands[row * 4 + lane] = make_float4(cd.nl, cd.z, cd.u2, 0.f);
+  }
   double s = 0.0;
   for (int t = lane; t < n2; t += 64) s = fma((double)A[(size_t)row * n2 + t], (double)S[t], s);
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
   if (lane == 0) r[row] = (float)((double)b[row] - s);
 }
-void launch_ssys_residual(const float* A, const float* b, const float* S, int n2, float* r, hipStream_t st) {
-  hipLaunchKernelGGL(ssys_residual_kernel, dim3((n2 + 3) / 4), dim3(256), 0, st, A, b, S, n2, r);
+void launch_ssys_residual(const float* A, const float* b, const float* S, int n2, float* r, hipStream_t st, float* cands, uint32_t it, uint32_t key0, uint32_t key1) {
+  hipLaunchKernelGGL(ssys_residual_kernel, dim3((n2 + 3) / 4), dim3(256), 0, st, A, b, S, n2, r, reinterpret_cast<float4*>(cands), it, key0, key1);
 }
 
 // The K.L sequential conditionals, row-major (k, l) (bnmtf_gibbs_optimised.py:157-160), one block of 8 waves.
@@ -390,11 +399,11 @@ __global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
     if (UPDATE == 0) {
       const TnPre pre = tn_fast_pre(tau * a.A[(size_t)e * n2 + e]);
       const float thr = pre.live ? -kTnA0 * pre.tpirt : __builtin_inff();    // a dead entry always leaves through the slow branch
+#pragma unroll
       for (int c = 0; c < NH; ++c) {
-        const U4 rr = philox4x32_10(0u, (uint32_t)e, a.it, kStreamS + 16u * (uint32_t)c, a.key0, a.key1);
-        const TnCand cd = tn_cand_pre(rr.x, rr.y);
-        recA[e * NH + c] = make_float4(cd.z * pre.irt, pre.rcp, thr, pre.irt);
-        recB[e * NH + c] = make_float2(cd.nl, cd.u2);
+        const float4 cd = a.cands[e * NH + c];                      // {-log u1, z, u2, -}: made by ssys_residual_kernel, off this kernel's critical path
+        recA[e * NH + c] = make_float4(cd.y * pre.irt, pre.rcp, thr, pre.irt);
+        recB[e * NH + c] = make_float2(cd.x, cd.z);
       }
     }
   }
@@ -437,14 +446,15 @@ __global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
 #pragma unroll
       for (int q = 0; q < 3; ++q) { rowq[q] = omp[q * 33]; raq[q] = pa[q * NH]; rbq[q] = pb[q * NH]; }
       float* snp = snl;                                             // the row's new values, by entry (every lane writes the same word)
+      const int cmask = lane < NH ? 0x1C0 : 0;                      // +0, +denormal, +normal
       auto step = [&](int l, int q, float row, float4 ra, float2 rb) {
         const float numer = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, numer_v), l));
         float snew;
         if (UPDATE == 0) {
           float xc = fmaf(numer, ra.y, ra.x);                       // normal regime, live entry: accepted iff x is +0, +denormal or +normal
           unsigned long long mc;
-          asm("v_cmp_class_f32 %0, %1, %2" : "=s"(mc) : "v"(xc), "s"(0x1C0));
-          unsigned long long m = (mc & ~__builtin_amdgcn_ballot_w64(numer <= ra.z)) & ((1ull << NH) - 1ull);
+          asm("v_cmp_class_f32 %0, %1, %2" : "=s"(mc) : "v"(xc), "v"(cmask));   // cmask: the class bits in the candidate lanes, 0 (never) in the others
+          unsigned long long m = mc & ~__builtin_amdgcn_ballot_w64(numer <= ra.z);
           if (__builtin_expect(m == 0ull, 0)) {
 #ifdef CHAIN_CLOCK
             ++n_slow; const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
@@ -504,7 +514,7 @@ __global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
 #endif
       const float my_s = snl[l32];
       const float my_delta = on ? my_s - my_sold : 0.f;
-      if (on) { a.S[k * L + lane] = my_s; delta[cur][lane] = my_delta; }
+      if (on) { Sl[k * L + lane] = my_s; delta[cur][lane] = my_delta; }
       }
       __syncthreads();
 #ifdef CHAIN_CLOCK
@@ -567,6 +577,7 @@ __global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
       __syncthreads();
     }
   }
+  for (int e = tid; e < n2; e += NT) a.S[e] = Sl[e];               // the walked rows, after the last barrier
 #ifdef CHAIN_CLOCK
   if (tid == 0 && (a.it == 30u || a.it == 31u)) printf("chain it %u: prologue %llu, row-pro %llu, steps %llu, barrier %llu cycles; slow %d taking %llu\n", a.it, c_begin - c_k0, c_pro, c_steps, c_wait, n_slow, c_slow);
 #endif

@@ -249,12 +249,14 @@ inline int ssys_b_blocks(int n) { return (n + 63) / 64 > 0 ? (n + 63) / 64 : 1; 
 void launch_ssys_b(const SSysBArgs& a, hipStream_t st);
 void launch_ssys_reduce(const float* slabs, int nsplit, int K, int L, float* A, hipStream_t st);   // sum the slabs on k <= k', mirror
 void launch_ssys_sum_parts(const float* parts, int nparts, size_t n, float* out, hipStream_t st);
-void launch_ssys_residual(const float* A, const float* b, const float* S, int n2, float* r, hipStream_t st);
+void launch_ssys_residual(const float* A, const float* b, const float* S, int n2, float* r, hipStream_t st,
+                          float* cands = nullptr, uint32_t it = 0, uint32_t key0 = 0, uint32_t key1 = 0);   // cands [n2][4][4]: the chain's first candidates (draws)
 struct SSysChainArgs {
   int K, L, update, cond;              // update: 0 draw, else mode (clamped from below by min_x); cond >= 0: evaluate entry cond only
   float min_x;
   const float* A; const float* r0; float* S; const float* lambdaS; const float* tau;
   uint32_t key0, key1, it;
+  const float4* cands;                 // [K L][4] {-log u1, z, u2, -} of iteration `it` (ssys_residual_kernel); draws only
   double* numer_out; double* tau_out;
 };
 void launch_ssys_chain(const SSysChainArgs& a, hipStream_t st);

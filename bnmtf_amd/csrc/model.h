@@ -105,7 +105,7 @@ struct bnmtf_model {
   int s_blocks = 0;
   // dense S system (kernel_ssys.hip), K, L <= 32
   bool ssys = false; int ss_nsplit = 1;
-  float *ss_Wt = nullptr, *ss_Gc = nullptr, *ss_slabs = nullptr, *ss_AB = nullptr, *ss_r = nullptr, *ss_bpart = nullptr;   // AB = [A (n2 x n2) | b (n2)]: one buffer, one all-reduce
+  float *ss_Wt = nullptr, *ss_Gc = nullptr, *ss_slabs = nullptr, *ss_AB = nullptr, *ss_r = nullptr, *ss_bpart = nullptr, *ss_cands = nullptr;   // AB = [A (n2 x n2) | b (n2)]: one buffer, one all-reduce
   // posterior means accumulated on the device (bnmtf_set_expectation): sums over the iterations burn_in, burn_in + thinning, ...
   int exp_burn = -1, exp_thin = 1; uint64_t exp_count = 0;
   double *exp_rows = nullptr, *exp_cols = nullptr, *exp_S = nullptr, *exp_tau = nullptr;
