@@ -23,6 +23,9 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
   const int KP = a.KP, tid = threadIdx.x;
   const int r0 = blockIdx.x * RB;
   const int nr = min(RB, a.rows - r0);
+  // two blocks per row group (blockIdx.y): one writes the layouts, the other forms the Gram partial and the column sums.
+  // Each is half as long, and twice as many blocks hide each other's load -> store / load -> FMA latencies.
+  const bool do_layout = blockIdx.y == 0, do_gram = blockIdx.y == 1;
   const float* src = a.X;
   for (int pass = 0; pass < (a.S2 ? 2 : 1); ++pass) {
     float* tile = pass == 0 ? tile0 : tile1;
@@ -33,17 +36,17 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
     }
     __syncthreads();
     float* T1 = pass == 0 ? a.XT : a.S2T;
-    if (T1)
+    if (T1 && do_layout)
       for (int t = tid; t < RB * KP; t += 256) {
         const int k = t / RB, r = t % RB;
         if (r < nr) T1[(size_t)k * a.ldT + r0 + r] = tile[r * LD + k];
       }
-    if (pass == 0 && a.XT2)
+    if (pass == 0 && a.XT2 && do_layout)
       for (int t = tid; t < RB * KP; t += 256) {
         const int kp = t / (2 * RB), rem = t % (2 * RB), r = rem >> 1, c = rem & 1;
         if (r < nr) a.XT2[((size_t)kp * a.ld2 + r0 + r) * 2 + c] = tile[r * LD + 2 * kp + c];
       }
-    if (pass == 0) {
+    if (pass == 0 && do_gram) {
       // Gram partial of this block's rows: C is symmetric, so only the 4x4 tiles on and above the diagonal are formed
       // (NT (NT + 1) / 2 of NT^2, NT = KP / 4), one per thread, and stored packed -- 16 contiguous doubles per tile
       const int NT = KP / 4, NU = NT * (NT + 1) / 2;
@@ -71,12 +74,12 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
           for (int j = 0; j < 4; ++j) out[i * 4 + j] = acc[i][j];
       }
     }
-    if (tid < KP) {
+    if (tid < KP && do_gram) {
       double s = 0.0;
       for (int r = 0; r < nr; ++r) s += (double)tile[r * LD + tid];
       (pass == 0 ? a.spart : a.s2part)[(size_t)blockIdx.x * KP + tid] = s;
     }
-    if (pass == 1 && a.XS)        // VB: the (E, S2) pair panels of the fast VB sweep, [KP][ldT][2]
+    if (pass == 1 && a.XS && do_layout)        // VB: the (E, S2) pair panels of the fast VB sweep, [KP][ldT][2]
       for (int t = tid; t < RB * KP; t += 256) {
         const int k = t / RB, r = t % RB;
         if (r < nr) *reinterpret_cast<float2*>(a.XS + ((size_t)k * a.ldT + r0 + r) * 2) = float2{tile0[r * LD + k], tile1[r * LD + k]};
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(1024) void gram_reduce_kernel(PostArgs a, int nblk)
 
 void launch_post(const PostArgs& a, hipStream_t st) {
   const int nblk = post_blocks(a.rows);
-  hipLaunchKernelGGL(post_kernel, dim3(nblk), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(post_kernel, dim3(nblk, 2), dim3(256), 0, st, a);
   const int nt = a.KP / 4, ps = nt * (nt + 1) / 2 * 16;
   hipLaunchKernelGGL(gram_reduce_kernel, dim3((ps + 31) / 32 + 1), dim3(1024), 0, st, a, nblk);
 }
