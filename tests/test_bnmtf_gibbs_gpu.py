@@ -135,6 +135,31 @@ def test_factors_wider_than_32_take_the_64_wide_paths(K, L):
     assert np.isfinite(b.S).all() and b.S.min() >= 0 and b.S.shape == (K, L)
 
 
+@pytest.mark.parametrize("I,J,K,L", [(150, 130, 32, 32), (120, 90, 32, 17), (90, 140, 9, 32)])
+def test_full_width_S_system_follows_the_oracle(I, J, K, L):
+    """K and / or L = 32: the packed (k <= k') x (l <= l') GEMM runs with full 64-wide tile groups and partly filled ones
+    (528, 153 and 45 pairs), the chain walks 32-entry rows.  Mode updates: every step deterministic, compared with the
+    oracle's sequential conditionals (bnmtf_gibbs_optimised.py:157-160)."""
+    rs = np.random.RandomState(5)
+    F0 = rs.exponential(1.0, (I, K)); S0 = rs.exponential(1.0, (K, L)) / np.sqrt(K * L / 25.0); G0 = rs.exponential(1.0, (J, L))
+    R = F0 @ S0 @ G0.T + rs.randn(I, J)
+    M = (rs.rand(I, J) > 0.15).astype(float)
+    M[rs.randint(I, size=J), np.arange(J)] = 1; M[np.arange(I), rs.randint(J, size=I)] = 1
+    pri = dict(alpha=1., beta=1., lambdaF=0.3, lambdaS=0.2, lambdaG=0.1)
+    Fi, Si, Gi = rs.exponential(1.0, (I, K)), rs.exponential(0.2, (K, L)), rs.exponential(1.0, (J, L))
+    o = O.BNMTFGibbsOracle(R, M, K, L, pri)
+    o.F, o.S, o.G, o.tau = Fi.copy(), Si.copy(), Gi.copy(), 0.5
+    o.run(3, draw=False)
+    b = bnmtf_gibbs_optimised(R, M, K, L, pri, verbose=False, seed=4)
+    b.F, b.S, b.G, b.tau = Fi.copy(), Si.copy(), Gi.copy(), 0.5
+    b.run(3, update='mode')
+    np.testing.assert_allclose(b.all_performances['MSE'], o.all_performances['MSE'], rtol=1e-3)
+    np.testing.assert_allclose(b.all_tau, o.all_tau, rtol=1e-3)
+    for name in ("all_F", "all_S", "all_G"):
+        x, y = np.asarray(getattr(b, name)[0]), np.asarray(getattr(o, name)[0])
+        assert np.abs(x - y).max() < 1e-3 * max(1.0, np.abs(y).max()), name
+
+
 def test_device_kmeans_equals_host_kmeans():
     """bnmtf_amd.kmeans.KMeans with the assignment / sums passes on the GPU against the NumPy path (code/models/kmeans/
     kmeans.py semantics: MSE over shared observed coordinates, ties to the lowest index, 'singleton' refill of an empty
