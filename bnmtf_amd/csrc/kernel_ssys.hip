@@ -337,12 +337,13 @@ __global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
   // ---- background register pipeline: issued in one row, consumed in the next.  Eight waves (256 VGPRs each: the
   // pipeline is held in registers); wave 4 shares wave 0's SIMD (waves of a workgroup go round the four SIMDs) and
   // stays idle -- whatever it issued would take issue slots from the chain.  That leaves 6 waves, 384 threads.
-  constexpr int NT = 512, NB = 384, QB = 3, QF = 5;                // block elements / fold items per thread: L.L <= QB NB, 2 (n2 - 2 L) <= QF NB
+  constexpr int NT = 512, NB = 384, QB = 3, QF = 5, kOwnWave = 7;   // kOwnWave: the background wave that also makes the own-row term (the last one: its fold items run out first)                // block elements / fold items per thread: L.L <= QB NB, 2 (n2 - 2 L) <= QF NB
   const bool bg = (wave & 3) != 0;
   const int bt = (wave - 1 - (wave >> 2)) * 64 + lane;
   float sm[QB], sd[QB], own[16];            // blocks of the row after next; its own-row operands (wave 1: 16 per half)
   float4 fold[QF][4];                                                // A[(k, h + 8 j)][4 columns]: the rows that fold row k's deltas, QF items a thread
   const bool vec = (L & 3) == 0;
+  const __amdgpu_buffer_rsrc_t rsAm = panel_rsrc(a.A, (size_t)n2 * n2 * 4);
   auto issue_blocks = [&](int kk) {                                // diagonal block of row kk and block (kk, kk+1) -> registers
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
@@ -353,10 +354,10 @@ __global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
         if (kk + 1 < K) sd[q] = a.A[(size_t)(kk * L + l1) * n2 + (kk + 1) * L + l2];
       }
     }
-    if (wave == 1) {
-      const int lp = lane & 31, lb = lane & 32 ? 16 : 0;
+    if (wave == kOwnWave) {                                         // rows kk L + lb + 0..15 of the diagonal block, column lp: lane part in a VGPR, row part in SGPRs,
+      const int voff = 4 * ((lane & 32 ? 16 : 0) * n2 + (lane & 31));   // nothing predicated (past the matrix the descriptor returns 0; l > lp is masked when it is used)
 #pragma unroll
-      for (int l = 0; l < 16; ++l) own[l] = (lb + l <= lp && lp < L) ? a.A[(size_t)(kk * L + lb + l) * n2 + kk * L + lp] : 0.f;
+      for (int l = 0; l < 16; ++l) own[l] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsAm, voff, 4 * ((kk * L + l) * n2 + kk * L), 0));
     }
   };
   auto store_blocks = [&](int kk) {
@@ -369,11 +370,11 @@ __global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
         if (kk + 1 < K) Od[kk % 3][l1 * 33 + l2] = sd[q];
       }
     }
-    if (wave == 1) {                                                // sum_{l <= lp} S_(kk,l) A[(kk,l)][(kk,lp)], row kk not walked yet
-      const int lb = lane & 32 ? 16 : 0;
+    if (wave == kOwnWave) {                                         // sum_{l <= lp} S_(kk,l) A[(kk,l)][(kk,lp)], row kk not walked yet
+      const int lb = lane & 32 ? 16 : 0, lp = lane & 31;
       float s = 0.f;
 #pragma unroll
-      for (int l = 0; l < 16; ++l) s = fmaf(Sl[kk * L + (lb + l < L ? lb + l : 0)], own[l], s);
+      for (int l = 0; l < 16; ++l) s = fmaf(lb + l <= lp ? Sl[kk * L + lb + l] : 0.f, own[l], s);   // (lp < L for every lane that is kept: lb + l stays inside the row)
       s += __shfl_xor(s, 32, 64);
       if (lane < 32) Tn[kk & 1][lane] = lane < L ? s : 0.f;
     }
@@ -522,6 +523,9 @@ __global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
 #endif
     }
   } else {
+#ifdef CHAIN_CLOCK
+    unsigned long long b_work = 0, b_wait = 0, b_t0 = __builtin_amdgcn_s_memtime(), b_cons = 0;
+#endif
     for (int k = 0; k < K; ++k) {
       const int cur = k & 1;
       if (bg) {
@@ -571,11 +575,25 @@ __global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
           }
         }
       }
+#ifdef CHAIN_CLOCK
+      { const unsigned long long tt = __builtin_amdgcn_s_memtime(); b_cons += tt - b_t0; }
+#endif
       // ---- issue for the next row
       if (k + 2 < K) { issue_blocks(k + 2); issue_fold(k); }
       }
-      __syncthreads();
+#ifdef CHAIN_CLOCK
+      { const unsigned long long tt = __builtin_amdgcn_s_memtime(); b_work += tt - b_t0; b_t0 = tt; }
+#endif
+      // LDS traffic only: the loads just issued stay in flight across the barrier (they are consumed in the next row;
+      // __syncthreads() would wait for them here, a memory latency per row in front of the chain)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef CHAIN_CLOCK
+      { const unsigned long long tt = __builtin_amdgcn_s_memtime(); b_wait += tt - b_t0; b_t0 = tt; }
+#endif
     }
+#ifdef CHAIN_CLOCK
+    if ((tid == 64 || tid == 7 * 64) && a.it == 30u) printf("bg wave %d: work %llu (consume %llu) wait %llu\n", wave, b_work, b_cons, b_wait);
+#endif
   }
   for (int e = tid; e < n2; e += NT) a.S[e] = Sl[e];               // the walked rows, after the last barrier
 #ifdef CHAIN_CLOCK
