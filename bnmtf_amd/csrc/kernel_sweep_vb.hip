@@ -173,14 +173,20 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
   // ------------------------------------------------------------ the K sequential columns, panels of (E_k, S2_k)
   const __amdgpu_buffer_rsrc_t rsx = panel_rsrc(f.XoS, (size_t)KP * f.ld2_o * 8);
   const uint32_t cstride_b = (uint32_t)f.ld2_o * 8u;
-  if (NS == 0) stage_panel_buf<NW>(rsx, 0u, pan, chunks2, wave, lane * 16);
+  // NS == 0: the panel of column k + 2 is issued inside column k's moments window by the fifteen waves that idle there,
+  // into the column's own buffer (every gather of column k is behind the first barrier).  A wave's LDS-DMA issue blocks
+  // for ~250 cycles per 1 KiB piece: at the top of a column that was ~1 000 cycles of every wave's slot work (66 KiB per
+  // column here), in the window it costs nothing.  So the first two panels are on their way before the first column.
+  if (NS == 0) {
+    stage_panel_buf<NW>(rsx, 0u, pan, chunks2, wave, lane * 16);
+    if (K > 1) stage_panel_buf<NW>(rsx, cstride_b, pan + (size_t)2 * PW, chunks2, wave, lane * 16);
+  }
   sync_with_dma();
 #ifdef BNMTF_PHASE_TIMING
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = tick(q2[0].x);
 #endif
   float dprev = 0.f;
   for (int k = 0; k < K; ++k) {
-    if (NS == 0 && k + 1 < K) stage_panel_buf<NW>(rsx, (uint32_t)(k + 1) * cstride_b, pan + (size_t)((k + 1) & 1) * 2 * PW, chunks2, wave, lane * 16);
     const uint32_t boff = (uint32_t)(k & 1) * buf_b;
     const float xsel = (NX == 2 && k >= 32) ? x[NX - 1] : x[0];
     const float xk = half_bcast(xsel, k & 31, half);
@@ -229,8 +235,15 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
       o = *reinterpret_cast<const float4*>(&xch[lane * 4]);
       if (mgi >= 0) tn_moments_f32(o.x, o.y, &ef, &vf);
       ret[lane] = ef;
+    } else if (NS == 0 && wave >= 1 && k + 2 < K) {
+      typedef __attribute__((address_space(3))) void* lds_ptr;
+      float* dst = pan + (size_t)(k & 1) * 2 * PW;
+      for (int c = wave - 1; c < chunks2; c += NW - 1)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(dst + (size_t)c * 256), 16, lane * 16,
+                                                  (int)((uint32_t)(k + 2) * cstride_b + (uint32_t)c * 1024u), 0, 0);
     }
-    sync_with_dma();                     // also lands the next panel (vmcnt) and retires this one
+    if (NS == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS traffic only: the pieces just issued have all of column k + 1 to land (its first barrier waits for them)
+    else sync_with_dma();                // service-wave shape: also lands the next panel (vmcnt) and retires this one
     if (mom && mgi >= 0) {
       const size_t p = (size_t)mgi * KP + k;
       a.Xself[p] = ef; a.mu_self[p] = o.x; a.tau_self[p] = o.y; a.var_self[p] = vf; a.S2self[p] = vf + ef * ef;
