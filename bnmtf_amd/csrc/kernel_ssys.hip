@@ -8,8 +8,11 @@
 //   tauS_kl = tau A_aa ,   muS_kl = (-lambdaS_kl + tau (b_a - sum_{a' != a} A_aa' S_a')) / tauS_kl ,   a = k L + l.
 // A factorises over the columns of R:  A = sum_j W_j (x) (G_j G_j^T),  W_j[k][k'] = sum_i M_ij F_ik F_ik'
 //                                         = (F^T F)[k][k'] - sum_{i in miss(j)} F_ik F_ik'   (a K x K matrix per column).
-// So an iteration costs one masked Gram per column (scol_gram_kernel: f32 MFMA over the ~10 % missing entries), one
-// K^2 x J x L^2 GEMM (ssys_gemm_kernel: f32 MFMA, partial slabs over column ranges, summed in a fixed order), and then the
+// W_j and G_j G_j^T are symmetric: with their upper triangles packed (p = (k <= k'), r = (l <= l'); tri_index, kernels.h)
+// the whole system is one plain GEMM, A[p][r] = sum_j Wc[j][p] Gc[j][r], written to its four symmetric places.
+// So an iteration costs one masked Gram per column (scol_gram_kernel: f32 MFMA over the ~10 % missing entries), the
+// packed second moments of G's rows (gamma_pack_kernel), one K(K+1)/2 x J x L(L+1)/2 GEMM (ssys_gemm_kernel: f32 MFMA,
+// partial slabs over column ranges, summed in a fixed order by ssys_reduce_kernel), and then the
 // K.L sequential conditionals touch nothing but A: ssys_chain_kernel keeps the residual r = b - A S on chip and walks the
 // entries row by row (a row of S = the lanes of one wave, the running correction of a lane grows by one FMA per step).
 // The variational version (second moments) is the same system with E[F_ik F_ik'] = F_ik F_ik' + [k = k'] varF_ik and
