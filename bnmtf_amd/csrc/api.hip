@@ -727,7 +727,7 @@ int bnmtf_destroy(bnmtf_handle h) {
   dfree(h->slabsS); dfree(h->CfS); dfree(h->deltaS); dfree(h->s_partial); dfree(h->s_w); dfree(h->s_omp); dfree(h->lambdaS); dfree(h->s_numer); dfree(h->s_taup);
   dfree(h->exp_rows); dfree(h->exp_cols); dfree(h->exp_S); dfree(h->exp_tau);
   dfree(h->muS); dfree(h->tauS); dfree(h->varS); dfree(h->mv_rows); dfree(h->mv_cols); dfree(h->tri_order); dfree(h->tri_sums);
-  dfree(h->ss_Wt); dfree(h->ss_Gc); dfree(h->ss_cands); dfree(h->ss_slabs); dfree(h->ss_AB); dfree(h->ss_r); dfree(h->ss_bpart);
+  dfree(h->ss_Wc); dfree(h->ss_Gc); dfree(h->ss_cands); dfree(h->ss_slabs); dfree(h->ss_AB); dfree(h->ss_r); dfree(h->ss_bpart);
   dfree(h->Rfull); dfree(h->Mtrain); dfree(h->Mscratch); dfree(h->Ad); dfree(h->Bd); dfree(h->out6);
   dfree(h->A2d); dfree(h->B2d); dfree(h->vb_rec); dfree(h->vbred);
   dfree(h->tau_d); dfree(h->tau_f); dfree(h->acc); dfree(h->rec); dfree(h->gunit); dfree(h->S);
