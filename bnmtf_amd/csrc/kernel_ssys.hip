@@ -101,11 +101,12 @@ void launch_scol_gram(const SColGramArgs& a, hipStream_t st) {
   else        hipLaunchKernelGGL(scol_gram_kernel<0>, dim3((a.n + 3) / 4), dim3(256), 0, st, a);
 }
 
-// Gc[j][r(l, l')] = G_jl G_jl' (l <= l'), the packed second-moment matrix of column j's row of G.  Block = 16 columns.
+// Gc[j][r(l, l')] = G_jl G_jl' (l <= l'), the packed second-moment matrix of column j's row of G.  Block = 8 columns (512 blocks at 4096 columns: two per CU hide each other's load -> store latency).
 __global__ __launch_bounds__(256) void gamma_pack_kernel(GammaPackArgs a) {
-  __shared__ float g[16][32], v[16][32];
-  const int j0 = blockIdx.x * 16, PL = tri_count(a.L), PLp = tri_padded(a.L);
-  for (int e = threadIdx.x; e < 16 * 32; e += 256) {
+  constexpr int NC = 8;
+  __shared__ float g[NC][32], v[NC][32];
+  const int j0 = blockIdx.x * NC, PL = tri_count(a.L), PLp = tri_padded(a.L);
+  for (int e = threadIdx.x; e < NC * 32; e += 256) {
     const int j = j0 + (e >> 5);
     g[e >> 5][e & 31] = j < a.n ? a.G[(size_t)(a.n0 + j) * 32 + (e & 31)] : 0.f;
     v[e >> 5][e & 31] = (j < a.n && a.varG) ? a.varG[(size_t)(a.n0 + j) * 32 + (e & 31)] : 0.f;
@@ -116,12 +117,12 @@ __global__ __launch_bounds__(256) void gamma_pack_kernel(GammaPackArgs a) {
     if (r >= PL) continue;                                          // pads stay zero
     int l, lp; tri_unindex(r, a.L, &l, &lp);
 #pragma unroll
-    for (int t = 0; t < 16; ++t)
+    for (int t = 0; t < NC; ++t)
       if (j0 + t < a.n) a.Gc[(size_t)(j0 + t) * PLp + pos] = fmaf(g[t][l], g[t][lp], l == lp ? v[t][l] : 0.f);
   }
 }
 void launch_gamma_pack(const GammaPackArgs& a, hipStream_t st) {
-  if (a.n > 0) hipLaunchKernelGGL(gamma_pack_kernel, dim3((a.n + 15) / 16), dim3(256), 0, st, a);
+  if (a.n > 0) hipLaunchKernelGGL(gamma_pack_kernel, dim3((a.n + 7) / 8), dim3(256), 0, st, a);
 }
 
 // A on the packed pairs: slab[s][p][r] = sum_{j in range s} Wc[j][p] Gc[j][r], p = (k <= k'), r = (l <= l') -- with both
@@ -233,8 +234,14 @@ __global__ __launch_bounds__(1024) void ssys_b_kernel(SSysBArgs a) {
     const int jj = e >> 5, cc = e & 31, j = j0 + jj;
     float p = 0.f, gg = 0.f;
     if (j < a.n) {
-      for (int t = 0; t < a.split; ++t) p += a.slabs[((size_t)t * a.n_pad + j) * 32 + cc];
       gg = a.G[(size_t)(a.n0 + j) * 32 + cc];
+      for (int t0 = 0; t0 < a.split; t0 += 8) {                     // eight loads in flight, added in slab order
+        float w[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) w[t] = t0 + t < a.split ? a.slabs[((size_t)(t0 + t) * a.n_pad + j) * 32 + cc] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) p += w[t];
+      }
     }
     pv[jj][cc] = p; g[jj][cc] = gg;
   }
