@@ -66,6 +66,7 @@ _SIGS = {
     "bnmtf_kmeans_destroy": ([_P], C.c_int),
     "bnmtf_kmeans_assign": ([_P, _P, _P, _P, _P], C.c_int),
     "bnmtf_kmeans_sums": ([_P, _P, _P, _P], C.c_int),
+    "bnmtf_kmeans_set_row": ([_P, C.c_int, _P], C.c_int),
     "bnmtf_metric_sums": ([_P, _P, _P, _P, _P, _P], C.c_int),
     "bnmtf_tn_sample": ([_P, _P, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, _P], C.c_int),
     "bnmtf_tn_moments": ([_P, _P, C.c_size_t, C.c_int, _P, _P], C.c_int),

@@ -73,14 +73,18 @@ __global__ __launch_bounds__(256) void scol_gram_kernel(SColGramArgs a) {
       if (VB) dv += r.v[t] + r.v[t + 1];
     }
   };
-  Idx ia, ib; Rows ra, rb;
-  load_idx(s0, ia); load_idx(s0 + 16, ib);
-  load_rows(ia, ra);
-  for (uint32_t e0 = s0; e0 < s1; e0 += 32) {                       // two batches per trip (the slot count is a multiple of 64): register sets alternate without copies
-    load_rows(ib, rb); load_idx(e0 + 32, ia);
-    mfmas(ra);
-    load_rows(ia, ra); load_idx(e0 + 48, ib);
-    mfmas(rb);
+  // a column with nothing missing has no slots at all (s0 == s1, possibly the very end of idx): nothing may be
+  // prefetched for it -- the words behind its range are another column's, or not there at all
+  if (s0 < s1) {
+    Idx ia, ib; Rows ra, rb;
+    load_idx(s0, ia); load_idx(s0 + 16, ib);
+    load_rows(ia, ra);
+    for (uint32_t e0 = s0; e0 < s1; e0 += 32) {                     // two batches per trip (the slot count is a multiple of 64): register sets alternate without copies
+      load_rows(ib, rb); load_idx(e0 + 32, ia);
+      mfmas(ra);
+      load_rows(ia, ra); load_idx(e0 + 48, ib);
+      mfmas(rb);
+    }
   }
 #pragma unroll
   for (int t = 0; t < 16; ++t) acc[t] += acc2[t];

@@ -201,15 +201,18 @@ int bnmtf_tn_moments(const double* mu, const double* tau, size_t n, int device,
 int bnmtf_gamma_sample(double alpha, double beta, uint64_t seed, uint64_t it, int device, double* out);
 
 /* ---- masked K-means for initialise(init_FG='kmeans') (code/models/kmeans/kmeans.py): the two O(points x coordinates x K)
- *      passes of an iteration; X [n_points][n_coords] fp32, M 0/1 bytes; the handle is a plain pointer of its own kind. */
-int bnmtf_kmeans_create(const float* X, const uint8_t* M, int n_points, int n_coords, int K, int device, void** out);
+ *      passes of an iteration; X [n_points][n_coords] fp64 (as the reference computes), M 0/1 bytes; the handle is a plain pointer of its own kind. */
+int bnmtf_kmeans_create(const double* X, const uint8_t* M, int n_points, int n_coords, int K, int device, void** out);
 int bnmtf_kmeans_destroy(void* h);
 /* assignment() (kmeans.py:87-119): closest centroid by MSE over the shared observed coordinates (none: infinitely far;
  * ties: lowest index); dist_out = that MSE (+inf without overlap) */
-int bnmtf_kmeans_assign(void* h, const float* centroids, const uint8_t* mask_centroids, int32_t* assign_out, double* dist_out);
+int bnmtf_kmeans_assign(void* h, const double* centroids, const uint8_t* mask_centroids, int32_t* assign_out, double* dist_out);
 /* the sums update() needs (kmeans.py:126-182): cnt_out / tot_out [K][n_coords] = number / sum of the values of the
  * cluster's members that observe the coordinate (assign < 0: the point belongs to no cluster) */
 int bnmtf_kmeans_sums(void* h, const int32_t* assign, double* cnt_out, double* tot_out);
+/* X[index][:] = values: `self.centroids[c] = self.X[index]` (kmeans.py:141) makes the refilled centroid a view of the data
+ * point, so the means written into the centroid afterwards (:158-163) change the point; the host class mirrors that */
+int bnmtf_kmeans_set_row(void* h, int index, const double* values);
 
 /* ---- measurement aids (bench.py) --------------------------------------- */
 #define BNMTF_KERNEL_GEMM_ROWS 0   /* P  = R~ . V      (U/F step numerators)        */

@@ -449,6 +449,82 @@ def make_masks():
     np.savez_compressed(os.path.join(HERE, "masks.npz"), **out)
 
 
+def make_kmeans():
+    """code/models/kmeans/kmeans.py under random.seed: starting centroids, every iteration's assignments, the final
+    centroids / masks / distances / clustering_results -- on clustered data with missing values, on a case that empties a
+    cluster ('singleton' refill, kmeans.py:137-152), on one with an unobserved column and a point that shares no
+    coordinate with some centroid, and on the toy BNMTF matrix as initialise(init_FG='kmeans') uses it (rows and columns)."""
+    from BNMTF.code.models.kmeans.kmeans import KMeans
+    rs = np.random.RandomState(77)
+    cases = {}
+    # three well separated groups, 25 % missing
+    cen = np.array([[0., 0, 0, 0, 0, 0], [5, 5, 5, 5, 5, 5], [-4, 6, -4, 6, -4, 6]])
+    X = np.vstack([c + 0.3 * rs.randn(14, 6) for c in cen]); M = (rs.rand(*X.shape) > 0.25).astype(float)
+    M[np.arange(len(X)), rs.randint(6, size=len(X))] = 1
+    cases["groups"] = (X, M, 3, 5)
+    # more clusters than natural groups and duplicated points: clusters run empty and are refilled
+    X = np.vstack([np.tile(rs.randn(1, 4), (6, 1)), 4 + 0.01 * rs.randn(5, 4), rs.randn(4, 4) * 3]); M = np.ones(X.shape)
+    M[1, 0] = M[7, 2] = M[12, 3] = 0
+    cases["empties"] = (X, M, 6, 3)
+    # an unobserved column (dropped), sparse rows, a point that overlaps few centroid coordinates
+    X = rs.randn(20, 7) * 2; M = (rs.rand(20, 7) > 0.55).astype(float); M[:, 4] = 0
+    M[np.arange(20), rs.randint(4, size=20)] = 1
+    cases["sparse"] = (X, M, 4, 11)
+    R = np.loadtxt(REF + "/data_toy/bnmtf/R.txt"); Mt = np.loadtxt(REF + "/data_toy/bnmtf/M.txt")
+    cases["toy_rows"] = (R, Mt, 5, 0)
+    cases["toy_cols"] = (R.T.copy(), Mt.T.copy(), 5, 1)
+    out = {}
+    for name, (X, M, K, seed) in cases.items():
+        with quiet():
+            km = KMeans(X, M, K)
+            km.initialise(seed)
+            out[name + "/X"] = X; out[name + "/M"] = M; out[name + "/K"] = np.array(K); out[name + "/seed"] = np.array(seed)
+            out[name + "/centroids0"] = np.array(km.centroids, dtype=float)
+            # the loop of cluster() (kmeans.py:70-84), keeping every iteration's state
+            hist = []
+            iteration = 1; change = True
+            while change:
+                iteration += 1
+                change = km.assignment()
+                km.update()
+                hist.append(np.array(km.cluster_assignments, dtype=int).copy())
+                if iteration >= 200:
+                    break
+            km.create_matrix()
+        out[name + "/assign_hist"] = np.array(hist)
+        out[name + "/centroids"] = np.array([np.asarray(c, dtype=float) for c in km.centroids])
+        out[name + "/mask_centroids"] = np.array(km.mask_centroids, dtype=float)
+        out[name + "/distances"] = np.array(km.distances, dtype=float)
+        out[name + "/clustering_results"] = km.clustering_results
+    np.savez_compressed(os.path.join(HERE, "kmeans.npz"), **out)
+
+
+def make_gdsc():
+    """data_drug_sensitivity/gdsc/load_data.py:15-54 on the reference's own ic50 file: what load_gdsc returns for the
+    first 12 cell lines (the excerpt travels as a fixture: header + 12 lines of the data file) and summary numbers of the
+    whole file (checked where /root/reference is present)."""
+    sys.path.insert(0, TMP + "/BNMTF/data_drug_sensitivity/gdsc")
+    import load_data as ref_load
+    src = REF + "/data_drug_sensitivity/gdsc/ic50_excl_empty_filtered_cell_lines_drugs.txt"
+    lines = open(src, "r").readlines()
+    excerpt = os.path.join(HERE, "gdsc_excerpt.txt")
+    with open(excerpt, "w") as f:
+        f.writelines(lines[:13])
+    out = {}
+    X, X_min, M, drugs, cells, cancers, tissues = ref_load.load_gdsc(location=excerpt)
+    out["ex/X"], out["ex/X_min"], out["ex/M"] = X, X_min, M
+    out["ex/n_drugs"] = np.array(len(drugs)); out["ex/n_cells"] = np.array(len(cells))
+    out["ex/negated"] = ref_load.negate_gdsc(X, M)
+    X, X_min, M, drugs, cells, cancers, tissues = ref_load.load_gdsc()
+    out["full/shape"] = np.array(X.shape); out["full/M_sum"] = np.array(M.sum()); out["full/X_sum"] = np.array(X.sum())
+    out["full/X_min_sum"] = np.array(X_min.sum()); out["full/minimum"] = np.array(X.min())
+    out["full/row_obs"] = M.sum(axis=1); out["full/col_obs"] = M.sum(axis=0)
+    ii = np.array([0, 5, 17, 100, 333, 621]); jj = np.array([0, 3, 77, 137, 50, 9])
+    out["full/ii"], out["full/jj"] = ii, jj
+    out["full/X_at"], out["full/M_at"], out["full/X_min_at"] = X[ii, jj], M[ii, jj], X_min[ii, jj]
+    np.savez_compressed(os.path.join(HERE, "gdsc.npz"), **out)
+
+
 def make_toy_data():
     """The reference's toy inputs (data files its own tests/experiments hold) as one fixture."""
     out = {}
@@ -461,7 +537,7 @@ def make_toy_data():
 
 if __name__ == "__main__":
     import_reference()
-    which = sys.argv[1:] or ["toy", "bnmf", "bnmtf", "vb", "tn", "traj", "icm", "trivb", "masks"]
+    which = sys.argv[1:] or ["toy", "bnmf", "bnmtf", "vb", "tn", "traj", "icm", "trivb", "masks", "kmeans", "gdsc"]
     if "toy" in which: make_toy_data()
     if "bnmf" in which: make_bnmf_cond()
     if "bnmtf" in which: make_bnmtf_cond()
@@ -471,6 +547,8 @@ if __name__ == "__main__":
     if "icm" in which: make_icm()
     if "trivb" in which: make_bnmtf_vb()
     if "masks" in which: make_masks()
+    if "kmeans" in which: make_kmeans()
+    if "gdsc" in which: make_gdsc()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -76,6 +76,25 @@ def test_headline_shape_properties():
     assert tot == I * J - int(0.1 * I * J)
     assert np.array_equal(row, M.sum(axis=1).astype(np.uint32)) and np.array_equal(col, M.sum(axis=0).astype(np.uint32))
     np.random.seed(0); b.initialise("random")
+    # conditional parameters of three columns of each factor against the reference's closed forms
+    # (bnmf_gibbs_optimised.py:167-177) in NumPy fp64, as tests/test_bnmf_gibbs_4096_gpu.py does at 4096^2
+    U, V, tau = b.U.copy(), b.V.copy(), b.tau
+    R64 = R.astype(np.float64); M64 = M.astype(np.float64)
+    res = M64 * (R64 - U @ V.T)
+    for k in (0, 37, K - 1):
+        t_ref = tau * (M64 @ (V[:, k] ** 2))
+        m_ref = (-0.1 + tau * ((res @ V[:, k]) + U[:, k] * (M64 @ (V[:, k] ** 2)))) / t_ref
+        t = b.tauU(k)
+        np.testing.assert_allclose(t, t_ref, rtol=2e-6)
+        scale = np.abs(tau * (np.abs(res) @ np.abs(V[:, k])) / t_ref).max()   # size of the cancelling terms
+        assert np.abs(b.muU(t, k) - m_ref).max() < 2e-5 * scale
+        t_ref = tau * (M64.T @ (U[:, k] ** 2))
+        m_ref = (-0.1 + tau * ((res.T @ U[:, k]) + V[:, k] * (M64.T @ (U[:, k] ** 2)))) / t_ref
+        t = b.tauV(k)
+        np.testing.assert_allclose(t, t_ref, rtol=2e-6)
+        scale = np.abs(tau * (np.abs(res).T @ np.abs(U[:, k])) / t_ref).max()
+        assert np.abs(b.muV(t, k) - m_ref).max() < 2e-5 * scale
+    del res, R64, M64
     b.run(120, store_samples=False)
     mse = np.array(b.all_performances["MSE"])
     assert mse[0] > 1000 * mse[-1] and 0.9 < mse[-1] < 3.0        # on its way to the noise variance 1/tau = 1 (reached after ~300)
@@ -84,6 +103,45 @@ def test_headline_shape_properties():
     assert abs(p["MSE"] - mse[-1]) < 1e-4 * mse[-1]
     assert abs(p["Rp"] - b.all_performances["Rp"][-1]) < 1e-5
     assert np.isfinite(b.U).all() and np.isfinite(b.V).all() and b.U.min() >= 0 and b.V.min() >= 0
+
+
+def test_headline_shape_whole_sweep_against_fp64_closed_forms():
+    """8192 x 8192, K = 64: one WHOLE iteration of the on-chip kernels (the sweep the bench times) in the deterministic
+    mode update against the reference's sequential column updates (bnmf_gibbs_optimised.py:134-142 with max(0, mu) for the
+    draw) restated on the masked residual in NumPy fp64: E = M (R - U V^T) kept current by rank-one updates, so every one
+    of the 2 x 64 columns sees the new values of the columns before it, exactly as the reference's loop."""
+    I = J = 8192; K = 64
+    R, M, _, _ = generate_bnmf(I, J, K, 0.1, tau=1.0, seed_data=0, seed_mask=1)
+    b = bnmf_gibbs_optimised(R, M, K, PRI, verbose=False, seed=0)
+    np.random.seed(0); b.initialise("random")
+    assert "sweep_nw=16" in b.describe()                      # the one-round block shape (kernel_sweep_ahead.hip unless BNMTF_AHEAD=0)
+    U, V, tau = b.U.copy(), b.V.copy(), float(b.tau)
+    b.run(1, update="mode")
+    R64 = R.astype(np.float64); M64 = M.astype(np.float64)
+    E = M64 * (R64 - U @ V.T)
+    del R64
+    lam = 0.1
+
+    def sweep(E, X, Y, Mm):            # columns of X given Y; E is (rows of X) x (rows of Y)
+        for k in range(K):
+            a = Mm @ (Y[:, k] ** 2)
+            num = E @ Y[:, k] + X[:, k] * a
+            mu = (-lam + tau * num) / (tau * a)
+            new = np.maximum(mu, 0.0)
+            d = new - X[:, k]
+            E -= Mm * np.outer(d, Y[:, k])
+            X[:, k] = new
+    sweep(E, U, V, M64)
+    sU = np.abs(U).max()
+    assert np.abs(b.all_U[0] - U).max() <= 5e-4 * sU
+    Et = np.ascontiguousarray(E.T); Mt = np.ascontiguousarray(M64.T)
+    del E
+    sweep(Et, V, U, Mt)
+    sV = np.abs(V).max()
+    assert np.abs(b.all_V[0] - V).max() <= 5e-4 * sV
+    # and the masked MSE the device reports for this sample (Gram identities) is the residual's
+    mse_ref = float((Et ** 2).sum() / Mt.sum())
+    assert abs(b.all_performances["MSE"][0] - mse_ref) <= 2e-4 * mse_ref
 
 
 @pytest.mark.parametrize("I,J,K,env", [(2048, 1500, 64, {"BNMTF_WIDE": "1"}),      # 16-wave blocks
