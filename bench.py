@@ -12,9 +12,12 @@ factor blocks are exchanged with RCCL inside libbnmtf_hip.so; the control plane 
 times) is plain TCP (bnmtf_amd/comm.py) -- no PyTorch anywhere.
 
 A step is one full iteration exactly as the reference's run() defines it (bnmf_gibbs_optimised.py:133-155): K column
-updates of U, K of V, the tau draw and the three training-mask metrics.  Inputs are resident in HBM when the timed
-region starts; `value` keeps the samples on the device, `pcie_inclusive` is the rate with every sample handed to the
-host (all_U / all_V, the reference's run() contract).  Rank 0 prints ONE JSON line.
+updates of U, K of V, the tau draw, the sample hand-off (all_U[it], all_V[it]) and the three training-mask metrics.
+Inputs (R, M) are resident in HBM when the timed region starts; `value` is the rate of that whole iteration, samples
+handed to page-locked host arrays included; `device_resident` is the same loop with the samples left
+on the device.  `mse_trajectory` holds the masked MSE of the first iterations of this very run (up to 200), and
+`cpu_baseline.mse_vs_iter_small` the same chain (same Philox seed) run by the CPU oracle and by the device at a size
+the oracle finishes.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import hashlib
@@ -62,6 +65,7 @@ def cpu_baseline(w, R, M):
     R = R.astype(np.float64); M = M.astype(np.float64)
     rs = np.random.RandomState(0)
     tic = time.perf_counter
+    fair, kind_note = None, "port"
     if kind == "bnmf":
         o = O.BNMFGibbsOracle(R, M, K, PRI2, seed=0)
         o.U = rs.exponential(10.0, (o.I, K)); o.V = rs.exponential(10.0, (o.J, K)); o.tau = 1.0
@@ -78,6 +82,30 @@ def cpu_baseline(w, R, M):
         t3 = tic()
         sec = K * (t2 - t0) / n + (t3 - t2)
         sample = "%d of %d U-column updates %.2fs, %d of %d V-column updates %.2fs, tau+metrics %.2fs" % (n, K, t1 - t0, n, K, t2 - t1, t3 - t2)
+        kind_note = "port, sampled %d/%d columns" % (n, K)
+        # the "fair CPU" variant: same conditionals on the masked residual kept current by rank-one
+        # updates (O(I J) per column instead of a full U V^T product), vectorised sampler -- so that the ratio is not only
+        # the as-written algorithm's redundant dgemms.  Same sampling: n columns of each factor, scaled.
+        t4 = tic()
+        E = o.M * (o.R - o.U @ o.V.T)
+        t5 = tic()
+        for k in range(n):
+            a_ = o.M @ (o.V[:, k] ** 2); t = o.tau * a_
+            m = (-o.lambdaU[:, k] + o.tau * (E @ o.V[:, k] + o.U[:, k] * a_)) / t
+            new = orng.tn_draw(m, t, np.arange(o.I), k, 1, orng.STREAM_ROWS, 0)
+            E -= o.M * np.outer(new - o.U[:, k], o.V[:, k]); o.U[:, k] = new
+        for k in range(n):
+            a_ = o.M.T @ (o.U[:, k] ** 2); t = o.tau * a_
+            m = (-o.lambdaV[:, k] + o.tau * (E.T @ o.U[:, k] + o.V[:, k] * a_)) / t
+            new = orng.tn_draw(m, t, np.arange(o.J), k, 1, orng.STREAM_COLS, 0)
+            E -= o.M * np.outer(o.U[:, k], new - o.V[:, k]); o.V[:, k] = new
+        t6 = tic()
+        (E ** 2).sum(); o.predict_while_running()
+        t7 = tic()
+        fair_sec = (t5 - t4) + K * (t6 - t5) / n + (t7 - t6)
+        fair = {"value": 1.0 / fair_sec, "unit": "iterations/s", "kind": "port (residual form, vectorised sampler), sampled %d/%d columns" % (n, K),
+                "sample": "oracle.BNMFGibbsFairCPU arithmetic at full size: residual %.2fs, %d of %d column updates of each factor %.2fs, tau+metrics %.2fs; iteration = %.1fs" % (
+                    t5 - t4, n, K, t6 - t5, t7 - t6, fair_sec)}
     elif kind == "bnmtf":
         L = w["L"]
         o = O.BNMTFGibbsOracle(R, M, K, L, PRI3, seed=0)
@@ -99,6 +127,7 @@ def cpu_baseline(w, R, M):
         sec = K * (t1 - t0) / nf + K * L * (t2 - t1) / ns + L * (t3 - t2) / nf + (t4 - t3)
         sample = "%d of %d F columns %.2fs, %d of %d S entries %.2fs, %d of %d G columns %.2fs, tau+metrics %.2fs" % (
             nf, K, t1 - t0, ns, K * L, t2 - t1, nf, L, t3 - t2, t4 - t3)
+        kind_note = "port, sampled %d/%d F columns, %d/%d S entries, %d/%d G columns" % (nf, K, ns, K * L, nf, L)
     else:
         o = O.BNMFVBOracle(R, M, K, PRI2)
         o.muU = rs.exponential(1.0, (o.I, K)); o.muV = rs.exponential(1.0, (o.J, K))
@@ -116,8 +145,33 @@ def cpu_baseline(w, R, M):
         t2 = tic()
         sec = K * (t1 - t0) / n + (t2 - t1)
         sample = "%d of %d update_U+update_exp_U and as many for V %.2fs, tau+metrics+ELBO %.2fs" % (n, K, t1 - t0, t2 - t1)
-    return {"value": 1.0 / sec, "unit": "iterations/s", "cores": _blas_cores(), "kind": "port",
-            "sample": "oracle/bnmtf_oracle.py (NumPy fp64, as written) at full size: %s; iteration = %.1fs" % (sample, sec)}
+        kind_note = "port, sampled %d/%d columns" % (n, K)
+    out = {"value": 1.0 / sec, "unit": "iterations/s", "cores": _blas_cores(), "kind": kind_note,
+           "sample": "oracle/bnmtf_oracle.py (NumPy fp64, as written) at full size: %s; iteration = %.1fs" % (sample, sec)}
+    if fair is not None:
+        out["fair_cpu"] = fair
+    return out
+
+
+def small_trajectories(n_iter=25):
+    """Masked MSE vs iteration of ONE chain run twice: by the CPU oracle and by the device, same data, same initial state,
+    same Philox seed (BNMF Gibbs, 1024 x 1024, K = 16, 10 % missing: a size the oracle finishes in seconds)."""
+    import bnmtf_amd
+    from bnmtf_amd.synthetic import generate_bnmf
+    from oracle import bnmtf_oracle as O
+    I = J = 1024; K = 16
+    R, M, _, _ = generate_bnmf(I, J, K, 0.1, tau=1.0, seed_data=0, seed_mask=1)
+    np.random.seed(0)
+    b = bnmtf_amd.bnmf_gibbs_optimised(R, M, K, PRI2, seed=0, verbose=False)
+    b.initialise("random")
+    o = O.BNMFGibbsOracle(R.astype(np.float64), M.astype(np.float64), K, PRI2, seed=0)
+    o.U, o.V, o.tau = b.U.copy(), b.V.copy(), b.tau
+    t0 = time.perf_counter(); o.run(n_iter); t_cpu = time.perf_counter() - t0
+    t0 = time.perf_counter(); b.run(n_iter); t_gpu = time.perf_counter() - t0
+    b.close()
+    return {"config": "BNMF Gibbs %dx%d K=%d, 10%% missing, seed 0, %d iterations" % (I, J, K, n_iter),
+            "cpu_oracle_mse": [float(x) for x in o.all_performances["MSE"]], "device_mse": [float(x) for x in b.all_performances["MSE"]],
+            "cpu_oracle_s_per_iteration": t_cpu / n_iter, "device_s_per_iteration": t_gpu / n_iter}
 
 
 def build_model(w, R, M, rank, world, local_rank, comm_id):
@@ -143,10 +197,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps iterations each; value = median")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps iterations each; value = median")
     ap.add_argument("--workload", default="bnmf_8192_k64", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-samples", action="store_true", help="skip the PCIe-inclusive leg")
+    ap.add_argument("--no-samples", action="store_true", help="leave the samples on the device in the timed loop too (then `value` is NOT the reference's iteration)")
     a = ap.parse_args()
 
     from bnmtf_amd import comm
@@ -170,6 +224,8 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(w, R, M)
+        if kind == "bnmf":
+            cpu["mse_vs_iter_small"] = small_trajectories()
 
     t_create = time.perf_counter()
     model = build_model(w, R, M, rank, world, local_rank, comm_id)
@@ -190,7 +246,20 @@ def main():
         else:
             _lib.check(L.bnmf_vb_run(h, n, None, _lib.ptr(perf), None, None))
 
-    run(a.warmup)
+    # the reference's run() hands every sample to the host (all_U[it], all_V[it]): the timed loop does too -- page-locked
+    # arrays of --steps samples (re-used by every timed region), asynchronous copies behind the compute stream
+    with_samples = kind != "vb" and not a.no_samples
+    bufs = None
+    if with_samples:
+        if kind == "bnmf":
+            bufs = (_lib.sample_buffer((a.steps, I, K)), _lib.sample_buffer((a.steps, J, K)), None)
+        else:
+            bufs = (_lib.sample_buffer((a.steps, I, K)), _lib.sample_buffer((a.steps, J, w["L"])), _lib.sample_buffer((a.steps, K, w["L"])))
+    trajectory = []
+    perf_w = np.zeros((max(a.warmup, 1), 3))
+    if a.warmup > 0:
+        run(a.warmup, perf_w)
+        trajectory += [float(x) for x in perf_w[:a.warmup, 0]]
     # timed regions: HIP events bracket the roofline kernel only (two records per iteration on its own stream)
     model.set_profiling(True, kernel=_lib.KERNEL_GEMM_COLS)
     perf_first = None
@@ -199,12 +268,15 @@ def main():
         perf = np.zeros((a.steps, 3))
         sync()
         t0 = time.perf_counter()
-        run(a.steps, perf)
+        run(a.steps, perf, samples=bufs)
         sync()
         dts.append(cp.allreduce_max(time.perf_counter() - t0))
+        trajectory += [float(x) for x in perf[:, 0]]
         if perf_first is None:
             perf_first = perf
     dt = float(np.median(dts))
+    if with_samples:
+        assert np.isfinite(bufs[0][-1]).all() and float(np.abs(bufs[0][-1]).max()) > 0.0
 
     names = {_lib.KERNEL_GEMM_ROWS: "gemm_rows(R~.V)", _lib.KERNEL_GEMM_COLS: "gemm_cols(R~^T.U)",
              _lib.KERNEL_SWEEP_ROWS: "sweep_rows", _lib.KERNEL_SWEEP_COLS: "sweep_cols"}
@@ -224,20 +296,13 @@ def main():
         stats[nm] = {"avg_us": 1e3 * ms / max(n, 1), "launches": n}
     model.set_profiling(False)
 
-    # the reference's run() hands every sample to the host: same loop with all_U / all_V (page-locked arrays, asynchronous
-    # copies behind the compute stream) -- the PCIe-inclusive rate
-    pcie = None
-    if not a.no_samples and kind != "vb":
-        n = min(a.steps, 50)
-        if kind == "bnmf":
-            bufs = (_lib.sample_buffer((n, I, K)), _lib.sample_buffer((n, J, K)), None)
-        else:
-            bufs = (_lib.sample_buffer((n, I, K)), _lib.sample_buffer((n, J, w["L"])), _lib.sample_buffer((n, K, w["L"])))
-        run(2, samples=tuple(None if b is None else b[:2] for b in bufs))
+    # the same loop with the samples left on the device (what round 1 and 2 reported as `value`)
+    resident = None
+    if with_samples:
+        run(2)
         sync(); t1 = time.perf_counter()
-        run(n, samples=bufs)
-        sync(); pcie = n / cp.allreduce_max(time.perf_counter() - t1)
-        assert np.isfinite(bufs[0][-1]).all() and float(np.abs(bufs[0][-1]).max()) > 0.0
+        run(a.steps)
+        sync(); resident = a.steps / cp.allreduce_max(time.perf_counter() - t1)
 
     if rank == 0:
         Wc = w.get("L", K)                 # width of the cols-direction contraction's factor operand is K (F or U)
@@ -288,11 +353,11 @@ def main():
                            {"bnmf": "BNMF Gibbs", "bnmtf": "BNMTF Gibbs", "vb": "BNMF VB"}[kind], I, J, K, " L=%d" % w["L"] if "L" in w else "",
                            "exp" if kind == "vb" else "random"),
                        "parallelism": "rows/cols split x%d, RCCL all-gather of factor blocks" % world if world > 1 else "single GPU",
-                       "samples": "device-resident"},
+                       "samples": ("handed to the host every iteration (all_U/all_V: %.1f MiB per iteration, page-locked arrays, copy stream)" % (
+                                       4.0 * (I * K + J * Wc + (K * Wc if kind == "bnmtf" else 0)) / 2 ** 20)) if with_samples else
+                                  ("none (the variational run() stores no samples)" if kind == "vb" else "device-resident (--no-samples)")},
             "repeats": {"n": len(dts), "values": [a.steps / d for d in dts], "min": a.steps / max(dts), "median": a.steps / dt, "max": a.steps / min(dts)},
-            "pcie_inclusive": None if pcie is None else {"value": pcie, "unit": "iterations/s",
-                                                         "what": "same loop with every sample handed to the host (all_U/all_V: %.1f MiB per iteration, page-locked arrays, copy stream)" % (
-                                                             4.0 * (I * K + J * Wc + (K * Wc if kind == "bnmtf" else 0)) / 2 ** 20)},
+            "device_resident": None if resident is None else {"value": resident, "unit": "iterations/s", "what": "same loop, samples left on the device"},
             "roofline": roof,
             "roofline_sweep": {"bound": "valu", "kernel": "sweep_cols: K sequential conditional updates per unit (LDS gathers + fp32 vector FMAs)",
                                "achieved": sweep_ach, "peak": PEAK_F32_VECTOR_TFLOPS, "unit": "TFLOP/s", "frac": sweep_ach / PEAK_F32_VECTOR_TFLOPS,
@@ -301,6 +366,8 @@ def main():
             "kernels": stats,
             "create_s": t_create,
             "mse_first_last": [float(perf_first[0, 0]), float(perf[-1, 0])],
+            "mse_trajectory": {"what": "masked MSE on the training mask after each iteration of this run, from iteration 1 (warm-up included), first %d" % min(len(trajectory), 200),
+                               "values": trajectory[:200]},
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -204,8 +204,8 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
     d.wide_can = wide_can;
     d.use_wide = wide_can && wide_blocks >= 192;
     if (const char* e = getenv("BNMTF_WIDE")) d.use_wide = wide_can && atoi(e) != 0;      // 0: never, 1: whenever it can run
-    d.use_ahead = false;
-    if (const char* e = getenv("BNMTF_AHEAD")) d.use_ahead = d.use_wide && sweep_ahead_supported(d.KP, d.pw) && atoi(e) != 0;
+    d.use_turns = false;
+    if (const char* e = getenv("BNMTF_TURNS")) d.use_turns = d.use_wide && sweep_turns_supported(d.KP, d.pw) && atoi(e) != 0;
     d.f_npairs = d.use_wide ? wide_blocks * 16 : npairs_real;
     auto slot_of = [&](int pi) {
       if (!d.use_wide) return pi;
@@ -389,7 +389,7 @@ static void enqueue_sweep(bnmtf_model* h, Dir& d, const Dir& other, SweepArgs& s
     SweepArgs s2 = s;
     s2.acc = nullptr;
     f.off16 = d.pair_ok ? d.f_off16 : nullptr;
-    if (d.use_wide && d.use_ahead) launch_sweep_ahead(s2, f, h->stream);
+    if (d.use_wide && d.use_turns) launch_sweep_turns(s2, f, h->stream);
     else if (d.use_wide) launch_sweep_wide(s2, f, h->stream);
     else launch_sweep_fast(s2, f, h->stream);
     h->last_sweep_fast = true;
@@ -717,11 +717,11 @@ int bnmtf_create(const bnmtf_problem* p, bnmtf_handle* out) {
   h->create_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create0).count();
   char buf[768];
   snprintf(buf, sizeof(buf),
-           "I=%d J=%d K=%d L=%d rank=%d/%d rows[n=%d n_pad=%d split=%d ipw=%d inner_pad=%d nmiss=%zu nslots=%zu sweep_nw=%d ahead=%d emax=%d generic_units=%d] "
-           "cols[n=%d n_pad=%d split=%d ipw=%d inner_pad=%d nmiss=%zu nslots=%zu sweep_nw=%d ahead=%d emax=%d generic_units=%d] n_obs=%.0f create_ms=%.0f",
+           "I=%d J=%d K=%d L=%d rank=%d/%d rows[n=%d n_pad=%d split=%d ipw=%d inner_pad=%d nmiss=%zu nslots=%zu sweep_nw=%d turns=%d emax=%d generic_units=%d] "
+           "cols[n=%d n_pad=%d split=%d ipw=%d inner_pad=%d nmiss=%zu nslots=%zu sweep_nw=%d turns=%d emax=%d generic_units=%d] n_obs=%.0f create_ms=%.0f",
            I, J, p->K, p->L, p->rank, p->world, h->rows.n, h->rows.n_pad, h->rows.split, h->rows.ipw, h->rows.inner_pad,
-           h->rows.nmiss, h->rows.nslots, h->rows.f_nw, (int)h->rows.use_ahead, h->rows.f_emax, h->rows.f_gen_count, h->cols.n, h->cols.n_pad, h->cols.split,
-           h->cols.ipw, h->cols.inner_pad, h->cols.nmiss, h->cols.nslots, h->cols.f_nw, (int)h->cols.use_ahead, h->cols.f_emax, h->cols.f_gen_count, n_obs, h->create_ms);
+           h->rows.nmiss, h->rows.nslots, h->rows.f_nw, (int)h->rows.use_turns, h->rows.f_emax, h->rows.f_gen_count, h->cols.n, h->cols.n_pad, h->cols.split,
+           h->cols.ipw, h->cols.inner_pad, h->cols.nmiss, h->cols.nslots, h->cols.f_nw, (int)h->cols.use_turns, h->cols.f_emax, h->cols.f_gen_count, n_obs, h->create_ms);
   h->description = buf;
   *out = h;
   return BNMTF_OK;

@@ -60,7 +60,7 @@ struct Dir {
   double* stats = nullptr; int stats_blocks = 0;
   bool fast_ok = false;
   int gemm_tw = 4;                       // contraction: 32-column tiles per wave
-  bool use_ahead = false;                // the wide layout run by kernel_sweep_ahead.hip (sampler one column behind the slot work)
+  bool use_turns = false;                // the wide layout run by kernel_sweep_turns.hip (two unit groups per block taking turns)
   bool use_wide = false;                 // 16-wave sweep kernel (pairs dealt to blocks per wave class) instead of the 8-wave one
   double* C64 = nullptr; float* C32 = nullptr; double* colsum = nullptr;   // Gram of X
   // VB only

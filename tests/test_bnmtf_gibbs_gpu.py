@@ -160,12 +160,27 @@ def test_full_width_S_system_follows_the_oracle(I, J, K, L):
         assert np.abs(x - y).max() < 1e-3 * max(1.0, np.abs(y).max()), name
 
 
-def test_device_kmeans_equals_host_kmeans():
-    """bnmtf_amd.kmeans.KMeans with the assignment / sums passes on the GPU against the NumPy path (code/models/kmeans/
-    kmeans.py semantics: MSE over shared observed coordinates, ties to the lowest index, 'singleton' refill of an empty
-    cluster), same `random.seed` -> same starting centroids -> same clustering, on clustered data with 30 % missing."""
-    import random
+def test_device_kmeans_reproduces_the_reference():
+    """bnmtf_amd.kmeans.KMeans (assignment distances and per-cluster sums on the GPU, fp64) against what the reference's
+    KMeans itself produced under random.seed (tests/golden/kmeans.npz: every iteration's assignments, final centroids,
+    masks, clustering_results -- incl. the cases that empty a cluster and the reference's centroid-is-a-view-of-X
+    behaviour), and against the CPU oracle on a larger clustered case."""
+    import os
     from bnmtf_amd.kmeans import KMeans
+    from oracle.kmeans_oracle import KMeansOracle
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kmeans.npz"))
+    for name in sorted(set(k.split("/")[0] for k in g.files)):
+        km = KMeans(g[name + "/X"], g[name + "/M"], int(g[name + "/K"]), device=0)
+        km.initialise(int(g[name + "/seed"]))
+        assert np.array_equal(np.array(km.centroids), g[name + "/centroids0"]), name
+        km.cluster()
+        assert np.array_equal(np.array(km.assign_hist), g[name + "/assign_hist"]), name
+        np.testing.assert_allclose(np.array(km.centroids), g[name + "/centroids"], rtol=1e-12, atol=1e-12, err_msg=name)
+        assert np.array_equal(km.mask_centroids, g[name + "/mask_centroids"]), name
+        assert np.array_equal(km.clustering_results, g[name + "/clustering_results"]), name
+        d_ref = g[name + "/distances"]
+        np.testing.assert_allclose(np.where(np.isfinite(km.distances), km.distances, np.nan), d_ref, rtol=1e-11, atol=1e-12, equal_nan=True, err_msg=name)
+        km.close()
     rs = np.random.RandomState(5)
     n, d, K = 700, 90, 6
     centres = rs.normal(0, 4, (K, d))
@@ -173,24 +188,13 @@ def test_device_kmeans_equals_host_kmeans():
     X = centres[lab] + rs.normal(0, 0.5, (n, d))
     M = (rs.rand(n, d) > 0.3).astype(float)
     M[np.arange(n), rs.randint(d, size=n)] = 1
-    res = {}
-    for dev in (None, 0):
-        km = KMeans(X, M, K, device=dev)
-        km.initialise(seed=11)
-        km.cluster()
-        res[dev] = (km.clustering_results.copy(), km.centroids.copy(), km.mask_centroids.copy())
-    assert np.array_equal(res[None][0], res[0][0])
-    assert np.abs(res[None][1] - res[0][1]).max() < 1e-5 * np.abs(res[None][1]).max()
-    assert np.array_equal(res[None][2], res[0][2])
-    # each true group ends in one cluster
-    rows = res[0][0].argmax(axis=1)
-    assert all(len(set(rows[lab == g])) == 1 for g in range(K))
-    # more clusters than natural groups: the empty-cluster rule runs on both paths alike
-    out = []
-    for dev in (None, 0):
-        km = KMeans(X[:60], M[:60], 9, device=dev)
-        km.initialise(seed=3)
-        km.cluster()
-        out.append(km.clustering_results.copy())
-        assert out[-1].sum(axis=0).min() >= 1
-    assert np.array_equal(out[0], out[1])
+    for Kc, seed, nn in ((K, 11, n), (9, 3, 60), (45, 2, 300)):          # natural groups; clusters that run empty; K above one sums pass (40)
+        km = KMeans(X[:nn], M[:nn], Kc, device=0); km.initialise(seed=seed); km.cluster()
+        ko = KMeansOracle(X[:nn], M[:nn], Kc); ko.initialise(seed=seed); ko.cluster()
+        assert np.array_equal(np.array(km.assign_hist), np.array(ko.assign_hist))
+        np.testing.assert_allclose(np.array(km.centroids), np.array(ko.centroids), rtol=1e-11, atol=1e-11)
+        assert np.array_equal(km.mask_centroids, ko.mask_centroids)
+        if Kc == K:
+            rows = km.clustering_results.argmax(axis=1)
+            assert all(len(set(rows[lab == gq])) == 1 for gq in range(K))     # each true group ends in one cluster
+        km.close()

@@ -27,9 +27,13 @@ def _ragged_mask(rs, I, J, lo, hi):
     return M
 
 
-@pytest.mark.parametrize("I,J,K,lo,hi", [(300, 420, 7, 0.0, 0.3), (513, 389, 32, 0.05, 0.5), (640, 800, 64, 0.0, 0.9), (257, 1100, 40, 0.1, 0.2)])
-def test_wide_kernel_equals_generic_kernel_and_oracle(monkeypatch, I, J, K, lo, hi):
+@pytest.mark.parametrize("I,J,K,lo,hi,turns", [(300, 420, 7, 0.0, 0.3, "0"), (513, 389, 32, 0.05, 0.5, "0"), (640, 800, 64, 0.0, 0.9, "0"), (257, 1100, 40, 0.1, 0.2, "0"),
+                                               (640, 800, 64, 0.0, 0.9, "1"), (257, 1100, 40, 0.1, 0.2, "1")])
+def test_wide_kernel_equals_generic_kernel_and_oracle(monkeypatch, I, J, K, lo, hi, turns):
+    """turns = "1": the same layout run by kernel_sweep_turns.hip (BNMTF_TURNS=1: 8-wave blocks, two groups of units taking
+    turns; an experiment kept in the tree -- its own order of the floating-point sums, the same draws)."""
     monkeypatch.setenv("BNMTF_WIDE", "1")
+    monkeypatch.setenv("BNMTF_TURNS", turns)
     rs = np.random.RandomState(I + J)
     U0 = rs.exponential(1.0, (I, K)); V0 = rs.exponential(1.0, (J, K))
     R = U0 @ V0.T + rs.randn(I, J)
@@ -41,7 +45,7 @@ def test_wide_kernel_equals_generic_kernel_and_oracle(monkeypatch, I, J, K, lo, 
         if path == "generic":
             b.set_sweep_path(False)
         else:
-            assert "wide" in b.describe() or True
+            assert ("turns=1" in b.describe()) == (turns == "1") and "sweep_nw=16" in b.describe()
         b.run(4)
         runs[path] = (b.all_U.copy(), b.all_V.copy(), b.all_tau.copy(), np.array(b.all_performances["MSE"]))
     w, g = runs["wide"], runs["generic"]
