@@ -75,46 +75,66 @@ class ControlPlane(object):
                 try:
                     srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
                     srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-                    srv.bind(("", p))
+                    srv.bind((addr if self._is_local(addr) else "", p))       # the rendezvous address only, not every interface
                     break
                 except OSError:
                     srv.close(); srv = None
             if srv is None:
                 raise _lib.BnmtfError("control plane: no free port in %d..%d" % (base, base + _PORT_TRIES - 1))
             srv.listen(self.world)
-            srv.settimeout(timeout)
             got = {}
             while len(got) < self.world - 1:
-                conn, _ = srv.accept()
-                conn.settimeout(timeout)
-                hello = _recv(conn)
-                if not hello.startswith(_MAGIC):
-                    conn.close(); continue
-                (r,) = struct.unpack("<I", hello[len(_MAGIC):len(_MAGIC) + 4])
-                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                _send(conn, _MAGIC)
-                got[r] = conn
+                left = deadline - time.time()
+                if left <= 0:
+                    srv.close()
+                    raise _lib.BnmtfError("control plane: only %d of %d ranks joined within %.0f s" % (len(got) + 1, self.world, timeout))
+                srv.settimeout(left)
+                try:
+                    conn, _ = srv.accept()
+                except socket.timeout:
+                    continue
+                # a stray connection that says nothing (or the wrong thing) is dropped after a short wait; it must not
+                # hold up, let alone end, the job
+                try:
+                    conn.settimeout(5.0)
+                    hello = _recv(conn)
+                    (r,) = struct.unpack("<I", hello[len(_MAGIC):len(_MAGIC) + 4]) if hello.startswith(_MAGIC) and len(hello) >= len(_MAGIC) + 4 else (None,)
+                    if r is None or not (1 <= r < self.world) or r in got:
+                        conn.close(); continue
+                    conn.settimeout(timeout)
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    _send(conn, _MAGIC)
+                    got[r] = conn
+                except (OSError, ConnectionError, struct.error):
+                    conn.close()
             srv.close()
             self.peers = [got[r] for r in range(1, self.world)]
         else:
             while True:
                 for p in range(base, base + _PORT_TRIES):
+                    s = None
                     try:
                         s = socket.create_connection((addr, p), timeout=2.0)
-                        s.settimeout(timeout)
+                        s.settimeout(10.0)
                         _send(s, _MAGIC + struct.pack("<I", self.rank))
                         if _recv(s) == _MAGIC:
+                            s.settimeout(timeout)
                             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                             self.sock = s
                             break
                         s.close()
-                    except OSError:
-                        pass
+                    except (OSError, ConnectionError):
+                        if s is not None:
+                            s.close()
                 if self.sock is not None:
                     break
                 if time.time() > deadline:
                     raise _lib.BnmtfError("control plane: rank %d could not reach rank 0 at %s:%d.." % (self.rank, addr, base))
                 time.sleep(0.05)
+
+    @staticmethod
+    def _is_local(addr):
+        return addr in ("127.0.0.1", "localhost", "::1")
 
     def broadcast(self, payload=None):
         if self.world == 1:
@@ -179,7 +199,20 @@ def spawn_local(n, argv, env=None):
     for r in range(n):
         e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable] + list(argv), env=e))
+    # all ranks are polled together: one that dies early takes the others with it instead of leaving them at a barrier
+    # until their own timeout
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            rc = max(rc, abs(code))
+            if code != 0:
+                for q in alive:
+                    q.terminate()
+        if alive:
+            time.sleep(0.05)
     return rc

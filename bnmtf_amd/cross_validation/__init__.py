@@ -5,7 +5,8 @@ GPU, each building its own handles -- and a candidate's posterior means are accu
 
 Same class names, constructor arguments, methods and log-file lines as the reference
 (line_search_bnmf.LineSearch, grid_search_bnmtf.GridSearch, greedy_search_bnmtf.GreedySearch,
-line_search_cross_validation.LineSearchCrossValidation, matrix_cross_validation.MatrixCrossValidation,
+line_search_cross_validation.LineSearchCrossValidation, greedy_search_cross_validation.GreedySearchCrossValidation,
+matrix_cross_validation.MatrixCrossValidation,
 parallel_matrix_cross_validation.ParallelMatrixCrossValidation, mask.*); build-only extras are keyword-only
 (`pool=`, a ReplicaPool)."""
 from . import mask
@@ -14,8 +15,9 @@ from .line_search_bnmf import LineSearch
 from .grid_search_bnmtf import GridSearch
 from .greedy_search_bnmtf import GreedySearch
 from .line_search_cross_validation import LineSearchCrossValidation
+from .greedy_search_cross_validation import GreedySearchCrossValidation
 from .matrix_cross_validation import MatrixCrossValidation
 from .parallel_matrix_cross_validation import ParallelMatrixCrossValidation
 
-__all__ = ["mask", "ReplicaPool", "LineSearch", "GridSearch", "GreedySearch", "LineSearchCrossValidation",
+__all__ = ["mask", "ReplicaPool", "LineSearch", "GridSearch", "GreedySearch", "LineSearchCrossValidation", "GreedySearchCrossValidation",
            "MatrixCrossValidation", "ParallelMatrixCrossValidation"]

@@ -1,16 +1,53 @@
-"""code/cross_validation/matrix_cross_validation.py (class MatrixCrossValidation): K-fold cross-validation of a method
-over a list of parameter settings; a fold is `method(X, train, **parameters).train(**train_config).predict(test)`."""
+"""K-fold cross-validation of a method over a list of parameter settings, as one batch of device jobs.
+
+Mirrors the contract of the reference's MatrixCrossValidation (code/cross_validation/matrix_cross_validation.py:47-148:
+constructor arguments, `run()`, `find_best_parameters(criterion, low_better)`, the attributes `all_performances`,
+`average_performances`, `performances`, `best_*`, and the three kinds of log line) -- but the work is organised around
+what is new here: a fold is an independent model, so `run()` first PLANS every (parameter setting, fold) pair -- drawing
+each setting's folds from Python's `random` stream in the order the reference draws them -- then EXECUTES the whole plan
+as one job list on a ReplicaPool (all settings and folds side by side on the GPU slots, not one setting after the
+other), and only then RECORDS the results setting by setting, writing the reference's log lines in its order.  A setting
+whose folds cannot be drawn, or any of whose models raises, is logged with the reference's "Tried parameters ... but got
+exception" line (:79-81) and skipped, like there.
+
+`ParallelMatrixCrossValidation` (parallel_matrix_cross_validation.py) is this class with P slots.
+"""
 import json
 
 import numpy
 
 from . import mask
+from .replicas import ReplicaError, ReplicaPool, _accepts
 
 attempts_generate_M = 1000
 
 
-class MatrixCrossValidation:
-    def __init__(self, method, X, M, K, parameter_search, train_config, file_performance):
+def fold_job(job, shared):
+    """One fold on the worker's GPU: `method(X, train, **parameters).train(**train_config).predict(test)` (:85-88)."""
+    method = job["method"]
+    kw = dict(job["parameters"])
+    if _accepts(method.__init__, "device"):
+        kw["device"] = job.get("device", 0)
+    if _accepts(method.__init__, "verbose"):
+        kw.setdefault("verbose", False)
+    model = method(shared["X"], job["train"], **kw)
+    try:
+        model.train(**job["train_config"])
+        return model.predict(job["test"])
+    finally:
+        if hasattr(model, "close"):
+            model.close()
+
+
+class _Setting(object):
+    """One entry of parameter_search in the plan: its key, its folds (or why it has none), later its fold results."""
+    def __init__(self, parameters, key):
+        self.parameters, self.key = parameters, key
+        self.folds, self.error, self.results = [], None, None
+
+
+class MatrixCrossValidation(object):
+    def __init__(self, method, X, M, K, parameter_search, train_config, file_performance, *, devices=None):
         self.method = method
         self.X = numpy.array(X, dtype=float)
         self.M = numpy.array(M)
@@ -20,74 +57,96 @@ class MatrixCrossValidation:
         self.fout = open(file_performance, 'w')
         (self.I, self.J) = self.X.shape
         assert (self.X.shape == self.M.shape), "X and M are of different shapes: %s and %s respectively." % (self.X.shape, self.M.shape)
-        self.all_performances = {}
-        self.average_performances = {}
-        self.performances = {}
+        self.devices = [0] if devices is None else list(devices)      # replica slots (ParallelMatrixCrossValidation: P of them)
+        self.all_performances = {}          # JSON(parameters) -> {measure: [value per fold]}
+        self.average_performances = {}      # JSON(parameters) -> {measure: mean over the folds}
+        self.performances = {}              # measure -> [mean, one per recorded setting, in parameter_search order]
 
+    # ------------------------------------------------------------------ plan -> execute -> record
     def run(self):
-        """:62-81."""
-        for parameters in self.parameter_search:
-            try:
-                folds_test = mask.compute_folds_attempts(I=self.I, J=self.J, no_folds=self.K, attempts=attempts_generate_M, M=self.M)
-                folds_training = mask.compute_Ms(folds_test)
-                self.all_performances[self.JSON(parameters)] = {}
-                for performance_dict in self.run_folds(folds_training, folds_test, parameters):
-                    self.store_performances(performance_dict, parameters)
-                self.log(parameters)
-            except Exception as e:      # noqa: BLE001 -- the reference logs and carries on (:79-81)
-                self.fout.write("Tried parameters %s but got exception: %s. \n" % (parameters, e))
-                self.fout.flush()
+        plan = self._plan()
+        self._execute(plan)
+        for setting in plan:
+            self._record(setting)
 
-    def run_folds(self, folds_training, folds_test, parameters):
-        return [self.run_model(train, test, parameters) for train, test in zip(folds_training, folds_test)]
+    def _plan(self):
+        plan = []
+        for parameters in self.parameter_search:
+            setting = _Setting(parameters, self.JSON(parameters))
+            try:
+                tests = mask.compute_folds_attempts(I=self.I, J=self.J, no_folds=self.K, attempts=attempts_generate_M, M=self.M)
+                setting.folds = list(zip(mask.compute_Ms(tests), tests))
+            except Exception as e:      # noqa: BLE001 -- reported by _record in the reference's words
+                setting.error = e
+            plan.append(setting)
+        return plan
+
+    def _execute(self, plan):
+        jobs, owner = [], []
+        for si, setting in enumerate(plan):
+            for train, test in setting.folds:
+                jobs.append(dict(method=self.method, parameters=setting.parameters, train=train, test=test, train_config=self.train_config))
+                owner.append(si)
+        if not jobs:
+            return
+        with ReplicaPool(devices=self.devices, shared={"X": self.X}) as pool:
+            out = pool.map(fold_job, jobs, errors="return")
+        for setting in plan:
+            setting.results = []
+        for si, res in zip(owner, out):
+            plan[si].results.append(res)
+
+    def _record(self, setting):
+        failed = setting.error
+        if failed is None:
+            failed = next((r for r in setting.results or [] if isinstance(r, ReplicaError)), None)
+        if failed is not None:
+            text = failed.first_line.split(": ", 1)[-1] if isinstance(failed, ReplicaError) else failed
+            self.fout.write("Tried parameters %s but got exception: %s. \n" % (setting.parameters, text))
+            self.fout.flush()
+            return
+        self.all_performances[setting.key] = {}
+        for fold_result in setting.results:
+            self.store_performances(fold_result, setting.parameters)
+        self.log(setting.parameters)
 
     def run_model(self, train, test, parameters):
-        """:85-88."""
-        model = self.method(self.X, train, **parameters)
-        model.train(**self.train_config)
-        return model.predict(test)
+        """One fold in this process on the first slot (the reference's per-fold entry point)."""
+        return fold_job(dict(method=self.method, parameters=parameters, train=train, test=test, train_config=self.train_config, device=self.devices[0]),
+                        {"X": self.X})
 
+    # ------------------------------------------------------------------ bookkeeping (names and formats are the contract)
     def JSON(self, d):
-        """:91-98."""
-        d_copy = d.copy()
-        for key, val in d.items():
-            if isinstance(val, numpy.ndarray):
-                d_copy[key] = val.tolist()
-        return json.dumps(d_copy, sort_keys=True)
+        return json.dumps({k: (v.tolist() if isinstance(v, numpy.ndarray) else v) for k, v in d.items()}, sort_keys=True)
 
     def store_performances(self, performance_dict, parameters):
-        """:101-106."""
-        for name in performance_dict:
-            self.all_performances[self.JSON(parameters)].setdefault(name, []).append(performance_dict[name])
+        per_measure = self.all_performances[self.JSON(parameters)]
+        for measure, value in performance_dict.items():
+            per_measure.setdefault(measure, []).append(value)
 
     def compute_average_performances(self, parameters):
-        """:109-119."""
-        performances = self.all_performances[self.JSON(parameters)]
-        average_performances = {name: (sum(values) / float(len(values))) for (name, values) in performances.items()}
-        self.average_performances[self.JSON(parameters)] = average_performances
-        for (name, avr_perf) in average_performances.items():
-            self.performances.setdefault(name, []).append(avr_perf)
+        key = self.JSON(parameters)
+        means = {measure: sum(vals) / float(len(vals)) for measure, vals in self.all_performances[key].items()}
+        self.average_performances[key] = means
+        for measure, mean in means.items():
+            self.performances.setdefault(measure, []).append(mean)
 
     def find_best_parameters(self, evaluation_criterion, low_better):
-        """:122-131."""
-        min_or_max = min if low_better else max
-        self.best_performance = min_or_max(self.performances[evaluation_criterion])
-        index_best = self.performances[evaluation_criterion].index(self.best_performance)
-        self.best_parameters = self.parameter_search[index_best]
+        scores = self.performances[evaluation_criterion]
+        self.best_performance = min(scores) if low_better else max(scores)
+        position = scores.index(self.best_performance)
+        self.best_parameters = self.parameter_search[position]
         self.best_performances_all = self.average_performances[self.JSON(self.best_parameters)]
-        self.log_best(index_best)
+        self.log_best(position)
         return (self.best_parameters, self.best_performance)
 
     def log(self, parameters):
-        """:134-138."""
         self.compute_average_performances(parameters)
-        message = "Tried parameters %s. Average performances: %s. \nAll performances: %s. \n" % (
-            parameters, self.average_performances[self.JSON(parameters)], self.all_performances[self.JSON(parameters)])
-        self.fout.write(message)
+        key = self.JSON(parameters)
+        self.fout.write("Tried parameters %s. Average performances: %s. \nAll performances: %s. \n" % (
+            parameters, self.average_performances[key], self.all_performances[key]))
         self.fout.flush()
 
     def log_best(self, index_best):
-        """:141-148."""
-        message = "Best performances: %s. Best parameters: %s. \n" % (self.best_performances_all, self.best_parameters)
-        self.fout.write(message)
+        self.fout.write("Best performances: %s. Best parameters: %s. \n" % (self.best_performances_all, self.best_parameters))
         self.fout.flush()

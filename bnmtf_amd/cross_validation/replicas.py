@@ -43,6 +43,14 @@ def _call(args):
         return ("error", "%s: %s\n%s" % (type(e).__name__, e, traceback.format_exc()))
 
 
+class ReplicaError(Exception):
+    """A job's exception as it comes back from a worker: str() is "<Type>: <message>" followed by the worker's traceback;
+    `.first_line` is the part a log line wants."""
+    @property
+    def first_line(self):
+        return str(self).split("\n", 1)[0]
+
+
 class ReplicaPool(object):
     def __init__(self, devices=None, shared=None):
         """devices: list of device ordinals, one worker each (repeat an ordinal to run several models on one GPU at
@@ -63,9 +71,10 @@ class ReplicaPool(object):
                 q.put(d)
             self._pool = ctx.Pool(len(self.devices), initializer=_init_worker, initargs=(q, self.shared))
 
-    def map(self, fn, jobs):
+    def map(self, fn, jobs, errors="raise"):
         """fn(job, shared) -> result for every job, results in job order; job gets a 'device' entry.  An exception in
-        any job is raised here (after all jobs have run) with the worker's traceback."""
+        any job is raised here (after all jobs have run) with the worker's traceback -- or, with errors="return", comes
+        back in the job's place as a ReplicaError (a caller that logs a failed setting and carries on)."""
         jobs = list(jobs)
         if len(self.devices) <= 1:                      # single slot: in this process, like the reference's serial loops
             _worker_device[0] = self.devices[0] if self.devices else 0
@@ -75,9 +84,9 @@ class ReplicaPool(object):
             self._start()
             out = self._pool.map(_call, [(fn, j) for j in jobs], chunksize=1)
         errs = [r[1] for r in out if r[0] == "error"]
-        if errs:
+        if errs and errors == "raise":
             raise RuntimeError("%d of %d replica jobs failed; first:\n%s" % (len(errs), len(jobs), errs[0]))
-        return [r[1] for r in out]
+        return [ReplicaError(r[1]) if r[0] == "error" else r[1] for r in out]
 
     def close(self):
         if self._pool is not None:

@@ -295,10 +295,10 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
     for (int k = 0; k < W; ++k) lam[(size_t)ul * d.KP + k] = (float)lambda[(size_t)(d.n0 + ul) * W + k];
   CHK(dalloc(&d.lambda, lam.size(), false));
   HIPCHK(hipMemcpy(d.lambda, lam.data(), lam.size() * sizeof(float), hipMemcpyHostToDevice));
-  CHK(dalloc(&d.C64, (size_t)64 * 64));
+  // C64 | colsum | colsum2 in one piece: what a multi-GPU run sums over the ranks with ONE all-reduce (exchange_factor)
+  CHK(dalloc(&d.C64, (size_t)64 * 64 + 128));
+  d.colsum = d.C64 + 64 * 64; d.colsum2 = d.colsum + 64; d.gram_packed = true;
   CHK(dalloc(&d.C32, (size_t)64 * 64));
-  CHK(dalloc(&d.colsum, 64));
-  CHK(dalloc(&d.colsum2, 64));
   CHK(dalloc(&d.numer, (size_t)std::max(d.n, 1)));
   CHK(dalloc(&d.taup, (size_t)std::max(d.n, 1)));
   return BNMTF_OK;
@@ -319,7 +319,12 @@ static int alloc_factor(Dir& d, int other_inner_pad) {
 
 static void free_dir(Dir& d) {
   dfree(d.big); dfree(d.slabs); dfree(d.lambda); dfree(d.slot_ptr); dfree(d.idx); dfree(d.q);
-  dfree(d.X); dfree(d.XT); dfree(d.C64); dfree(d.C32); dfree(d.colsum); dfree(d.colsum2);
+  dfree(d.X); dfree(d.XT); dfree(d.C64); dfree(d.C32);
+  if (!d.gram_packed) { dfree(d.colsum); dfree(d.colsum2); }
+  if (d.ev_sweep) (void)hipEventDestroy(d.ev_sweep);
+  if (d.ev_gram) (void)hipEventDestroy(d.ev_gram);
+  if (d.ev_gathered) (void)hipEventDestroy(d.ev_gathered);
+  if (d.ev_gram_all) (void)hipEventDestroy(d.ev_gram_all);
   dfree(d.XT2); dfree(d.Cpart); dfree(d.spart); dfree(d.s2part); dfree(d.f_unit_map); dfree(d.f_pair_E);
   dfree(d.f_pair_base); dfree(d.f_off); dfree(d.f_off16); dfree(d.stats); dfree(d.f_gen_units);
   dfree(d.vb_stats);
@@ -376,6 +381,41 @@ static void enqueue_post(bnmtf_model* h, Dir& d, bool vb = false) {
   g.Cpart = d.Cpart; g.spart = d.spart; g.C64 = d.C64; g.C32 = d.C32; g.colsum = d.colsum;
   if (vb) { g.S2 = d.S2; g.S2T = d.S2T; g.s2part = d.s2part; g.colsum2 = d.colsum2; g.XS = d.XS; }
   launch_post(g, h->stream);
+}
+// Several GPUs, after a half sweep: the block of X this rank has just drawn goes to the other ranks (all-gather on the
+// exchange stream) WHILE the rank forms the Gram partial and the column sums of its own rows; the partials -- one buffer,
+// C64 | colsum -- are then summed over the ranks by one all-reduce (north_star's "all-reduce on the K x K Gram matrices";
+// every rank used to form the whole Gram from the gathered factor), which runs beside the relayout of the gathered factor
+// and the next contraction.  The compute stream waits for the gathered factor here and for the summed Gram in await_gram(),
+// just ahead of its first reader.  Every collective is issued on the ONE exchange stream, in the same order on all ranks.
+static int exchange_factor(bnmtf_model* h, Dir& d) {
+  if (!h->comm) { enqueue_post(h, d); return BNMTF_OK; }
+  if (!h->xchg_stream) HIPCHK(hipStreamCreateWithFlags(&h->xchg_stream, hipStreamNonBlocking));
+  for (hipEvent_t* e : {&d.ev_sweep, &d.ev_gram, &d.ev_gathered, &d.ev_gram_all})
+    if (!*e) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  PostArgs g;
+  memset(&g, 0, sizeof(g));
+  g.X = d.X; g.rows = d.nglob; g.KP = d.KP; g.XT = d.XT; g.ldT = d.ldT; g.XT2 = d.XT2; g.ld2 = d.ldT;
+  g.Cpart = d.Cpart; g.spart = d.spart; g.C64 = d.C64; g.C32 = d.C32; g.colsum = d.colsum;
+  HIPCHK(hipEventRecord(d.ev_sweep, h->stream));
+  launch_post_gram_rows(g, d.n0, d.n0 + d.n, h->stream);             // own rows only: they are final, whatever the others send
+  HIPCHK(hipEventRecord(d.ev_gram, h->stream));
+  HIPCHK(hipStreamWaitEvent(h->xchg_stream, d.ev_sweep, 0));
+  CHK(comm_allgather_factor(h->comm, d.X, d.KP, d.nglob, h->world, h->xchg_stream));
+  HIPCHK(hipEventRecord(d.ev_gathered, h->xchg_stream));
+  HIPCHK(hipStreamWaitEvent(h->xchg_stream, d.ev_gram, 0));
+  CHK(comm_allreduce_sum(h->comm, d.C64, 64 * 64 + 64, h->xchg_stream));          // C64 | colsum
+  launch_gram_cast(d.C64, d.C32, d.KP * d.KP, h->xchg_stream);
+  HIPCHK(hipEventRecord(d.ev_gram_all, h->xchg_stream));
+  d.gram_pending = true;
+  HIPCHK(hipStreamWaitEvent(h->stream, d.ev_gathered, 0));
+  launch_post_layout(g, h->stream);
+  return BNMTF_OK;
+}
+// the summed Gram of d (C32, C64, colsum) is about to be read on the compute stream
+static int await_gram(bnmtf_model* h, Dir& d) {
+  if (d.gram_pending) { HIPCHK(hipStreamWaitEvent(h->stream, d.ev_gram_all, 0)); d.gram_pending = false; }
+  return BNMTF_OK;
 }
 static void enqueue_sweep(bnmtf_model* h, Dir& d, const Dir& other, SweepArgs& s, bool want_stats) {
   s.unit_list = nullptr;
@@ -749,6 +789,7 @@ int bnmtf_destroy(bnmtf_handle h) {
   }
   dfree(h->snap_dev);
   if (h->snap_host) (void)hipHostFree(h->snap_host);
+  if (h->xchg_stream) { (void)hipStreamSynchronize(h->xchg_stream); (void)hipStreamDestroy(h->xchg_stream); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return BNMTF_OK;
@@ -904,17 +945,18 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
     CHK(sink.open_slot(it));
     // ---- U columns: P = R~ . V, then the K sequential row-wise updates
     enqueue_gemm(h, r, c, BNMTF_KERNEL_GEMM_ROWS);
+    CHK(await_gram(h, c));                       // V^T V of the previous iteration's exchange
     {
       ScopedKernelTimer t(h, BNMTF_KERNEL_SWEEP_ROWS);
       SweepArgs s = sweep_args(h, r, c, mode, kStreamRows);
       enqueue_sweep(h, r, c, s, false);
     }
-    if (h->comm) CHK(comm_allgather_factor(h->comm, r.X, r.KP, r.nglob, h->world, h->stream));
+    CHK(exchange_factor(h, r));                  // one GPU: relayout + Gram; several: see exchange_factor
     sink.snapshot(it, r.X);
-    enqueue_post(h, r);
     // ---- V columns: Pv = R~^T . U
     enqueue_gemm(h, c, r, BNMTF_KERNEL_GEMM_COLS);
     if (acc_used && it > 0) HIPCHK(hipMemsetAsync(h->acc, 0, 4 * sizeof(double), h->stream));
+    CHK(await_gram(h, r));
     {
       ScopedKernelTimer t(h, BNMTF_KERNEL_SWEEP_COLS);
       SweepArgs s = sweep_args(h, c, r, mode, kStreamCols);
@@ -922,14 +964,16 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
       enqueue_sweep(h, c, r, s, true);
     }
     const bool fast_stats = h->last_sweep_fast;
+    if (h->comm && fast_stats) launch_sum_stats(c.stats, c.stats_blocks, h->acc, h->stream);   // fold the slab before the exchange
+    CHK(exchange_factor(h, c));
     if (h->comm) {
-      CHK(comm_allgather_factor(h->comm, c.X, c.KP, c.nglob, h->world, h->stream));
-      if (fast_stats) launch_sum_stats(c.stats, c.stats_blocks, h->acc, h->stream);   // fold the slab before the exchange
-      CHK(comm_allreduce_sum(h->comm, h->acc, 4, h->stream));
+      // the three sums of the SSE identity: behind the Gram on the exchange stream (its event covers the fold above)
+      CHK(comm_allreduce_sum(h->comm, h->acc, 4, h->xchg_stream));
+      HIPCHK(hipEventRecord(c.ev_gram_all, h->xchg_stream));
     }
     sink.snapshot(it, c.X);
     CHK(sink.close_slot(it));
-    enqueue_post(h, c);
+    CHK(await_gram(h, c)); CHK(await_gram(h, r));
     // ---- tau and the metrics of this sample
     FinishArgs f;
     f.Cr64 = r.C64; f.Cc64 = c.C64; f.sr = r.colsum; f.sc = c.colsum; f.KP = r.KP;

@@ -21,18 +21,20 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
   __shared__ float tile0[RB * 68], tile1[RB * 68];     // X rows ; VB: S2 rows
   constexpr int LD = 68;
   const int KP = a.KP, tid = threadIdx.x;
-  const int r0 = blockIdx.x * RB;
+  const int r0 = (a.blk0 + blockIdx.x) * RB;
   const int nr = min(RB, a.rows - r0);
   // two blocks per row group (blockIdx.y): one writes the layouts, the other forms the Gram partial and the column sums.
   // Each is half as long, and twice as many blocks hide each other's load -> store / load -> FMA latencies.
-  const bool do_layout = blockIdx.y == 0, do_gram = blockIdx.y == 1;
+  // (a launch that does only one of the two has one block per group)
+  const bool do_layout = a.do_layout && (!a.do_gram || blockIdx.y == 0), do_gram = a.do_gram && (!a.do_layout || blockIdx.y == 1);
   const float* src = a.X;
   for (int pass = 0; pass < (a.S2 ? 2 : 1); ++pass) {
     float* tile = pass == 0 ? tile0 : tile1;
     if (pass == 1) src = a.S2;
     for (int t = tid; t < RB * KP; t += 256) {
       const int r = t / KP, k = t % KP;
-      tile[r * LD + k] = (r < nr) ? src[(size_t)(r0 + r) * KP + k] : 0.f;
+      // (Gram-only launches of a multi-GPU run: rows of other ranks count as zero)
+      tile[r * LD + k] = (r < nr && (do_layout || (r0 + r >= a.own0 && r0 + r < a.own1))) ? src[(size_t)(r0 + r) * KP + k] : 0.f;
     }
     __syncthreads();
     float* T1 = pass == 0 ? a.XT : a.S2T;
@@ -151,11 +153,37 @@ __global__ __launch_bounds__(1024) void gram_reduce_kernel(PostArgs a, int nblk)
   }
 }
 
-void launch_post(const PostArgs& a, hipStream_t st) {
+void launch_post(const PostArgs& a0, hipStream_t st) {
+  PostArgs a = a0;
+  a.do_layout = 1; a.do_gram = 1; a.blk0 = 0; a.own0 = 0; a.own1 = a.rows;
   const int nblk = post_blocks(a.rows);
   hipLaunchKernelGGL(post_kernel, dim3(nblk, 2), dim3(256), 0, st, a);
   const int nt = a.KP / 4, ps = nt * (nt + 1) / 2 * 16;
   hipLaunchKernelGGL(gram_reduce_kernel, dim3((ps + 31) / 32 + 1), dim3(1024), 0, st, a, nblk);
+}
+
+void launch_post_layout(const PostArgs& a0, hipStream_t st) {
+  PostArgs a = a0;
+  a.do_layout = 1; a.do_gram = 0; a.blk0 = 0; a.own0 = 0; a.own1 = a.rows;
+  hipLaunchKernelGGL(post_kernel, dim3(post_blocks(a.rows), 1), dim3(256), 0, st, a);
+}
+
+void launch_post_gram_rows(const PostArgs& a0, int own0, int own1, hipStream_t st) {
+  PostArgs a = a0;
+  a.do_layout = 0; a.do_gram = 1; a.own0 = own0; a.own1 = own1;
+  a.blk0 = own0 / kPostRows;
+  const int nblk = own1 > own0 ? (own1 + kPostRows - 1) / kPostRows - a.blk0 : 0;
+  if (nblk > 0) hipLaunchKernelGGL(post_kernel, dim3(nblk, 1), dim3(256), 0, st, a);
+  const int nt = a.KP / 4, ps = nt * (nt + 1) / 2 * 16;
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3((ps + 31) / 32 + 1), dim3(1024), 0, st, a, nblk);     // no rows: zeros
+}
+
+__global__ void gram_cast_kernel(const double* C64, float* C32, int n) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) C32[t] = (float)C64[t];
+}
+void launch_gram_cast(const double* C64, float* C32, int n, hipStream_t st) {
+  hipLaunchKernelGGL(gram_cast_kernel, dim3((n + 255) / 256), dim3(256), 0, st, C64, C32, n);
 }
 
 }  // namespace bnmtf

@@ -125,8 +125,15 @@ struct PostArgs {
   // VB: second moment matrix S2 = var + exp^2
   const float* S2; float* S2T; double* s2part; double* colsum2;
   float* XS;                             // VB: [KP][ldT][2] (E, S2) interleaved per row: pair panels of the fast VB sweep, or null
+  // which half of the work a launch does (launch_post: both, every row).  Several GPUs: the Gram partial is formed over the
+  // rank's OWN rows [own0, own1) only (blocks blk0 .. of 32 rows; rows outside the range count as zero) and the partial
+  // C64 | colsum is summed over the ranks by one all-reduce; the layouts are written for all rows once they are gathered.
+  int do_layout, do_gram, blk0, own0, own1;
 };
 void launch_post(const PostArgs& a, hipStream_t st);
+void launch_post_layout(const PostArgs& a, hipStream_t st);                       // XT / XT2 (/ S2T / XS) of every row
+void launch_post_gram_rows(const PostArgs& a, int own0, int own1, hipStream_t st);   // C64, colsum (, colsum2) of the rows [own0, own1) only
+void launch_gram_cast(const double* C64, float* C32, int n, hipStream_t st);      // C32 = (float) C64 after the partial sums were all-reduced
 constexpr int kPostRows = 32;
 inline int post_blocks(int rows) { return (rows + kPostRows - 1) / kPostRows; }
 

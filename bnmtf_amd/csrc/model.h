@@ -63,6 +63,9 @@ struct Dir {
   bool use_turns = false;                // the wide layout run by kernel_sweep_turns.hip (two unit groups per block taking turns)
   bool use_wide = false;                 // 16-wave sweep kernel (pairs dealt to blocks per wave class) instead of the 8-wave one
   double* C64 = nullptr; float* C32 = nullptr; double* colsum = nullptr;   // Gram of X
+  bool gram_packed = false;             // colsum / colsum2 live behind C64 in one allocation (what exchange_factor all-reduces)
+  hipEvent_t ev_sweep = nullptr, ev_gram = nullptr, ev_gathered = nullptr, ev_gram_all = nullptr;   // exchange_factor (several GPUs)
+  bool gram_pending = false;            // the summed Gram is still on its way on the exchange stream
   // VB only
   float *mu = nullptr, *tauq = nullptr, *var = nullptr, *S2 = nullptr, *S2T = nullptr;
   float *XS = nullptr, *vb_asq = nullptr, *vb_vsq = nullptr;   // fast VB sweep: (E, S2) pair panels; per (unit, column) sums for the ELBO pieces
@@ -85,6 +88,7 @@ struct bnmtf_model {
   uint64_t seed = 0, iteration = 0;
   int device = 0, rank = 0, world = 1;
   hipStream_t stream = nullptr;
+  hipStream_t xchg_stream = nullptr;    // several GPUs: every collective is issued here, beside the compute stream
   bnmtf::Dir rows, cols;
   // full-matrix copies for predict()/validation
   float* Rfull = nullptr; uint8_t* Mtrain = nullptr; uint8_t* Mscratch = nullptr;

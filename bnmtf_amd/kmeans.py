@@ -114,12 +114,15 @@ class KMeans(object):
                     self._alias[c] = None
                     self.mask_centroids[c] = np.ones(self.no_coordinates)
             return
+        if self._sums is None:
+            self._device_sums()
         cnt, tot = self._sums[0][c], self._sums[1][c]
         with np.errstate(all='ignore'):
             self.centroids[c][:] = np.where(cnt > 0, tot / np.maximum(cnt, 1), 0.0)
         self.mask_centroids[c] = (cnt > 0).astype(float)
-        if self._alias[c] is not None:                    # the mean went into the data point itself: the device copy follows
+        if self._alias[c] is not None:                    # the mean went into the data point itself: the device copy follows,
             _lib.check(_lib.lib().bnmtf_kmeans_set_row(self._device_handle(), int(self._alias[c]), _lib.ptr(np.ascontiguousarray(self.X[self._alias[c]]))))
+            self._sums = None                             # and the point may by now belong to a cluster that is still to be updated
 
     def cluster(self):
         iteration = 1
