@@ -260,8 +260,9 @@ def main():
     if a.warmup > 0:
         run(a.warmup, perf_w)
         trajectory += [float(x) for x in perf_w[:a.warmup, 0]]
-    # timed regions: HIP events bracket the roofline kernel only (two records per iteration on its own stream)
-    model.set_profiling(True, kernel=_lib.KERNEL_GEMM_COLS)
+    # timed regions: HIP events bracket the roofline kernel only, on its own stream, in every fourth iteration (an event
+    # record drains the queue for ~4 us: two per iteration were 2 % of the headline iteration)
+    model.set_profiling(True, kernel=_lib.KERNEL_GEMM_COLS, every=4)
     perf_first = None
     dts = []
     for rep in range(max(1, a.repeats)):

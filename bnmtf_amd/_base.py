@@ -9,6 +9,16 @@ import numpy as np
 from . import _lib
 
 
+def check_rank(what, limit, **ranks):
+    """The reference accepts any rank; this build's kernels hold a latent factor per wave lane (K, L <= 64) and the
+    variational tri-factorisation has only the dense S system (K, L <= 32).  Said at construction, not at the first device
+    call of a search that has already fitted its smaller candidates."""
+    from ._lib import BnmtfError
+    for name, v in ranks.items():
+        if not (1 <= int(v) <= limit):
+            raise BnmtfError("%s: %s = %s is outside what this build runs (1 <= %s <= %d; DESIGN.md section 1, limits)" % (what, name, v, name, limit))
+
+
 def check_R_M(R, M):
     """bnmf_gibbs_optimised.py:59-62 and check_empty_rows_columns :82-90 (same text in
     bnmtf_gibbs_optimised.py:62-65,88-96 and bnmf_vb_optimised.py:58-61,81-89)."""
@@ -167,9 +177,10 @@ class DeviceModel(object):
         _lib.check(_lib.lib().bnmtf_describe(self._handle(), buf, 1024))
         return buf.value.decode()
 
-    def set_profiling(self, enable=True, kernel=None):
-        """Bracket kernel launches with HIP events (all listed kernels, or only `kernel`)."""
-        code = 0 if not enable else (1 if kernel is None else 2 + int(kernel))
+    def set_profiling(self, enable=True, kernel=None, every=1):
+        """Bracket kernel launches with HIP events (all listed kernels, or only `kernel`, and then only in every
+        `every`-th iteration)."""
+        code = 0 if not enable else (1 if kernel is None else 2 + int(kernel) + 32 * (max(int(every), 1) - 1))
         _lib.check(_lib.lib().bnmtf_set_profiling(self._handle(), code))
 
     def set_sweep_path(self, fast=True):

@@ -21,7 +21,7 @@ import math
 import numpy as np
 
 from . import _lib
-from ._base import DeviceModel, broadcast_lambda, check_R_M, metrics_from_sums
+from ._base import DeviceModel, broadcast_lambda, check_rank, check_R_M, metrics_from_sums
 
 
 class bnmf_gibbs_optimised(DeviceModel):
@@ -30,6 +30,7 @@ class bnmf_gibbs_optimised(DeviceModel):
         self.M = np.array(M, dtype=float)
         self.K = K
         check_R_M(self.R, self.M)
+        check_rank("bnmf_gibbs_optimised", 64, K=self.K)
         (self.I, self.J) = self.R.shape
         self.size_Omega = self.M.sum()
         self.alpha, self.beta = float(priors['alpha']), float(priors['beta'])

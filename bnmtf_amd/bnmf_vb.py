@@ -12,7 +12,7 @@ import numpy as np
 import scipy.special
 
 from . import _lib
-from ._base import DeviceModel, broadcast_lambda, check_R_M, metrics_from_sums
+from ._base import DeviceModel, broadcast_lambda, check_rank, check_R_M, metrics_from_sums
 from .distributions import TN_vector_expectation, TN_vector_variance, gamma_expectation, gamma_expectation_log
 
 
@@ -22,6 +22,7 @@ class bnmf_vb_optimised(DeviceModel):
         self.M = np.array(M, dtype=float)
         self.K = K
         check_R_M(self.R, self.M)
+        check_rank("bnmf_vb_optimised", 64, K=self.K)
         (self.I, self.J) = self.R.shape
         self.size_Omega = self.M.sum()
         self.alpha, self.beta = float(priors['alpha']), float(priors['beta'])

@@ -11,7 +11,7 @@ import math
 import numpy as np
 
 from . import _lib
-from ._base import DeviceModel, broadcast_lambda, check_R_M, metrics_from_sums
+from ._base import DeviceModel, broadcast_lambda, check_rank, check_R_M, metrics_from_sums
 from .kmeans import KMeans
 
 
@@ -22,6 +22,7 @@ class bnmtf_gibbs_optimised(DeviceModel):
         self.K = K
         self.L = L
         check_R_M(self.R, self.M)
+        check_rank("bnmtf_gibbs_optimised", 64, K=self.K, L=self.L)
         (self.I, self.J) = self.R.shape
         self.size_Omega = self.M.sum()
         self.alpha, self.beta = float(priors['alpha']), float(priors['beta'])

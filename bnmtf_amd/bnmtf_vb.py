@@ -18,7 +18,7 @@ import numpy as np
 import scipy.special
 
 from . import _lib
-from ._base import DeviceModel, broadcast_lambda, check_R_M, metrics_from_sums
+from ._base import DeviceModel, broadcast_lambda, check_rank, check_R_M, metrics_from_sums
 from .distributions import TN_vector_expectation, TN_vector_variance, gamma_expectation, gamma_expectation_log
 from .kmeans import KMeans
 
@@ -29,6 +29,7 @@ class bnmtf_vb_optimised(DeviceModel):
         self.M = np.array(M, dtype=float)
         self.K, self.L = K, L
         check_R_M(self.R, self.M)
+        check_rank("bnmtf_vb_optimised", 32, K=self.K, L=self.L)
         (self.I, self.J) = self.R.shape
         self.size_Omega = self.M.sum()
         self.alpha, self.beta = float(priors['alpha']), float(priors['beta'])

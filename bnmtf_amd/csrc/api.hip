@@ -97,8 +97,9 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
   d.gemm_tw = (d.KP == 64 && d.n_pad <= 2048) ? 2 : 4;
   if (const char* e = getenv("BNMTF_GEMM_TW")) d.gemm_tw = atoi(e) == 2 && d.KP == 64 ? 2 : 4;
   const int tiles = d.n_pad / (32 * d.gemm_tw);
-  // one resident block per CU at KP = 64 (the GEMM holds 332 registers per lane), two at KP = 32
-  int split = std::max(1, (d.KP == 64 ? 256 : 512) / tiles);
+  // one block per CU: at KP = 64 the GEMM holds 332 registers per lane (one resident block), and at KP = 32 -- where two
+  // would fit -- 256 blocks with twice the inner slice per wave beat 512 (4096^2, K = 32: 20.3 us against 23.2; round 3)
+  int split = std::max(1, 256 / tiles);
   if (const char* e = getenv("BNMTF_GEMM_SPLIT")) split = std::max(1, atoi(e));
   const int max_split = std::max(1, m / (4 * 64));
   d.split = std::min(split, max_split);
@@ -335,7 +336,7 @@ static void free_dir(Dir& d) {
 struct ScopedKernelTimer {
   bnmtf_model* h; int id; hipEvent_t a = nullptr, b = nullptr;
   bool on;
-  ScopedKernelTimer(bnmtf_model* h_, int id_) : h(h_), id(id_), on((h_->profiling >> id_) & 1u) {
+  ScopedKernelTimer(bnmtf_model* h_, int id_) : h(h_), id(id_), on(((h_->profiling >> id_) & 1u) && h_->iteration % h_->profile_stride == 0) {
     if (!on) return;
     auto get = [&]() {
       hipEvent_t e;
@@ -380,6 +381,7 @@ static void enqueue_post(bnmtf_model* h, Dir& d, bool vb = false) {
   g.X = d.X; g.rows = d.nglob; g.KP = d.KP; g.XT = d.XT; g.ldT = d.ldT; g.XT2 = d.XT2; g.ld2 = d.ldT;
   g.Cpart = d.Cpart; g.spart = d.spart; g.C64 = d.C64; g.C32 = d.C32; g.colsum = d.colsum;
   if (vb) { g.S2 = d.S2; g.S2T = d.S2T; g.s2part = d.s2part; g.colsum2 = d.colsum2; g.XS = d.XS; }
+  g.snap = d.snap_dst; g.snapW = d.W; d.snap_dst = nullptr;
   launch_post(g, h->stream);
 }
 // Several GPUs, after a half sweep: the block of X this rank has just drawn goes to the other ranks (all-gather on the
@@ -409,6 +411,7 @@ static int exchange_factor(bnmtf_model* h, Dir& d) {
   HIPCHK(hipEventRecord(d.ev_gram_all, h->xchg_stream));
   d.gram_pending = true;
   HIPCHK(hipStreamWaitEvent(h->stream, d.ev_gathered, 0));
+  g.snap = d.snap_dst; g.snapW = d.W; d.snap_dst = nullptr;
   launch_post_layout(g, h->stream);
   return BNMTF_OK;
 }
@@ -491,13 +494,17 @@ static int bnmtf_alloc_extras(bnmtf_model* h, const double* lambdaS);
 // pinned (bnmtf_host_alloc, or registered by the caller) receive the copy directly, at PCIe rate and with no host work;
 // pageable ones go through a pinned ring that the calling thread empties kDepth iterations behind the enqueue front.
 struct SampleSink {
-  static constexpr int kDepth = 4;
+  // Slots are handed over in GROUPS of kGroup iterations: one event recorded on the compute stream and one stream wait per
+  // group, not per iteration -- an event record drains the compute queue for a few microseconds each time (round 1: eight
+  // records cost 30 us per iteration).  Two groups of slots: one being filled while the other goes to the host.
+  static constexpr int kGroup = 4, kGroups = 2, kDepth = kGroup * kGroups;
   struct Mat { const float* src; int rows, W, KP; float* dst; size_t off; };
   bnmtf_model* h = nullptr;
   Mat m[3]; int nmat = 0;
   size_t per_it = 0;            // floats per iteration over all matrices
   bool active = false, direct = true;
-  int n_iter = 0;
+  int n_iter = 0, group_first = 0, drained = 0;     // first iteration of the group being filled; ring path: iterations already in the caller's arrays
+  int pending_last[kGroups] = {-1, -1};             // ring path: last iteration of the group whose copy is in flight in event slot g
 
   void add(const float* src, int rows, int W, int KP, float* dst) {
     if (!dst) return;
@@ -517,7 +524,7 @@ struct SampleSink {
     if (getenv("BNMTF_SAMPLES_RING")) direct = false;       // test hook: force the pageable path
     if (!h->copy_stream) {
       HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
-      for (int s = 0; s < kDepth; ++s) {
+      for (int s = 0; s < kGroups; ++s) {
         HIPCHK(hipEventCreateWithFlags(&h->snap_ready[s], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->copy_done[s], hipEventDisableTiming));
       }
@@ -535,18 +542,32 @@ struct SampleSink {
     }
     return BNMTF_OK;
   }
-  void drain_slot(int it) {        // ring path: iteration `it` has landed in its pinned slot -> the caller's arrays
-    const float* slot = h->snap_host + (size_t)(it % kDepth) * per_it;
-    for (int i = 0; i < nmat; ++i)
-      memcpy(m[i].dst + (size_t)it * m[i].rows * m[i].W, slot + m[i].off, (size_t)m[i].rows * m[i].W * sizeof(float));
-  }
-  // before iteration `it` is enqueued: its slot must have been taken to the host (iteration it - kDepth)
-  int open_slot(int it) {
-    if (!active || it < kDepth) return BNMTF_OK;
-    const int s = it % kDepth;
-    if (!direct) { HIPCHK(hipEventSynchronize(h->copy_done[s])); drain_slot(it - kDepth); }
-    HIPCHK(hipStreamWaitEvent(h->stream, h->copy_done[s], 0));
+  // ring path: the group in event slot g has landed in the pinned ring -> the caller's arrays
+  int drain_group(int g) {
+    if (pending_last[g] < 0) return BNMTF_OK;
+    HIPCHK(hipEventSynchronize(h->copy_done[g]));
+    for (; drained <= pending_last[g]; ++drained) {
+      const float* slot = h->snap_host + (size_t)(drained % kDepth) * per_it;
+      for (int i = 0; i < nmat; ++i)
+        memcpy(m[i].dst + (size_t)drained * m[i].rows * m[i].W, slot + m[i].off, (size_t)m[i].rows * m[i].W * sizeof(float));
+    }
+    pending_last[g] = -1;
     return BNMTF_OK;
+  }
+  // before iteration `it` is enqueued: at the start of a group its slots must have been taken to the host (the group two back)
+  int open_slot(int it) {
+    if (!active || it % kGroup != 0 || it < kDepth) return BNMTF_OK;
+    const int g = (it / kGroup) % kGroups;
+    if (!direct) CHK(drain_group(g));
+    HIPCHK(hipStreamWaitEvent(h->stream, h->copy_done[g], 0));
+    return BNMTF_OK;
+  }
+  // where matrix `src` goes in the slot of iteration `it` (the relayout kernel that follows its sweep writes it there), or null
+  float* slot_for(int it, const float* src) const {
+    if (!active) return nullptr;
+    for (int i = 0; i < nmat; ++i)
+      if (m[i].src == src) return h->snap_dev + (size_t)(it % kDepth) * per_it + m[i].off;
+    return nullptr;
   }
   // matrix `src` is final for iteration `it`: pack it into the slot (compute stream)
   void snapshot(int it, const float* src) {
@@ -554,26 +575,36 @@ struct SampleSink {
     for (int i = 0; i < nmat; ++i)
       if (m[i].src == src) launch_compact_rows(src, m[i].rows, m[i].W, m[i].KP, h->snap_dev + (size_t)(it % kDepth) * per_it + m[i].off, h->stream);
   }
-  int close_slot(int it) {         // every matrix of iteration `it` is in the slot: hand it to the copy stream
+  // every matrix of iteration `it` is in its slot; at the end of a group (or of the run) the group goes to the copy stream
+  int close_slot(int it) {
     if (!active) return BNMTF_OK;
-    const int s = it % kDepth;
-    HIPCHK(hipEventRecord(h->snap_ready[s], h->stream));
-    HIPCHK(hipStreamWaitEvent(h->copy_stream, h->snap_ready[s], 0));
-    const float* slot = h->snap_dev + (size_t)s * per_it;
-    if (direct) {
-      for (int i = 0; i < nmat; ++i)
-        HIPCHK(hipMemcpyAsync(m[i].dst + (size_t)it * m[i].rows * m[i].W, slot + m[i].off, (size_t)m[i].rows * m[i].W * sizeof(float),
-                              hipMemcpyDeviceToHost, h->copy_stream));
-    } else {
-      HIPCHK(hipMemcpyAsync(h->snap_host + (size_t)s * per_it, slot, per_it * sizeof(float), hipMemcpyDeviceToHost, h->copy_stream));
+    if (it % kGroup != kGroup - 1 && it != n_iter - 1) return BNMTF_OK;
+    const int first = it - it % kGroup, g = (it / kGroup) % kGroups;
+    HIPCHK(hipEventRecord(h->snap_ready[g], h->stream));
+    HIPCHK(hipStreamWaitEvent(h->copy_stream, h->snap_ready[g], 0));
+    static const bool nocopy = getenv("BNMTF_SAMPLES_NOCOPY") != nullptr;     // measurement hook (wrong results): the hand-off without its copies
+    for (int j = first; j <= it && !nocopy; ++j) {
+      const float* slot = h->snap_dev + (size_t)(j % kDepth) * per_it;
+      if (direct) {
+        for (int i = 0; i < nmat; ++i)
+          HIPCHK(hipMemcpyAsync(m[i].dst + (size_t)j * m[i].rows * m[i].W, slot + m[i].off, (size_t)m[i].rows * m[i].W * sizeof(float),
+                                hipMemcpyDeviceToHost, h->copy_stream));
+      } else {
+        HIPCHK(hipMemcpyAsync(h->snap_host + (size_t)(j % kDepth) * per_it, slot, per_it * sizeof(float), hipMemcpyDeviceToHost, h->copy_stream));
+      }
     }
-    HIPCHK(hipEventRecord(h->copy_done[s], h->copy_stream));
+    HIPCHK(hipEventRecord(h->copy_done[g], h->copy_stream));
+    pending_last[g] = it;
     return BNMTF_OK;
   }
   int finish() {
     if (!active) return BNMTF_OK;
     HIPCHK(hipStreamSynchronize(h->copy_stream));
-    if (!direct) for (int it = std::max(0, n_iter - kDepth); it < n_iter; ++it) drain_slot(it);
+    if (!direct) {                                   // the groups still in the ring, oldest first
+      const int g_last = ((n_iter - 1) / kGroup) % kGroups;
+      CHK(drain_group((g_last + 1) % kGroups));
+      CHK(drain_group(g_last));
+    }
     active = false;
     return BNMTF_OK;
   }
@@ -859,6 +890,7 @@ int bnmtf_set_minimum_tn(bnmtf_handle h, double minimum_TN) {
 int bnmtf_set_profiling(bnmtf_handle h, int enable) {
   // 0: off; 1: every kernel; 2 + k: kernel k only (so that a timed region carries two event records, not eight)
   h->profiling = enable == 0 ? 0u : (enable == 1 ? 0xFFFFFFFFu : 1u << (unsigned)((enable - 2) & 31));
+  h->profile_stride = enable >= 2 ? (uint64_t)((enable - 2) >> 5) + 1 : 1;     // every n-th iteration only: an event record costs the queue a few microseconds
   for (int i = 0; i < BNMTF_KERNEL_COUNT; ++i) { h->kernel_ms[i] = 0; h->kernel_launches[i] = 0; }
   return BNMTF_OK;
 }
@@ -951,8 +983,10 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
       SweepArgs s = sweep_args(h, r, c, mode, kStreamRows);
       enqueue_sweep(h, r, c, s, false);
     }
+    static const bool snap_compact = getenv("BNMTF_SNAP_COMPACT") != nullptr;      // A/B switch: the packing kernel of round 2
+    if (!snap_compact) r.snap_dst = sink.slot_for(it, r.X);         // the sample of U goes out with the relayout (no packing kernel of its own)
     CHK(exchange_factor(h, r));                  // one GPU: relayout + Gram; several: see exchange_factor
-    sink.snapshot(it, r.X);
+    if (snap_compact) sink.snapshot(it, r.X);
     // ---- V columns: Pv = R~^T . U
     enqueue_gemm(h, c, r, BNMTF_KERNEL_GEMM_COLS);
     if (acc_used && it > 0) HIPCHK(hipMemsetAsync(h->acc, 0, 4 * sizeof(double), h->stream));
@@ -965,13 +999,14 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
     }
     const bool fast_stats = h->last_sweep_fast;
     if (h->comm && fast_stats) launch_sum_stats(c.stats, c.stats_blocks, h->acc, h->stream);   // fold the slab before the exchange
+    if (!snap_compact) c.snap_dst = sink.slot_for(it, c.X);
     CHK(exchange_factor(h, c));
+    if (snap_compact) sink.snapshot(it, c.X);
     if (h->comm) {
       // the three sums of the SSE identity: behind the Gram on the exchange stream (its event covers the fold above)
       CHK(comm_allreduce_sum(h->comm, h->acc, 4, h->xchg_stream));
       HIPCHK(hipEventRecord(c.ev_gram_all, h->xchg_stream));
     }
-    sink.snapshot(it, c.X);
     CHK(sink.close_slot(it));
     CHK(await_gram(h, c)); CHK(await_gram(h, r));
     // ---- tau and the metrics of this sample

@@ -43,6 +43,11 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
         const int k = t / RB, r = t % RB;
         if (r < nr) T1[(size_t)k * a.ldT + r0 + r] = tile[r * LD + k];
       }
+    if (pass == 0 && a.snap && do_layout)
+      for (int t = tid; t < RB * a.snapW; t += 256) {
+        const int r = t / a.snapW, k = t % a.snapW;
+        if (r < nr) a.snap[(size_t)(r0 + r) * a.snapW + k] = tile[r * LD + k];
+      }
     if (pass == 0 && a.XT2 && do_layout)
       for (int t = tid; t < RB * KP; t += 256) {
         const int kp = t / (2 * RB), rem = t % (2 * RB), r = rem >> 1, c = rem & 1;

@@ -129,6 +129,9 @@ struct PostArgs {
   // rank's OWN rows [own0, own1) only (blocks blk0 .. of 32 rows; rows outside the range count as zero) and the partial
   // C64 | colsum is summed over the ranks by one all-reduce; the layouts are written for all rows once they are gathered.
   int do_layout, do_gram, blk0, own0, own1;
+  // the sample hand-off of run(): the layout blocks also write the rows packed [rows][snapW] into a snapshot slot (what a
+  // separate compaction kernel did), or null
+  float* snap; int snapW;
 };
 void launch_post(const PostArgs& a, hipStream_t st);
 void launch_post_layout(const PostArgs& a, hipStream_t st);                       // XT / XT2 (/ S2T / XS) of every row

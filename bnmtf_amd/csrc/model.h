@@ -65,6 +65,7 @@ struct Dir {
   double* C64 = nullptr; float* C32 = nullptr; double* colsum = nullptr;   // Gram of X
   bool gram_packed = false;             // colsum / colsum2 live behind C64 in one allocation (what exchange_factor all-reduces)
   hipEvent_t ev_sweep = nullptr, ev_gram = nullptr, ev_gathered = nullptr, ev_gram_all = nullptr;   // exchange_factor (several GPUs)
+  float* snap_dst = nullptr;            // set for ONE relayout: where its rows also go, packed [rows][W] (run()'s sample hand-off)
   bool gram_pending = false;            // the summed Gram is still on its way on the exchange stream
   // VB only
   float *mu = nullptr, *tauq = nullptr, *var = nullptr, *S2 = nullptr, *S2T = nullptr;
@@ -129,6 +130,7 @@ struct bnmtf_model {
   double min_tn = 0.0;                   // ICM: lower clamp of every mode update (run(iterations, minimum_TN))
   float cur_min_x = 0.f;                 // clamp in force for the sweeps being enqueued
   uint32_t profiling = 0;                // bit k: bracket the launches of kernel k with events
+  uint64_t profile_stride = 1;           // ... in every profile_stride-th iteration
   double kernel_ms[BNMTF_KERNEL_COUNT] = {0};
   uint64_t kernel_launches[BNMTF_KERNEL_COUNT] = {0};
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending_events;

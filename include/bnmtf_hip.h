@@ -222,8 +222,8 @@ int bnmtf_kmeans_set_row(void* h, int index, const double* values);
 #define BNMTF_KERNEL_SWEEP_S 4      /* BNMTF: the K*L sequential S entries */
 #define BNMTF_KERNEL_COUNT 8
 /* enable = 1: run() brackets each launch of the listed kernels with hipEvents on the handle's
- * stream; enable = 2 + k: only kernel k (BNMTF_KERNEL_*); 0: off.  Totals are read back with
- * bnmtf_kernel_stats. */
+ * stream; enable = 2 + k (+ 32 (n - 1)): only kernel k (BNMTF_KERNEL_*), in every n-th iteration (an event record
+ * costs the queue a few microseconds: a timed run samples); 0: off.  Totals are read back with bnmtf_kernel_stats. */
 int bnmtf_set_profiling(bnmtf_handle h, int enable);
 /* ICM: the lower clamp run(iterations, minimum_TN) applies to every updated entry (nmf_icm.py:129,135;
  * nmtf_icm.py:147,153,159).  Used by *_gibbs_run with update = BNMTF_UPDATE_ICM.  Default 0. */
