@@ -106,7 +106,7 @@ bool sweep_wide_supported(int KP, int pw);
 void launch_sweep_wide(const SweepArgs& a, const FastArgs& f, hipStream_t st);
 // the same pair layout run by 8-wave blocks of four units per wave, two groups of units taking turns so that a group's draw
 // is made during the other group's slot work (kernel_sweep_turns.hip; an experiment kept behind BNMTF_TURNS=1: correct,
-// slower than the 16-wave kernel -- DESIGN.md section 7.0)
+// slower than the 16-wave kernel -- DESIGN.md section 7.3)
 bool sweep_turns_supported(int KP, int pw);
 void launch_sweep_turns(const SweepArgs& a, const FastArgs& f, hipStream_t st);
 // VB sweep in the 16-wave shape (kernel_sweep_vb.hip) and the ELBO pieces it leaves to a second pass
