@@ -144,17 +144,25 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
   // residues per row, so that few rows pay it.  BNMTF_BALANCE=0 restores the padded conflict-free layout.
   d.mz = round_up(m, 32);
   d.pw = round_up(d.mz + 32, 256);
+  // an inner extent that does not fit one LDS panel is cut in two chunks (kernel_sweep_fast.hip: sweep_two_chunks_plan); a
+  // unit's entries are then laid out chunk by chunk, with inner indices local to the chunk
+  d.nch = 1; d.mh = 0; d.pw_chunk = d.pw; d.pw1 = 0;
+  if (!sweep_fast_supported(d.KP, d.pw) && !getenv("BNMTF_NO_CHUNKS") && sweep_two_chunks_plan(d.KP, m, &d.mh, &d.pw_chunk, &d.pw1)) d.nch = 2;
+  const int nch = d.nch;
   {
     const bool balance = !(getenv("BNMTF_BALANCE") && atoi(getenv("BNMTF_BALANCE")) == 0);
     const uint32_t kNone = 0xFFFFFFFFu;
     std::vector<int> Eu(d.n, 0);
-    std::vector<std::vector<uint32_t>> lanes((size_t)d.n * 32);     // per unit, per lane: slot contents (kNone = empty)
+    std::vector<std::vector<uint32_t>> lanes((size_t)d.n * 32 * nch);     // per unit, per chunk, per lane: slot contents (kNone = empty), chunk-local inner indices
     parallel_chunks(d.n, 64, [&](int ua, int ub) {
     std::vector<std::vector<uint32_t>> over(32);
     for (int ul = ua; ul < ub; ++ul) {
-      std::vector<uint32_t>* L = &lanes[(size_t)ul * 32];
-      const size_t cnt = missv[ul].size();
-      for (uint32_t j : missv[ul]) L[j & 31].push_back(j);
+      int ehalf = 0;
+      for (int ch = 0; ch < nch; ++ch) {
+      std::vector<uint32_t>* L = &lanes[((size_t)ul * nch + ch) * 32];
+      const uint32_t lo = ch == 0 ? 0u : (uint32_t)d.mh, hi = (nch == 2 && ch == 0) ? (uint32_t)d.mh : 0xFFFFFFFFu;
+      size_t cnt = 0;
+      for (uint32_t j : missv[ul]) if (j >= lo && j < hi) { L[(j - lo) & 31].push_back(j - lo); ++cnt; }
       int emax = 0;
       for (int r = 0; r < 32; ++r) emax = std::max(emax, (int)L[r].size());
       int E = std::max(2, (emax + 1) & ~1);
@@ -187,10 +195,12 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
             for (int r = 0; r < 32; ++r) if (!over[r].empty()) { L[lane][row] = over[r].back(); over[r].pop_back(); --nover; break; }
           }
       }
-      Eu[ul] = E;
+      ehalf = std::max(ehalf, E);
+      }
+      Eu[ul] = nch * ehalf;                  // two chunks: each gets half of the unit's slot rows (a multiple of 4 in all)
     }
     });
-    auto res = [&](int ul, int r) -> const std::vector<uint32_t>& { return lanes[(size_t)ul * 32 + r]; };
+    auto res = [&](int ul, int ch, int r) -> const std::vector<uint32_t>& { return lanes[((size_t)ul * nch + ch) * 32 + r]; };
     std::vector<int> order(d.n);
     for (int i = 0; i < d.n; ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return Eu[x] > Eu[y]; });
@@ -201,7 +211,7 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
     const int npairs_real = (d.n + 1) / 2;
     const int emax_all = d.n > 0 ? Eu[order[0]] : 0;
     const int wide_blocks = (npairs_real + 15) / 16;
-    const bool wide_can = sweep_wide_supported(d.KP, d.pw) && emax_all <= kWideMaxSlots && d.n > 0;
+    const bool wide_can = nch == 1 && sweep_wide_supported(d.KP, d.pw) && emax_all <= kWideMaxSlots && d.n > 0;
     d.wide_can = wide_can;
     d.use_wide = wide_can && wide_blocks >= 192;
     if (const char* e = getenv("BNMTF_WIDE")) d.use_wide = wide_can && atoi(e) != 0;      // 0: never, 1: whenever it can run
@@ -235,12 +245,17 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
     for (int pi = pa; pi < pb; ++pi)
       for (int hh = 0; hh < 2; ++hh) {
         const int ul = umap[2 * pi + hh];
-        for (uint32_t sidx = 0; sidx < pE[pi]; ++sidx)
+        for (uint32_t sidx = 0; sidx < pE[pi]; ++sidx) {
+          // two chunks: the pair's first pE / 2 rows are chunk 0 (zero words behind index mh), the rest chunk 1 (behind mz - mh)
+          const int ch = (nch == 2 && sidx >= pE[pi] / 2) ? 1 : 0;
+          const uint32_t sl = sidx - (uint32_t)ch * (pE[pi] / 2);
+          const uint32_t sent0 = nch == 2 ? (uint32_t)(ch ? d.mz - d.mh : d.mh) : (uint32_t)d.mz;
           for (int r = 0; r < 32; ++r) {
-            uint32_t v = (uint32_t)(d.mz + r);
-            if (ul >= 0) { const auto& lst = res(ul, r); if (sidx < lst.size() && lst[sidx] != kNone) v = lst[sidx]; }
+            uint32_t v = sent0 + (uint32_t)r;
+            if (ul >= 0) { const auto& lst = res(ul, ch, r); if (sl < lst.size() && lst[sl] != kNone) v = lst[sl]; }
             off[((size_t)pB[pi] + sidx) * 64 + hh * 32 + r] = v;
           }
+        }
       }
     });
     d.f_slots = rows_total;
@@ -271,6 +286,7 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
       d.f_nw = d.f_npairs >= 8 * 256 ? 8 : (d.f_npairs >= 4 * 256 ? 4 : (d.f_npairs >= 2 * 64 ? 2 : 8));
       if (const char* e = getenv("BNMTF_FAST_NW")) d.f_nw = atoi(e) == 2 ? 2 : (atoi(e) == 4 ? 4 : 8);
       if (d.use_wide) d.f_nw = 16;
+      if (nch == 2) d.f_nw = 8;                       // the two-chunk variant is an 8-wave kernel
       for (int pi = 0; pi < d.f_npairs && !d.use_wide; ++pi)
         if ((int)pE[pi] > kFastMaxSlots)
           for (int t = 2 * pi; t < 2 * pi + 2; ++t) if (umap[t] >= 0) gen.push_back(umap[t]);
@@ -423,10 +439,11 @@ static int await_gram(bnmtf_model* h, Dir& d) {
 static void enqueue_sweep(bnmtf_model* h, Dir& d, const Dir& other, SweepArgs& s, bool want_stats) {
   s.unit_list = nullptr;
   h->last_sweep_fast = false;
-  if (h->use_fast && d.fast_ok && s.cond_k < 0 && s.mode != kSweepVB && sweep_fast_supported(d.KP, d.pw)) {
+  if (h->use_fast && d.fast_ok && s.cond_k < 0 && s.mode != kSweepVB && (d.nch == 2 || sweep_fast_supported(d.KP, d.pw))) {
     FastArgs f;
     f.unit_map = d.f_unit_map; f.pair_E = d.f_pair_E; f.pair_base = d.f_pair_base; f.off = d.f_off;
-    f.npairs = d.f_npairs; f.mz = d.mz; f.pw = d.pw; f.nw = d.f_nw;
+    f.npairs = d.f_npairs; f.mz = d.mz; f.pw = d.nch == 2 ? d.pw_chunk : d.pw; f.nw = d.f_nw;
+    f.nch = d.nch; f.mh = d.mh; f.pw1 = d.pw1;
     f.XoT = other.XT; f.ldT_o = other.ldT; f.XoT2 = other.XT2; f.ld2_o = other.ldT;
     f.stats = want_stats ? d.stats : nullptr;
     SweepArgs s2 = s;
@@ -962,7 +979,7 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
   Dir& r = h->rows; Dir& c = h->cols;
   if (mode == kSweepDraw) CHK(stage_gamma_variates(h, n_iter));
   // the [3] accumulator is only written by the generic sweep kernel (and summed across ranks): zero once, reset when used
-  const bool acc_used = h->comm != nullptr || !h->use_fast || !c.fast_ok || c.f_gen_count > 0 || !sweep_fast_supported(c.KP, c.pw);
+  const bool acc_used = h->comm != nullptr || !h->use_fast || !c.fast_ok || c.f_gen_count > 0 || !(c.nch == 2 || sweep_fast_supported(c.KP, c.pw));
   HIPCHK(hipMemsetAsync(h->acc, 0, 4 * sizeof(double), h->stream));
   EventList ev;
   CHK(ev.create(times_out ? n_iter + 1 : 0));

@@ -88,6 +88,10 @@ struct FastArgs {
   int nw;                      // unit waves per block (2, 4, 8 or 16)
   int npairs;                  // pairs in descending slot-count order
   int mz, pw;                  // inner extent rounded up to 32 (sentinel zero words at mz..mz+31); panel floats pw = round_up(mz+32, 256)
+  // an inner extent too long for one LDS panel (round 3): the inner indices are cut in TWO chunks, [0, mh) and [mh, m); a
+  // unit's slots are its chunk-0 entries (first half of its slot rows) then its chunk-1 entries, inner indices LOCAL to the
+  // chunk; a column is staged and gathered chunk by chunk (nch = 2, sweep_chip.inc); pw = the longer chunk's panel floats.
+  int nch, mh, pw1;            // chunks (1 or 2), first inner index of chunk 1 (multiple of 256), panel floats of chunk 1
   const float* XoT; int ldT_o;   // other factor transposed [KP][ldT_o]
   const float* XoT2; int ld2_o;  // other factor, column pairs interleaved [KP/2][ld2_o][2]
   double* stats;               // [blocks][4] partial (sum P.X', sum_miss q, sum_miss q^2) or null
@@ -98,6 +102,9 @@ struct FastArgs {
 // 2/4/8-wave instantiations (kernel_sweep_fast.hip): pairs that need more than kFastMaxSlots slots per lane go to the generic kernel
 constexpr int kFastMaxSlots = 56;
 bool sweep_fast_supported(int KP, int pw);
+// an inner extent m too long for one LDS panel: can it be cut in two chunks [0, mh) and [mh, m) that fit one each?  Then mh (a
+// multiple of 256), the panel floats of the longer chunk (pw: LDS sizing) and of chunk 1 (pw1).
+bool sweep_two_chunks_plan(int KP, int m, int* mh, int* pw, int* pw1);
 void launch_sweep_fast(const SweepArgs& a, const FastArgs& f, hipStream_t st);
 void launch_sweep_small(const SweepArgs& a, const FastArgs& f, hipStream_t st);   // nw = 2, 4 (kernel_sweep_small.hip)
 // 16-wave instantiation (kernel_sweep_wide.hip): at most kWideMaxSlots slots per lane, 16 pairs per block

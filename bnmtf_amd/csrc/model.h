@@ -56,6 +56,7 @@ struct Dir {
   int f_nw = 8;                          // waves per fast-sweep block
   uint32_t* f_off16 = nullptr; bool pair_ok = false;
   int pw = 0;                                     // LDS panel floats = round_up(mz + 32, 256)
+  int nch = 1, mh = 0, pw_chunk = 0, pw1 = 0;     // an inner extent of two LDS panels (FastArgs::nch): chunk split, panel floats of the longer chunk / of chunk 1
   int* f_gen_units = nullptr; int f_gen_count = 0;
   double* stats = nullptr; int stats_blocks = 0;
   bool fast_ok = false;

@@ -176,22 +176,37 @@ def test_block_shape_variants_draw_the_same_chain(monkeypatch, I, J, K, env):
         assert np.array_equal(x, y)
 
 
-def test_inner_extent_beyond_the_on_chip_panel_falls_back_to_the_generic_kernel():
-    """A factor with more than 9184 rows does not fit the on-chip kernels' LDS panel (kChipPanelStride): the direction that
-    gathers from it runs the generic kernel.  Same results as the oracle (mode update), no error."""
-    I, J, K = 40, 9400, 6
+@pytest.mark.parametrize("I,J,K,miss", [(40, 9400, 6, 0.2), (300, 12000, 20, 0.08), (64, 17000, 33, 0.05)])
+def test_inner_extent_of_two_panels_runs_the_two_chunk_kernel(monkeypatch, I, J, K, miss):
+    """A factor with more than 9184 rows does not fit ONE LDS panel of the on-chip kernels (kChipPanelStride).  Up to ~18 000
+    the direction that gathers from it now cuts the inner indices in two chunks (round 3: sweep_chip.inc NCH = 2, 8-wave
+    blocks) instead of falling back to the generic kernel (16 x slower).  Same results as the oracle (mode update), the same
+    chain as the generic kernel (draws: BNMTF_NO_CHUNKS=1 restores the fall-back), no error."""
     rs = np.random.RandomState(9)
     R = rs.exponential(1.0, (I, K)) @ rs.exponential(1.0, (J, K)).T + rs.randn(I, J)
-    M = (rs.rand(I, J) > 0.2).astype(float)
+    M = (rs.rand(I, J) > miss).astype(float)
     M[rs.randint(I, size=J), np.arange(J)] = 1
+    M[np.arange(I), rs.randint(J, size=I)] = 1
+    U0, V0 = rs.exponential(1.0, (I, K)), rs.exponential(1.0, (J, K))     # at the data's scale (no collapse to zero)
     b = bnmf_gibbs_optimised(R, M, K, PRI, verbose=False, seed=1)
-    b.U, b.V, b.tau = rs.exponential(1.0, (I, K)), rs.exponential(1.0, (J, K)), 1.0     # at the data's scale (no collapse to zero)
+    b.U, b.V, b.tau = U0.copy(), V0.copy(), 1.0
     o = O.BNMFGibbsOracle(R, M, K, PRI)
-    o.U, o.V, o.tau = b.U.copy(), b.V.copy(), b.tau
+    o.U, o.V, o.tau = U0.copy(), V0.copy(), 1.0
     b.run(3, update="mode")
     o.run(3, draw=False)
     assert o.U.max() > 0.1 and o.V.max() > 0.1
     np.testing.assert_allclose(b.all_tau[-1], o.tau, rtol=2e-4)
     assert np.abs(b.U - o.U).max() <= 2e-3 * np.abs(o.U).max() and np.abs(b.V - o.V).max() <= 2e-3 * np.abs(o.V).max()
-    b.run(2)                                   # draws through the same path
-    assert np.isfinite(b.U).all() and b.U.min() >= 0
+    runs = {}
+    for env in ("0", "1"):
+        if env == "1":
+            monkeypatch.setenv("BNMTF_NO_CHUNKS", "1")
+        c = bnmf_gibbs_optimised(R, M, K, PRI, verbose=False, seed=1)
+        c.U, c.V, c.tau = U0.copy(), V0.copy(), 1.0
+        c.run(3)                                   # draws: same Philox counters on both paths
+        runs[env] = (c.all_U.copy(), c.all_V.copy(), c.all_tau.copy())
+        assert np.isfinite(c.U).all() and c.U.min() >= 0
+        c.close()
+    d0 = np.abs(runs["0"][0][0] - runs["1"][0][0]) / (np.abs(runs["1"][0][0]) + 1e-3)
+    assert np.mean(d0 < 1e-3) > 0.995
+    np.testing.assert_allclose(runs["0"][2][:2], runs["1"][2][:2], rtol=2e-3)
