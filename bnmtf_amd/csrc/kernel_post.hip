@@ -16,9 +16,10 @@ __device__ __forceinline__ void tri_tile(int p, int NT, int* ty, int* tx) {
   *ty = y; *tx = y + rem;
 }
 
+template <bool VB>
 __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
   constexpr int RB = kPostRows;
-  __shared__ float tile0[RB * 68], tile1[RB * 68];     // X rows ; VB: S2 rows
+  __shared__ float tile0[RB * 68], tile1[VB ? RB * 68 : 1];     // X rows ; VB: S2 rows (the Gibbs launches do not carry the second tile)
   constexpr int LD = 68;
   const int KP = a.KP, tid = threadIdx.x;
   const int r0 = (a.blk0 + blockIdx.x) * RB;
@@ -28,7 +29,7 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
   // (a launch that does only one of the two has one block per group)
   const bool do_layout = a.do_layout && (!a.do_gram || blockIdx.y == 0), do_gram = a.do_gram && (!a.do_layout || blockIdx.y == 1);
   const float* src = a.X;
-  for (int pass = 0; pass < (a.S2 ? 2 : 1); ++pass) {
+  for (int pass = 0; pass < (VB ? 2 : 1); ++pass) {
     float* tile = pass == 0 ? tile0 : tile1;
     if (pass == 1) src = a.S2;
     for (int t = tid; t < RB * KP; t += 256) {
@@ -162,7 +163,7 @@ void launch_post(const PostArgs& a0, hipStream_t st) {
   PostArgs a = a0;
   a.do_layout = 1; a.do_gram = 1; a.blk0 = 0; a.own0 = 0; a.own1 = a.rows;
   const int nblk = post_blocks(a.rows);
-  hipLaunchKernelGGL(post_kernel, dim3(nblk, 2), dim3(256), 0, st, a);
+  if (a.S2) hipLaunchKernelGGL(post_kernel<true>, dim3(nblk, 2), dim3(256), 0, st, a); else hipLaunchKernelGGL(post_kernel<false>, dim3(nblk, 2), dim3(256), 0, st, a);
   const int nt = a.KP / 4, ps = nt * (nt + 1) / 2 * 16;
   hipLaunchKernelGGL(gram_reduce_kernel, dim3((ps + 31) / 32 + 1), dim3(1024), 0, st, a, nblk);
 }
@@ -170,7 +171,7 @@ void launch_post(const PostArgs& a0, hipStream_t st) {
 void launch_post_layout(const PostArgs& a0, hipStream_t st) {
   PostArgs a = a0;
   a.do_layout = 1; a.do_gram = 0; a.blk0 = 0; a.own0 = 0; a.own1 = a.rows;
-  hipLaunchKernelGGL(post_kernel, dim3(post_blocks(a.rows), 1), dim3(256), 0, st, a);
+  if (a.S2) hipLaunchKernelGGL(post_kernel<true>, dim3(post_blocks(a.rows), 1), dim3(256), 0, st, a); else hipLaunchKernelGGL(post_kernel<false>, dim3(post_blocks(a.rows), 1), dim3(256), 0, st, a);
 }
 
 void launch_post_gram_rows(const PostArgs& a0, int own0, int own1, hipStream_t st) {
@@ -178,7 +179,7 @@ void launch_post_gram_rows(const PostArgs& a0, int own0, int own1, hipStream_t s
   a.do_layout = 0; a.do_gram = 1; a.own0 = own0; a.own1 = own1;
   a.blk0 = own0 / kPostRows;
   const int nblk = own1 > own0 ? (own1 + kPostRows - 1) / kPostRows - a.blk0 : 0;
-  if (nblk > 0) hipLaunchKernelGGL(post_kernel, dim3(nblk, 1), dim3(256), 0, st, a);
+  if (nblk > 0) { if (a.S2) hipLaunchKernelGGL(post_kernel<true>, dim3(nblk, 1), dim3(256), 0, st, a); else hipLaunchKernelGGL(post_kernel<false>, dim3(nblk, 1), dim3(256), 0, st, a); }
   const int nt = a.KP / 4, ps = nt * (nt + 1) / 2 * 16;
   hipLaunchKernelGGL(gram_reduce_kernel, dim3((ps + 31) / 32 + 1), dim3(1024), 0, st, a, nblk);     // no rows: zeros
 }
