@@ -137,6 +137,10 @@ def sample_buffer(shape, dtype=np.float32):
     """A zero-copy NumPy array over page-locked memory for run()'s sample outputs (asynchronous device-to-host
     copies land in it while the next iterations compute); ordinary pageable memory when pinning fails."""
     n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    # page-locking gigabytes takes the host seconds and memory it may not have (1 000 samples of an 8192 x 64 factor are
+    # 2 GB): above the cap the array is pageable and run() goes through its small pinned ring instead (BNMTF_PIN_CAP_MB)
+    if n > int(os.environ.get("BNMTF_PIN_CAP_MB", "1024")) * (1 << 20):
+        return np.zeros(shape, dtype=dtype)
     try:
         blk = _PinnedBlock(max(n, 1))
     except BnmtfError:
