@@ -297,6 +297,8 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
       d.stats_blocks = std::max((d.f_npairs + d.f_nw - 1) / d.f_nw, sweep_vb_blocks(d.f_npairs)) + 2;   // the VB sweep writes its own block count of rows
     }
     CHK(dalloc(&d.stats, (size_t)d.stats_blocks * 4));
+    // host copies of the slot layout for build_handover (released there)
+    if (d.use_wide && !d.use_turns && world == 1 && d.pair_ok && d.f_gen_count == 0) { d.h_off = std::move(off); d.h_pE = pE; d.h_pB = pB; d.h_umap = umap; }
   }
 
   CHK(dalloc(&d.big, big.size(), false));
@@ -319,6 +321,119 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
   CHK(dalloc(&d.numer, (size_t)std::max(d.n, 1)));
   CHK(dalloc(&d.taup, (size_t)std::max(d.n, 1)));
   return BNMTF_OK;
+}
+
+// q hand-over tables for one writer / reader pair of directions (model.h Dir::ho_*).  An entry (i, j) of the mask sits in a
+// slot of W's layout (unit i, inner index j) and in a slot of Rd's (unit j, inner index i).  W's block bw stages the final q
+// of its entries sorted by Rd's block, [bw][br] one run padded to four entries; run (bw, br) is copied as it is into block
+// br's region at Rd, which is the runs (0, br), (1, br), ... behind one another, then >= 32 zeros (what empty slots read),
+// padded to 256 entries (one LDS-DMA piece).  ho_out (W) and ho_in (Rd) give every slot its 16-bit place in the staging area
+// / the region.  Returns false (and leaves the pair without hand-over) if a staging area or a region would not fit.
+static bool build_handover(Dir& W, Dir& Rd) {
+  if (W.h_off.empty() || Rd.h_off.empty() || W.f_npairs % 16 || Rd.f_npairs % 16) return false;
+  const int nbW = W.f_npairs / 16, nbR = Rd.f_npairs / 16;
+  const uint32_t mW = (uint32_t)Rd.nglob, mR = (uint32_t)W.nglob;       // inner extents: W's inner indices are Rd's units and back
+  const size_t rowsW = W.h_off.size() / 64, rowsR = Rd.h_off.size() / 64;
+  // Rd's entries by unit: (inner index, slot id = row * 64 + lane), sorted; and the block of every slot row
+  std::vector<std::vector<std::pair<uint32_t, uint32_t>>> ent(Rd.n);
+  std::vector<uint16_t> row_blk(rowsR, 0);
+  parallel_chunks(Rd.f_npairs, 64, [&](int pa, int pb) {
+    for (int pi = pa; pi < pb; ++pi) {
+      for (uint32_t sidx = 0; sidx < Rd.h_pE[pi]; ++sidx) row_blk[Rd.h_pB[pi] + sidx] = (uint16_t)(pi / 16);
+      for (int hh = 0; hh < 2; ++hh) {
+        const int ul = Rd.h_umap[2 * pi + hh];
+        if (ul < 0) continue;
+        auto& e = ent[ul];
+        for (uint32_t sidx = 0; sidx < Rd.h_pE[pi]; ++sidx)
+          for (int r = 0; r < 32; ++r) {
+            const size_t sid = ((size_t)Rd.h_pB[pi] + sidx) * 64 + hh * 32 + r;
+            if (Rd.h_off[sid] < mR) e.push_back({Rd.h_off[sid], (uint32_t)sid});
+          }
+        std::sort(e.begin(), e.end());
+      }
+    }
+  });
+  // pass 1: every W slot's destination (Rd slot, Rd block, rank inside the run)
+  const uint32_t kNone = 0xFFFFFFFFu;
+  std::vector<uint32_t> dst_slot(rowsW * 64, kNone), dst_rank(rowsW * 64, 0u), count((size_t)nbW * nbR, 0u);
+  std::atomic<bool> ok{true};
+  parallel_chunks(nbW, 4, [&](int ba, int bb) {
+    for (int bw = ba; bw < bb; ++bw) {
+      uint32_t* cnt = &count[(size_t)bw * nbR];
+      for (int pi = 16 * bw; pi < 16 * bw + 16; ++pi)
+        for (uint32_t sidx = 0; sidx < W.h_pE[pi]; ++sidx)
+          for (int l = 0; l < 64; ++l) {
+            const int ul = W.h_umap[2 * pi + (l >> 5)];
+            const size_t sid = ((size_t)W.h_pB[pi] + sidx) * 64 + l;
+            const uint32_t j = W.h_off[sid];
+            if (ul < 0 || j >= mW) continue;
+            const auto& e = ent[j];
+            auto it = std::lower_bound(e.begin(), e.end(), std::make_pair((uint32_t)ul, 0u));
+            if (it == e.end() || it->first != (uint32_t)ul) { ok = false; continue; }
+            dst_slot[sid] = it->second;
+            dst_rank[sid] = cnt[row_blk[it->second / 64]]++;
+          }
+    }
+  });
+  if (!ok) return false;
+  auto r4 = [](uint32_t v) { return (v + 3u) & ~3u; };
+  std::vector<uint32_t> sbase((size_t)nbW * nbR), stotal(nbW), rbase((size_t)nbR * nbW), rdata(nbR), rofs(nbR + 1, 0u);
+  const uint32_t capW = 4u * (uint32_t)W.pw - 256u - 32u, capR = std::min<uint32_t>(4u * (uint32_t)Rd.pw, 65536u);
+  for (int bw = 0; bw < nbW; ++bw) {
+    uint32_t run = 0;
+    for (int br = 0; br < nbR; ++br) { sbase[(size_t)bw * nbR + br] = run; run += r4(count[(size_t)bw * nbR + br]); }
+    stotal[bw] = run;
+    if (run > capW || run + 32 > 65536u) return false;
+  }
+  for (int br = 0; br < nbR; ++br) {
+    uint32_t run = 0;
+    for (int bw = 0; bw < nbW; ++bw) { rbase[(size_t)br * nbW + bw] = run; run += r4(count[(size_t)bw * nbR + br]); }
+    rdata[br] = run;
+    const uint32_t size = (uint32_t)round_up((int)run + 32, 256);
+    if (size > capR) return false;
+    rofs[br + 1] = rofs[br] + size;
+  }
+  // pass 2: the two offset tables (16-bit pairs, the slot table's packing) and the packet list
+  std::vector<uint32_t> t_out(rowsW * 64), t_in(rowsR * 64);
+  parallel_chunks((int)rowsR, 4096, [&](int ra, int rb) {
+    for (size_t r = (size_t)ra; r < (size_t)rb; ++r)
+      for (int l = 0; l < 64; ++l) t_in[r * 64 + l] = rdata[row_blk[r]] + (uint32_t)(l & 31);
+  });
+  parallel_chunks(nbW, 4, [&](int ba, int bb) {
+    for (int bw = ba; bw < bb; ++bw)
+      for (int pi = 16 * bw; pi < 16 * bw + 16; ++pi)
+        for (uint32_t sidx = 0; sidx < W.h_pE[pi]; ++sidx)
+          for (int l = 0; l < 64; ++l) {
+            const size_t sid = ((size_t)W.h_pB[pi] + sidx) * 64 + l;
+            if (dst_slot[sid] == kNone) { t_out[sid] = stotal[bw] + (uint32_t)(l & 31); continue; }
+            const int br = row_blk[dst_slot[sid] / 64];
+            t_out[sid] = sbase[(size_t)bw * nbR + br] + dst_rank[sid];
+            t_in[dst_slot[sid]] = rbase[(size_t)br * nbW + bw] + dst_rank[sid];
+          }
+  });
+  auto pack = [](const std::vector<uint32_t>& t, size_t rows) {
+    std::vector<uint32_t> p16(std::max<size_t>(rows / 2, 1) * 64, 0);
+    parallel_chunks((int)(rows / 2), 4096, [&](int ra, int rb) {
+      for (size_t r2 = (size_t)ra; r2 < (size_t)rb; ++r2)
+        for (int l = 0; l < 64; ++l) p16[r2 * 64 + l] = (t[(2 * r2) * 64 + l] & 0xFFFFu) | (t[(2 * r2 + 1) * 64 + l] << 16);
+    });
+    return p16;
+  };
+  const std::vector<uint32_t> out16 = pack(t_out, rowsW), in16 = pack(t_in, rowsR);
+  std::vector<uint32_t> pk((size_t)nbW * nbR * 3);
+  for (int bw = 0; bw < nbW; ++bw)
+    for (int br = 0; br < nbR; ++br) {
+      uint32_t* p = &pk[((size_t)bw * nbR + br) * 3];
+      p[0] = sbase[(size_t)bw * nbR + br]; p[1] = r4(count[(size_t)bw * nbR + br]); p[2] = rofs[br] + rbase[(size_t)br * nbW + bw];
+    }
+  auto up = [](uint32_t** dst, const std::vector<uint32_t>& v) {
+    if (dalloc(dst, v.size(), false) != BNMTF_OK) return false;
+    return hipMemcpy(*dst, v.data(), v.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
+  };
+  if (!up(&W.ho_out, out16) || !up(&W.ho_pk, pk) || !up(&Rd.ho_in, in16) || !up(&Rd.ho_region_ofs, rofs)) return false;
+  if (dalloc(&Rd.ho_region, (size_t)rofs[nbR] + 256) != BNMTF_OK) return false;      // zero-filled: the zeros behind the runs are never written
+  Rd.ho_blocks = nbR;
+  return true;
 }
 
 static int alloc_factor(Dir& d, int other_inner_pad) {
@@ -345,6 +460,7 @@ static void free_dir(Dir& d) {
   dfree(d.XT2); dfree(d.Cpart); dfree(d.spart); dfree(d.s2part); dfree(d.f_unit_map); dfree(d.f_pair_E);
   dfree(d.f_pair_base); dfree(d.f_off); dfree(d.f_off16); dfree(d.stats); dfree(d.f_gen_units);
   dfree(d.vb_stats);
+  dfree(d.ho_in); dfree(d.ho_out); dfree(d.ho_pk); dfree(d.ho_region_ofs); dfree(d.ho_region);
   dfree(d.mu); dfree(d.tauq); dfree(d.var); dfree(d.S2); dfree(d.S2T); dfree(d.XS); dfree(d.vb_asq); dfree(d.vb_vsq); dfree(d.numer); dfree(d.taup);
 }
 
@@ -449,6 +565,19 @@ static void enqueue_sweep(bnmtf_model* h, Dir& d, const Dir& other, SweepArgs& s
     SweepArgs s2 = s;
     s2.acc = nullptr;
     f.off16 = d.pair_ok ? d.f_off16 : nullptr;
+    // q hand-over (bnmf_gibbs_run switches it on): read this direction's region if the other direction's last sweep filled it,
+    // fill the other's.  Every kHandoverRefresh-th iteration the rows sweep runs its pre-pass all the same: q handed back and
+    // forth collects one fp32 rounding per column update, the pre-pass starts from X again.
+    f.ho_read = f.ho_write = 0; f.ho_nb_other = 0; f.ho_rows_total = (int)d.f_slots;
+    f.ho_in = f.ho_out = f.ho_pk = f.ho_region_ofs = nullptr; f.ho_region = nullptr; f.ho_dst = nullptr;
+    if (h->ho_active && d.ho_ready && other.ho_ready && d.use_wide && !d.use_turns && s.mode != kSweepVB) {
+      const bool refresh = &d == &h->rows && h->iteration % h->ho_refresh == 0;
+      f.ho_read = d.ho_filled && !refresh;
+      f.ho_in = d.ho_in; f.ho_region = d.ho_region; f.ho_region_ofs = d.ho_region_ofs;
+      f.ho_write = 1; f.ho_nb_other = other.ho_blocks;
+      f.ho_out = d.ho_out; f.ho_pk = d.ho_pk; f.ho_dst = other.ho_region;
+      other.ho_filled = true; d.ho_filled = false;
+    }
     if (d.use_wide && d.use_turns) launch_sweep_turns(s2, f, h->stream);
     else if (d.use_wide) launch_sweep_wide(s2, f, h->stream);
     else launch_sweep_fast(s2, f, h->stream);
@@ -802,13 +931,21 @@ int bnmtf_create(const bnmtf_problem* p, bnmtf_handle* out) {
     if ((rcode = comm_create(&h->comm, id, 0, 1, h->stream))) return fail(rcode);
   }
 
+  // q hand-over tables (BNMF on one GPU with the 16-wave kernels on both directions; BNMTF_HANDOVER=0: off)
+  {
+    const char* e = getenv("BNMTF_HANDOVER");
+    const bool want = !(e && atoi(e) == 0) && p->L == 0 && !h->comm;
+    if (want && build_handover(h->rows, h->cols) && build_handover(h->cols, h->rows)) h->rows.ho_ready = h->cols.ho_ready = h->ho_enabled = true;
+    if (const char* r = getenv("BNMTF_HANDOVER_REFRESH")) h->ho_refresh = (uint64_t)std::max(1, atoi(r));
+    for (Dir* d : {&h->rows, &h->cols}) { std::vector<uint32_t>().swap(d->h_off); std::vector<uint32_t>().swap(d->h_pE); std::vector<uint32_t>().swap(d->h_pB); std::vector<int>().swap(d->h_umap); }
+  }
   h->create_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create0).count();
   char buf[768];
   snprintf(buf, sizeof(buf),
-           "I=%d J=%d K=%d L=%d rank=%d/%d rows[n=%d n_pad=%d split=%d ipw=%d inner_pad=%d nmiss=%zu nslots=%zu sweep_nw=%d turns=%d emax=%d generic_units=%d] "
+           "I=%d J=%d K=%d L=%d rank=%d/%d rows[n=%d n_pad=%d split=%d ipw=%d inner_pad=%d nmiss=%zu nslots=%zu sweep_nw=%d turns=%d handover=%d emax=%d generic_units=%d] "
            "cols[n=%d n_pad=%d split=%d ipw=%d inner_pad=%d nmiss=%zu nslots=%zu sweep_nw=%d turns=%d emax=%d generic_units=%d] n_obs=%.0f create_ms=%.0f",
            I, J, p->K, p->L, p->rank, p->world, h->rows.n, h->rows.n_pad, h->rows.split, h->rows.ipw, h->rows.inner_pad,
-           h->rows.nmiss, h->rows.nslots, h->rows.f_nw, (int)h->rows.use_turns, h->rows.f_emax, h->rows.f_gen_count, h->cols.n, h->cols.n_pad, h->cols.split,
+           h->rows.nmiss, h->rows.nslots, h->rows.f_nw, (int)h->rows.use_turns, (int)h->ho_enabled, h->rows.f_emax, h->rows.f_gen_count, h->cols.n, h->cols.n_pad, h->cols.split,
            h->cols.ipw, h->cols.inner_pad, h->cols.nmiss, h->cols.nslots, h->cols.f_nw, (int)h->cols.use_turns, h->cols.f_emax, h->cols.f_gen_count, n_obs, h->create_ms);
   h->description = buf;
   *out = h;
@@ -978,6 +1115,10 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
   h->cur_min_x = update == BNMTF_UPDATE_ICM ? (float)h->min_tn : 0.f;
   Dir& r = h->rows; Dir& c = h->cols;
   if (mode == kSweepDraw) CHK(stage_gamma_variates(h, n_iter));
+  // q hand-over between the half sweeps: from this call's first rows sweep (a pre-pass) on; off again when the call returns
+  struct HandoverScope { bnmtf_model* h; ~HandoverScope() { h->ho_active = false; } } ho_scope{h};
+  r.ho_filled = c.ho_filled = false;
+  h->ho_active = h->ho_enabled && !h->comm && h->use_fast;
   // the [3] accumulator is only written by the generic sweep kernel (and summed across ranks): zero once, reset when used
   const bool acc_used = h->comm != nullptr || !h->use_fast || !c.fast_ok || c.f_gen_count > 0 || !(c.nch == 2 || sweep_fast_supported(c.KP, c.pw));
   HIPCHK(hipMemsetAsync(h->acc, 0, 4 * sizeof(double), h->stream));

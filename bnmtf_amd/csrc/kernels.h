@@ -92,6 +92,11 @@ struct FastArgs {
   // unit's slots are its chunk-0 entries (first half of its slot rows) then its chunk-1 entries, inner indices LOCAL to the
   // chunk; a column is staged and gathered chunk by chunk (nch = 2, sweep_chip.inc); pw = the longer chunk's panel floats.
   int nch, mh, pw1;            // chunks (1 or 2), first inner index of chunk 1 (multiple of 256), panel floats of chunk 1
+  // q hand-over between the half sweeps (16-wave kernel, one GPU; model.h Dir::ho_*): read q from the block's region instead of
+  // the pre-pass / write q sorted by the other direction's blocks at the end
+  int ho_read, ho_write, ho_nb_other, ho_rows_total;       // ho_rows_total: slot rows of the whole direction (= the end of the last block's slice)
+  const uint32_t* ho_in; const float* ho_region; const uint32_t* ho_region_ofs;
+  const uint32_t* ho_out; const uint32_t* ho_pk; float* ho_dst;
   const float* XoT; int ldT_o;   // other factor transposed [KP][ldT_o]
   const float* XoT2; int ld2_o;  // other factor, column pairs interleaved [KP/2][ld2_o][2]
   double* stats;               // [blocks][4] partial (sum P.X', sum_miss q, sum_miss q^2) or null

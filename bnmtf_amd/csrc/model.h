@@ -64,6 +64,18 @@ struct Dir {
   bool use_turns = false;                // the wide layout run by kernel_sweep_turns.hip (two unit groups per block taking turns)
   bool use_wide = false;                 // 16-wave sweep kernel (pairs dealt to blocks per wave class) instead of the 8-wave one
   double* C64 = nullptr; float* C32 = nullptr; double* colsum = nullptr;   // Gram of X
+  // q hand-over between the half sweeps (round 3, one GPU, 16-wave kernels on both directions): this direction's blocks end a
+  // sweep by writing q = X_i . Xo_j of their missing entries, sorted by the OTHER direction's blocks, into that direction's
+  // regions; they start a sweep by reading their own region instead of running the pre-pass (build_handover, api.hip)
+  uint32_t* ho_in = nullptr;            // [slot rows / 2][64] two 16-bit offsets (entries) into the block's region per word, like f_off16
+  uint32_t* ho_out = nullptr;           // same shape: offsets into the block's staging area (sorted by destination block)
+  uint32_t* ho_pk = nullptr;            // [blocks][blocks of the other direction][3]: staging start, count, global offset in the other's regions
+  uint32_t* ho_region_ofs = nullptr;    // [blocks + 1] first entry of each block's region
+  float* ho_region = nullptr;           // the regions: what the other direction's sweep writes and this one reads
+  int ho_blocks = 0;
+  bool ho_ready = false;                // tables exist
+  mutable bool ho_filled = false;       // the regions hold q of the current (X, Xo)
+  std::vector<uint32_t> h_off, h_pE, h_pB; std::vector<int> h_umap; std::vector<std::vector<uint32_t>> h_miss;   // host copies kept until build_handover has run
   bool gram_packed = false;             // colsum / colsum2 live behind C64 in one allocation (what exchange_factor all-reduces)
   hipEvent_t ev_sweep = nullptr, ev_gram = nullptr, ev_gathered = nullptr, ev_gram_all = nullptr;   // exchange_factor (several GPUs)
   float* snap_dst = nullptr;            // set for ONE relayout: where its rows also go, packed [rows][W] (run()'s sample hand-off)
@@ -131,6 +143,8 @@ struct bnmtf_model {
   double min_tn = 0.0;                   // ICM: lower clamp of every mode update (run(iterations, minimum_TN))
   float cur_min_x = 0.f;                 // clamp in force for the sweeps being enqueued
   uint32_t profiling = 0;                // bit k: bracket the launches of kernel k with events
+  bool ho_enabled = false, ho_active = false;   // q hand-over between the half sweeps (Dir::ho_*): tables built / in use by the running loop
+  uint64_t ho_refresh = 8;                      // the rows sweep runs its pre-pass every ho_refresh-th iteration
   uint64_t profile_stride = 1;           // ... in every profile_stride-th iteration
   double kernel_ms[BNMTF_KERNEL_COUNT] = {0};
   uint64_t kernel_launches[BNMTF_KERNEL_COUNT] = {0};
