@@ -297,8 +297,14 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
       d.stats_blocks = std::max((d.f_npairs + d.f_nw - 1) / d.f_nw, sweep_vb_blocks(d.f_npairs)) + 2;   // the VB sweep writes its own block count of rows
     }
     CHK(dalloc(&d.stats, (size_t)d.stats_blocks * 4));
-    // host copies of the slot layout for build_handover (released there)
-    if (d.use_wide && !d.use_turns && world == 1 && d.pair_ok && d.f_gen_count == 0) { d.h_off = std::move(off); d.h_pE = pE; d.h_pB = pB; d.h_umap = umap; }
+    // the block of every slot row: what build_handover needs beside the layout itself
+    if (d.use_wide && !d.use_turns && world == 1 && d.pair_ok && d.f_gen_count == 0 && d.f_npairs / 16 < 65536) {
+      std::vector<uint16_t> row_blk(std::max<size_t>(rows_total, 1), 0);
+      for (int pi = 0; pi < d.f_npairs; ++pi)
+        for (uint32_t sidx = 0; sidx < pE[pi]; ++sidx) row_blk[pB[pi] + sidx] = (uint16_t)(pi / 16);
+      CHK(dalloc(&d.f_row_blk, row_blk.size(), false));
+      HIPCHK(hipMemcpy(d.f_row_blk, row_blk.data(), row_blk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
   }
 
   CHK(dalloc(&d.big, big.size(), false));
@@ -323,115 +329,39 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
   return BNMTF_OK;
 }
 
-// q hand-over tables for one writer / reader pair of directions (model.h Dir::ho_*).  An entry (i, j) of the mask sits in a
-// slot of W's layout (unit i, inner index j) and in a slot of Rd's (unit j, inner index i).  W's block bw stages the final q
-// of its entries sorted by Rd's block, [bw][br] one run padded to four entries; run (bw, br) is copied as it is into block
-// br's region at Rd, which is the runs (0, br), (1, br), ... behind one another, then >= 32 zeros (what empty slots read),
-// padded to 256 entries (one LDS-DMA piece).  ho_out (W) and ho_in (Rd) give every slot its 16-bit place in the staging area
-// / the region.  Returns false (and leaves the pair without hand-over) if a staging area or a region would not fit.
-static bool build_handover(Dir& W, Dir& Rd) {
-  if (W.h_off.empty() || Rd.h_off.empty() || W.f_npairs % 16 || Rd.f_npairs % 16) return false;
+// q hand-over tables for one writer / reader pair of directions (model.h Dir::ho_*), built on the device from the two slot
+// layouts (kernel_handover.hip).  Returns false (and leaves the pair without hand-over) if a staging area or a region would
+// not fit the block's LDS or its 16-bit offsets.
+static bool build_handover(bnmtf_model* h, Dir& W, Dir& Rd) {
+  if (!W.f_row_blk || !Rd.f_row_blk || W.f_npairs % 16 || Rd.f_npairs % 16 || W.f_npairs == 0 || Rd.f_npairs == 0) return false;
   const int nbW = W.f_npairs / 16, nbR = Rd.f_npairs / 16;
-  const uint32_t mW = (uint32_t)Rd.nglob, mR = (uint32_t)W.nglob;       // inner extents: W's inner indices are Rd's units and back
-  const size_t rowsW = W.h_off.size() / 64, rowsR = Rd.h_off.size() / 64;
-  // Rd's entries by unit: (inner index, slot id = row * 64 + lane), sorted; and the block of every slot row
-  std::vector<std::vector<std::pair<uint32_t, uint32_t>>> ent(Rd.n);
-  std::vector<uint16_t> row_blk(rowsR, 0);
-  parallel_chunks(Rd.f_npairs, 64, [&](int pa, int pb) {
-    for (int pi = pa; pi < pb; ++pi) {
-      for (uint32_t sidx = 0; sidx < Rd.h_pE[pi]; ++sidx) row_blk[Rd.h_pB[pi] + sidx] = (uint16_t)(pi / 16);
-      for (int hh = 0; hh < 2; ++hh) {
-        const int ul = Rd.h_umap[2 * pi + hh];
-        if (ul < 0) continue;
-        auto& e = ent[ul];
-        for (uint32_t sidx = 0; sidx < Rd.h_pE[pi]; ++sidx)
-          for (int r = 0; r < 32; ++r) {
-            const size_t sid = ((size_t)Rd.h_pB[pi] + sidx) * 64 + hh * 32 + r;
-            if (Rd.h_off[sid] < mR) e.push_back({Rd.h_off[sid], (uint32_t)sid});
-          }
-        std::sort(e.begin(), e.end());
-      }
-    }
-  });
-  // pass 1: every W slot's destination (Rd slot, Rd block, rank inside the run)
-  const uint32_t kNone = 0xFFFFFFFFu;
-  std::vector<uint32_t> dst_slot(rowsW * 64, kNone), dst_rank(rowsW * 64, 0u), count((size_t)nbW * nbR, 0u);
-  std::atomic<bool> ok{true};
-  parallel_chunks(nbW, 4, [&](int ba, int bb) {
-    for (int bw = ba; bw < bb; ++bw) {
-      uint32_t* cnt = &count[(size_t)bw * nbR];
-      for (int pi = 16 * bw; pi < 16 * bw + 16; ++pi)
-        for (uint32_t sidx = 0; sidx < W.h_pE[pi]; ++sidx)
-          for (int l = 0; l < 64; ++l) {
-            const int ul = W.h_umap[2 * pi + (l >> 5)];
-            const size_t sid = ((size_t)W.h_pB[pi] + sidx) * 64 + l;
-            const uint32_t j = W.h_off[sid];
-            if (ul < 0 || j >= mW) continue;
-            const auto& e = ent[j];
-            auto it = std::lower_bound(e.begin(), e.end(), std::make_pair((uint32_t)ul, 0u));
-            if (it == e.end() || it->first != (uint32_t)ul) { ok = false; continue; }
-            dst_slot[sid] = it->second;
-            dst_rank[sid] = cnt[row_blk[it->second / 64]]++;
-          }
-    }
-  });
-  if (!ok) return false;
-  auto r4 = [](uint32_t v) { return (v + 3u) & ~3u; };
-  std::vector<uint32_t> sbase((size_t)nbW * nbR), stotal(nbW), rbase((size_t)nbR * nbW), rdata(nbR), rofs(nbR + 1, 0u);
-  const uint32_t capW = 4u * (uint32_t)W.pw - 256u - 32u, capR = std::min<uint32_t>(4u * (uint32_t)Rd.pw, 65536u);
-  for (int bw = 0; bw < nbW; ++bw) {
-    uint32_t run = 0;
-    for (int br = 0; br < nbR; ++br) { sbase[(size_t)bw * nbR + br] = run; run += r4(count[(size_t)bw * nbR + br]); }
-    stotal[bw] = run;
-    if (run > capW || run + 32 > 65536u) return false;
-  }
-  for (int br = 0; br < nbR; ++br) {
-    uint32_t run = 0;
-    for (int bw = 0; bw < nbW; ++bw) { rbase[(size_t)br * nbW + bw] = run; run += r4(count[(size_t)bw * nbR + br]); }
-    rdata[br] = run;
-    const uint32_t size = (uint32_t)round_up((int)run + 32, 256);
-    if (size > capR) return false;
-    rofs[br + 1] = rofs[br] + size;
-  }
-  // pass 2: the two offset tables (16-bit pairs, the slot table's packing) and the packet list
-  std::vector<uint32_t> t_out(rowsW * 64), t_in(rowsR * 64);
-  parallel_chunks((int)rowsR, 4096, [&](int ra, int rb) {
-    for (size_t r = (size_t)ra; r < (size_t)rb; ++r)
-      for (int l = 0; l < 64; ++l) t_in[r * 64 + l] = rdata[row_blk[r]] + (uint32_t)(l & 31);
-  });
-  parallel_chunks(nbW, 4, [&](int ba, int bb) {
-    for (int bw = ba; bw < bb; ++bw)
-      for (int pi = 16 * bw; pi < 16 * bw + 16; ++pi)
-        for (uint32_t sidx = 0; sidx < W.h_pE[pi]; ++sidx)
-          for (int l = 0; l < 64; ++l) {
-            const size_t sid = ((size_t)W.h_pB[pi] + sidx) * 64 + l;
-            if (dst_slot[sid] == kNone) { t_out[sid] = stotal[bw] + (uint32_t)(l & 31); continue; }
-            const int br = row_blk[dst_slot[sid] / 64];
-            t_out[sid] = sbase[(size_t)bw * nbR + br] + dst_rank[sid];
-            t_in[dst_slot[sid]] = rbase[(size_t)br * nbW + bw] + dst_rank[sid];
-          }
-  });
-  auto pack = [](const std::vector<uint32_t>& t, size_t rows) {
-    std::vector<uint32_t> p16(std::max<size_t>(rows / 2, 1) * 64, 0);
-    parallel_chunks((int)(rows / 2), 4096, [&](int ra, int rb) {
-      for (size_t r2 = (size_t)ra; r2 < (size_t)rb; ++r2)
-        for (int l = 0; l < 64; ++l) p16[r2 * 64 + l] = (t[(2 * r2) * 64 + l] & 0xFFFFu) | (t[(2 * r2 + 1) * 64 + l] << 16);
-    });
-    return p16;
-  };
-  const std::vector<uint32_t> out16 = pack(t_out, rowsW), in16 = pack(t_in, rowsR);
-  std::vector<uint32_t> pk((size_t)nbW * nbR * 3);
-  for (int bw = 0; bw < nbW; ++bw)
-    for (int br = 0; br < nbR; ++br) {
-      uint32_t* p = &pk[((size_t)bw * nbR + br) * 3];
-      p[0] = sbase[(size_t)bw * nbR + br]; p[1] = r4(count[(size_t)bw * nbR + br]); p[2] = rofs[br] + rbase[(size_t)br * nbW + bw];
-    }
-  auto up = [](uint32_t** dst, const std::vector<uint32_t>& v) {
-    if (dalloc(dst, v.size(), false) != BNMTF_OK) return false;
-    return hipMemcpy(*dst, v.data(), v.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
-  };
-  if (!up(&W.ho_out, out16) || !up(&W.ho_pk, pk) || !up(&Rd.ho_in, in16) || !up(&Rd.ho_region_ofs, rofs)) return false;
-  if (dalloc(&Rd.ho_region, (size_t)rofs[nbR] + 256) != BNMTF_OK) return false;      // zero-filled: the zeros behind the runs are never written
+  if (nbR > 8192) return false;                         // (the destination kernel counts per reader block in LDS)
+  const size_t rowsW = W.f_slots, rowsR = Rd.f_slots;
+  DevBuf<uint32_t> inv, dst_slot, dst_rank, count, sbase, stotal, rbase, rdata, rsize, limits;
+  if (inv.alloc(std::max<size_t>(Rd.nslots, 1)) || dst_slot.alloc(std::max<size_t>(rowsW, 1) * 64) || dst_rank.alloc(std::max<size_t>(rowsW, 1) * 64) ||
+      count.alloc((size_t)nbW * nbR) || sbase.alloc((size_t)nbW * nbR) || stotal.alloc(nbW) || rbase.alloc((size_t)nbW * nbR) || rdata.alloc(nbR) ||
+      rsize.alloc(nbR) || limits.alloc(4, true)) return false;
+  uint16_t *t_out = nullptr, *t_in = nullptr;
+  // (two 16-bit places per word; an odd row count leaves the last word's upper half unused)
+  if (dalloc(&t_out, ((rowsW + 1) / 2) * 128, true) || dalloc(&t_in, ((rowsR + 1) / 2) * 128, true)) return false;
+  W.ho_out = reinterpret_cast<uint32_t*>(t_out); Rd.ho_in = reinterpret_cast<uint32_t*>(t_in);
+  if (dalloc(&W.ho_pk, (size_t)nbW * nbR * 3, false) || dalloc(&Rd.ho_region_ofs, (size_t)nbR + 1, false)) return false;
+  HandoverArgs a;
+  a.w_off = W.f_off; a.w_pB = W.f_pair_base; a.w_pE = W.f_pair_E; a.w_umap = W.f_unit_map; a.w_nb = nbW; a.w_inner = (uint32_t)Rd.nglob;
+  a.r_off = Rd.f_off; a.r_pB = Rd.f_pair_base; a.r_pE = Rd.f_pair_E; a.r_umap = Rd.f_unit_map; a.r_nb = nbR; a.r_inner = (uint32_t)W.nglob;
+  a.r_row_blk = Rd.f_row_blk; a.r_ptr = Rd.slot_ptr; a.r_idx = Rd.idx;
+  a.inv = inv.p; a.dst_slot = dst_slot.p; a.dst_rank = dst_rank.p; a.count = count.p;
+  a.sbase = sbase.p; a.stotal = stotal.p; a.rbase = rbase.p; a.rdata = rdata.p; a.rsize = rsize.p;
+  a.rofs = Rd.ho_region_ofs; a.t_out = t_out; a.t_in = t_in; a.pk = W.ho_pk; a.limits = limits.p;
+  launch_handover_build(a, h->stream);
+  uint32_t lim[4];
+  if (hipMemcpyAsync(lim, limits.p, sizeof(lim), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return false;
+  // staging area and region live behind the Gram in the block's LDS (160 KiB in all; the launch asks for what they need)
+  const uint32_t lds_floats = 160u * 1024u / 4u - (uint32_t)(W.KP * W.KP);
+  if (lim[2] != 0 || lim[0] + 256u + 32u > lds_floats || lim[0] + 32u > 65536u || lim[1] > lds_floats || lim[1] > 65536u) return false;
+  W.ho_lds_floats = std::max(W.ho_lds_floats, (int)lim[0] + 256 + 32);
+  Rd.ho_lds_floats = std::max(Rd.ho_lds_floats, (int)lim[1]);
+  if (dalloc(&Rd.ho_region, (size_t)lim[3] + 256) != BNMTF_OK) return false;      // zero-filled: the zeros behind the runs are never written
   Rd.ho_blocks = nbR;
   return true;
 }
@@ -460,7 +390,7 @@ static void free_dir(Dir& d) {
   dfree(d.XT2); dfree(d.Cpart); dfree(d.spart); dfree(d.s2part); dfree(d.f_unit_map); dfree(d.f_pair_E);
   dfree(d.f_pair_base); dfree(d.f_off); dfree(d.f_off16); dfree(d.stats); dfree(d.f_gen_units);
   dfree(d.vb_stats);
-  dfree(d.ho_in); dfree(d.ho_out); dfree(d.ho_pk); dfree(d.ho_region_ofs); dfree(d.ho_region);
+  dfree(d.ho_in); dfree(d.ho_out); dfree(d.ho_pk); dfree(d.ho_region_ofs); dfree(d.ho_region); dfree(d.f_row_blk);
   dfree(d.mu); dfree(d.tauq); dfree(d.var); dfree(d.S2); dfree(d.S2T); dfree(d.XS); dfree(d.vb_asq); dfree(d.vb_vsq); dfree(d.numer); dfree(d.taup);
 }
 
@@ -568,13 +498,13 @@ static void enqueue_sweep(bnmtf_model* h, Dir& d, const Dir& other, SweepArgs& s
     // q hand-over (bnmf_gibbs_run switches it on): read this direction's region if the other direction's last sweep filled it,
     // fill the other's.  Every kHandoverRefresh-th iteration the rows sweep runs its pre-pass all the same: q handed back and
     // forth collects one fp32 rounding per column update, the pre-pass starts from X again.
-    f.ho_read = f.ho_write = 0; f.ho_nb_other = 0; f.ho_rows_total = (int)d.f_slots;
+    f.ho_read = f.ho_write = 0; f.ho_nb_other = 0; f.ho_lds_floats = 0; f.ho_rows_total = (int)d.f_slots;
     f.ho_in = f.ho_out = f.ho_pk = f.ho_region_ofs = nullptr; f.ho_region = nullptr; f.ho_dst = nullptr;
     if (h->ho_active && d.ho_ready && other.ho_ready && d.use_wide && !d.use_turns && s.mode != kSweepVB) {
       const bool refresh = &d == &h->rows && h->iteration % h->ho_refresh == 0;
       f.ho_read = d.ho_filled && !refresh;
       f.ho_in = d.ho_in; f.ho_region = d.ho_region; f.ho_region_ofs = d.ho_region_ofs;
-      f.ho_write = 1; f.ho_nb_other = other.ho_blocks;
+      f.ho_write = 1; f.ho_nb_other = other.ho_blocks; f.ho_lds_floats = d.ho_lds_floats;
       f.ho_out = d.ho_out; f.ho_pk = d.ho_pk; f.ho_dst = other.ho_region;
       other.ho_filled = true; d.ho_filled = false;
     }
@@ -935,9 +865,10 @@ int bnmtf_create(const bnmtf_problem* p, bnmtf_handle* out) {
   {
     const char* e = getenv("BNMTF_HANDOVER");
     const bool want = !(e && atoi(e) == 0) && p->L == 0 && !h->comm;
-    if (want && build_handover(h->rows, h->cols) && build_handover(h->cols, h->rows)) h->rows.ho_ready = h->cols.ho_ready = h->ho_enabled = true;
+    const auto t_ho0 = std::chrono::steady_clock::now();
+    if (want && build_handover(h, h->rows, h->cols) && build_handover(h, h->cols, h->rows)) h->rows.ho_ready = h->cols.ho_ready = h->ho_enabled = true;
     if (const char* r = getenv("BNMTF_HANDOVER_REFRESH")) h->ho_refresh = (uint64_t)std::max(1, atoi(r));
-    for (Dir* d : {&h->rows, &h->cols}) { std::vector<uint32_t>().swap(d->h_off); std::vector<uint32_t>().swap(d->h_pE); std::vector<uint32_t>().swap(d->h_pB); std::vector<int>().swap(d->h_umap); }
+    if (getenv("BNMTF_CREATE_TIMING")) fprintf(stderr, "hand-over tables: %.1f ms (create so far %.1f ms)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_ho0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create0).count());
   }
   h->create_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create0).count();
   char buf[768];

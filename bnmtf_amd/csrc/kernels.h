@@ -94,6 +94,7 @@ struct FastArgs {
   int nch, mh, pw1;            // chunks (1 or 2), first inner index of chunk 1 (multiple of 256), panel floats of chunk 1
   // q hand-over between the half sweeps (16-wave kernel, one GPU; model.h Dir::ho_*): read q from the block's region instead of
   // the pre-pass / write q sorted by the other direction's blocks at the end
+  int ho_lds_floats;           // floats behind the Gram in LDS that the hand-over's region / staging area needs (0: none)
   int ho_read, ho_write, ho_nb_other, ho_rows_total;       // ho_rows_total: slot rows of the whole direction (= the end of the last block's slice)
   const uint32_t* ho_in; const float* ho_region; const uint32_t* ho_region_ofs;
   const uint32_t* ho_out; const uint32_t* ho_pk; float* ho_dst;
@@ -148,6 +149,21 @@ struct PostArgs {
 void launch_post(const PostArgs& a, hipStream_t st);
 void launch_post_layout(const PostArgs& a, hipStream_t st);                       // XT / XT2 (/ S2T / XS) of every row
 void launch_post_gram_rows(const PostArgs& a, int own0, int own1, hipStream_t st);   // C64, colsum (, colsum2) of the rows [own0, own1) only
+// q hand-over tables of one writer / reader pair of directions, built on the device (kernel_handover.hip)
+struct HandoverArgs {
+  // the writer's and the reader's slot layouts (FastArgs::off, pair_base, pair_E, unit_map), blocks of 16 pairs, inner extents
+  const uint32_t* w_off; const uint32_t* w_pB; const uint32_t* w_pE; const int* w_umap; int w_nb; uint32_t w_inner;
+  const uint32_t* r_off; const uint32_t* r_pB; const uint32_t* r_pE; const int* r_umap; int r_nb; uint32_t r_inner;
+  const uint16_t* r_row_blk;                 // reader: block of every slot row
+  const uint32_t* r_ptr; const uint32_t* r_idx;   // reader: sorted missing inner indices per unit (Dir::slot_ptr, Dir::idx)
+  // scratch
+  uint32_t* inv; uint32_t* dst_slot; uint32_t* dst_rank; uint32_t* count;
+  uint32_t* sbase; uint32_t* stotal; uint32_t* rbase; uint32_t* rdata; uint32_t* rsize;
+  // results
+  uint32_t* rofs; uint16_t* t_out; uint16_t* t_in; uint32_t* pk;
+  uint32_t* limits;                          // [0] longest staging area, [1] largest region, [2] entries without a partner, [3] all regions (entries)
+};
+void launch_handover_build(const HandoverArgs& a, hipStream_t st);
 void launch_gram_cast(const double* C64, float* C32, int n, hipStream_t st);      // C32 = (float) C64 after the partial sums were all-reduced
 constexpr int kPostRows = 32;
 inline int post_blocks(int rows) { return (rows + kPostRows - 1) / kPostRows; }

@@ -72,10 +72,10 @@ struct Dir {
   uint32_t* ho_pk = nullptr;            // [blocks][blocks of the other direction][3]: staging start, count, global offset in the other's regions
   uint32_t* ho_region_ofs = nullptr;    // [blocks + 1] first entry of each block's region
   float* ho_region = nullptr;           // the regions: what the other direction's sweep writes and this one reads
-  int ho_blocks = 0;
+  int ho_blocks = 0, ho_lds_floats = 0;  // ... and the LDS floats the region (as reader) and the staging area (as writer) take
   bool ho_ready = false;                // tables exist
   mutable bool ho_filled = false;       // the regions hold q of the current (X, Xo)
-  std::vector<uint32_t> h_off, h_pE, h_pB; std::vector<int> h_umap; std::vector<std::vector<uint32_t>> h_miss;   // host copies kept until build_handover has run
+  uint16_t* f_row_blk = nullptr;        // block (of 16 pairs) of every slot row: build_handover's input
   bool gram_packed = false;             // colsum / colsum2 live behind C64 in one allocation (what exchange_factor all-reduces)
   hipEvent_t ev_sweep = nullptr, ev_gram = nullptr, ev_gathered = nullptr, ev_gram_all = nullptr;   // exchange_factor (several GPUs)
   float* snap_dst = nullptr;            // set for ONE relayout: where its rows also go, packed [rows][W] (run()'s sample hand-off)
@@ -144,7 +144,7 @@ struct bnmtf_model {
   float cur_min_x = 0.f;                 // clamp in force for the sweeps being enqueued
   uint32_t profiling = 0;                // bit k: bracket the launches of kernel k with events
   bool ho_enabled = false, ho_active = false;   // q hand-over between the half sweeps (Dir::ho_*): tables built / in use by the running loop
-  uint64_t ho_refresh = 8;                      // the rows sweep runs its pre-pass every ho_refresh-th iteration
+  uint64_t ho_refresh = 64;                     // the rows sweep runs its pre-pass every ho_refresh-th iteration
   uint64_t profile_stride = 1;           // ... in every profile_stride-th iteration
   double kernel_ms[BNMTF_KERNEL_COUNT] = {0};
   uint64_t kernel_launches[BNMTF_KERNEL_COUNT] = {0};

@@ -69,6 +69,47 @@ def test_wide_kernel_equals_generic_kernel_and_oracle(monkeypatch, I, J, K, lo, 
     np.testing.assert_allclose(b.all_performances["MSE"], o.all_performances["MSE"], rtol=2e-4)
 
 
+@pytest.mark.parametrize("I,J,K,lo,hi", [(640, 800, 64, 0.0, 0.9), (513, 389, 32, 0.05, 0.5), (1500, 2048, 40, 0.08, 0.12)])
+def test_q_handed_over_between_the_half_sweeps_equals_the_pre_pass(monkeypatch, I, J, K, lo, hi):
+    """One GPU, 16-wave blocks on both directions: q of the missing entries goes from the end of one half sweep to the start of
+    the next through block-sorted packets instead of being rebuilt by the pre-pass.  Same chain as with the
+    pre-pass (BNMTF_HANDOVER=0) up to fp32 rounding; never refreshed, twelve mode updates still follow the fp64 oracle."""
+    monkeypatch.setenv("BNMTF_WIDE", "1")
+    rs = np.random.RandomState(I * 3 + J)
+    U0 = rs.exponential(1.0, (I, K)); V0 = rs.exponential(1.0, (J, K))
+    R = U0 @ V0.T + rs.randn(I, J)
+    M = _ragged_mask(rs, I, J, lo, hi)
+    runs = {}
+    for ho in ("1", "0"):
+        monkeypatch.setenv("BNMTF_HANDOVER", ho)
+        monkeypatch.setenv("BNMTF_HANDOVER_REFRESH", "1000000")
+        b = bnmf_gibbs_optimised(R, M, K, PRI, verbose=False, seed=5)
+        assert ("handover=1" in b.describe()) == (ho == "1")
+        np.random.seed(2); b.initialise("random")
+        b.run(3)
+        draw = (b.all_U.copy(), b.all_V.copy(), np.array(b.all_performances["MSE"]))
+        np.random.seed(2); b.initialise("random")
+        U_init, V_init, tau_init = b.U.copy(), b.V.copy(), b.tau
+        b.run(12, update="mode")
+        runs[ho] = draw + (b.all_U.copy(), b.all_V.copy(), b.all_tau.copy(), np.array(b.all_performances["MSE"]))
+    h, p = runs["1"], runs["0"]
+    # draws: the first iteration's U is bit-for-bit the same (its rows sweep runs the pre-pass either way), V (the first reader of
+    # handed-over q) agrees except where an fp32 rounding flips a rejection
+    assert np.array_equal(h[0][0], p[0][0])
+    d = np.abs(h[1][0] - p[1][0]) / (np.abs(p[1][0]) + 1e-3)
+    assert np.mean(d < 1e-3) > 0.995
+    np.testing.assert_allclose(h[2][:2], p[2][:2], rtol=2e-3)
+    # mode updates: deterministic, so the two paths stay together, and both follow the oracle
+    sU = np.abs(p[3][-1]).max(); sV = np.abs(p[4][-1]).max()
+    assert np.abs(h[3][-1] - p[3][-1]).max() <= 2e-4 * sU and np.abs(h[4][-1] - p[4][-1]).max() <= 2e-4 * sV
+    o = O.BNMFGibbsOracle(R, M, K, PRI)
+    o.U, o.V, o.tau = U_init, V_init, tau_init
+    o.run(12, draw=False)
+    assert np.abs(h[3][-1] - o.all_U[-1]).max() <= 1e-3 * sU and np.abs(h[4][-1] - o.all_V[-1]).max() <= 1e-3 * sV
+    np.testing.assert_allclose(h[5], o.all_tau, rtol=5e-4)
+    np.testing.assert_allclose(h[6], o.all_performances["MSE"], rtol=5e-4)
+
+
 def test_headline_shape_properties():
     """8192 x 8192, K = 64, 10 % missing (the bench configuration): the observed counts are exact, the metrics from the
     Gram identities equal the direct fp64 metric kernel on the same sample, the chain reaches the noise floor, and the
