@@ -295,16 +295,18 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
       CHK(dalloc(&d.f_gen_units, std::max<size_t>(gen.size(), 1), false));
       if (!gen.empty()) HIPCHK(hipMemcpy(d.f_gen_units, gen.data(), gen.size() * sizeof(int), hipMemcpyHostToDevice));
       d.stats_blocks = std::max((d.f_npairs + d.f_nw - 1) / d.f_nw, sweep_vb_blocks(d.f_npairs)) + 2;   // the VB sweep writes its own block count of rows
+      // the block of every slot row: what build_handover needs beside the layout itself (one GPU, the 16-wave shape or the
+      // plain 8-wave shape, every unit on the on-chip kernel)
+      if (world == 1 && !d.use_turns && d.pair_ok && d.f_gen_count == 0 && nch == 1 && (d.f_nw == 16 || d.f_nw == 8) && d.f_npairs / d.f_nw < 65535) {
+        d.ho_ppb = d.f_nw;
+        std::vector<uint16_t> row_blk(std::max<size_t>(rows_total, 1), 0);
+        for (int pi = 0; pi < d.f_npairs; ++pi)
+          for (uint32_t sidx = 0; sidx < pE[pi]; ++sidx) row_blk[pB[pi] + sidx] = (uint16_t)(pi / d.ho_ppb);
+        CHK(dalloc(&d.f_row_blk, row_blk.size(), false));
+        HIPCHK(hipMemcpy(d.f_row_blk, row_blk.data(), row_blk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+      }
     }
     CHK(dalloc(&d.stats, (size_t)d.stats_blocks * 4));
-    // the block of every slot row: what build_handover needs beside the layout itself
-    if (d.use_wide && !d.use_turns && world == 1 && d.pair_ok && d.f_gen_count == 0 && d.f_npairs / 16 < 65536) {
-      std::vector<uint16_t> row_blk(std::max<size_t>(rows_total, 1), 0);
-      for (int pi = 0; pi < d.f_npairs; ++pi)
-        for (uint32_t sidx = 0; sidx < pE[pi]; ++sidx) row_blk[pB[pi] + sidx] = (uint16_t)(pi / 16);
-      CHK(dalloc(&d.f_row_blk, row_blk.size(), false));
-      HIPCHK(hipMemcpy(d.f_row_blk, row_blk.data(), row_blk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    }
   }
 
   CHK(dalloc(&d.big, big.size(), false));
@@ -333,8 +335,8 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
 // layouts (kernel_handover.hip).  Returns false (and leaves the pair without hand-over) if a staging area or a region would
 // not fit the block's LDS or its 16-bit offsets.
 static bool build_handover(bnmtf_model* h, Dir& W, Dir& Rd) {
-  if (!W.f_row_blk || !Rd.f_row_blk || W.f_npairs % 16 || Rd.f_npairs % 16 || W.f_npairs == 0 || Rd.f_npairs == 0) return false;
-  const int nbW = W.f_npairs / 16, nbR = Rd.f_npairs / 16;
+  if (!W.f_row_blk || !Rd.f_row_blk || W.f_npairs == 0 || Rd.f_npairs == 0) return false;
+  const int nbW = (W.f_npairs + W.ho_ppb - 1) / W.ho_ppb, nbR = (Rd.f_npairs + Rd.ho_ppb - 1) / Rd.ho_ppb;
   if (nbR > 8192) return false;                         // (the destination kernel counts per reader block in LDS)
   const size_t rowsW = W.f_slots, rowsR = Rd.f_slots;
   DevBuf<uint32_t> inv, dst_slot, dst_rank, count, sbase, stotal, rbase, rdata, rsize, limits;
@@ -347,8 +349,8 @@ static bool build_handover(bnmtf_model* h, Dir& W, Dir& Rd) {
   W.ho_out = reinterpret_cast<uint32_t*>(t_out); Rd.ho_in = reinterpret_cast<uint32_t*>(t_in);
   if (dalloc(&W.ho_pk, (size_t)nbW * nbR * 3, false) || dalloc(&Rd.ho_region_ofs, (size_t)nbR + 1, false)) return false;
   HandoverArgs a;
-  a.w_off = W.f_off; a.w_pB = W.f_pair_base; a.w_pE = W.f_pair_E; a.w_umap = W.f_unit_map; a.w_nb = nbW; a.w_inner = (uint32_t)Rd.nglob;
-  a.r_off = Rd.f_off; a.r_pB = Rd.f_pair_base; a.r_pE = Rd.f_pair_E; a.r_umap = Rd.f_unit_map; a.r_nb = nbR; a.r_inner = (uint32_t)W.nglob;
+  a.w_off = W.f_off; a.w_pB = W.f_pair_base; a.w_pE = W.f_pair_E; a.w_umap = W.f_unit_map; a.w_npairs = W.f_npairs; a.w_ppb = W.ho_ppb; a.w_nb = nbW; a.w_inner = (uint32_t)Rd.nglob;
+  a.r_off = Rd.f_off; a.r_pB = Rd.f_pair_base; a.r_pE = Rd.f_pair_E; a.r_umap = Rd.f_unit_map; a.r_npairs = Rd.f_npairs; a.r_ppb = Rd.ho_ppb; a.r_nb = nbR; a.r_inner = (uint32_t)W.nglob;
   a.r_row_blk = Rd.f_row_blk; a.r_ptr = Rd.slot_ptr; a.r_idx = Rd.idx;
   a.inv = inv.p; a.dst_slot = dst_slot.p; a.dst_rank = dst_rank.p; a.count = count.p;
   a.sbase = sbase.p; a.stotal = stotal.p; a.rbase = rbase.p; a.rdata = rdata.p; a.rsize = rsize.p;
@@ -357,8 +359,10 @@ static bool build_handover(bnmtf_model* h, Dir& W, Dir& Rd) {
   uint32_t lim[4];
   if (hipMemcpyAsync(lim, limits.p, sizeof(lim), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return false;
   // staging area and region live behind the Gram in the block's LDS (160 KiB in all; the launch asks for what they need)
-  const uint32_t lds_floats = 160u * 1024u / 4u - (uint32_t)(W.KP * W.KP);
-  if (lim[2] != 0 || lim[0] + 256u + 32u > lds_floats || lim[0] + 32u > 65536u || lim[1] > lds_floats || lim[1] > 65536u) return false;
+  // (8-wave blocks run two to a CU: half the LDS each.  256: the VB kernel's small arrays ahead of the panels)
+  const uint32_t lds_w = (W.ho_ppb == 8 ? 80u : 160u) * 1024u / 4u - (uint32_t)(W.KP * W.KP) - 256u;
+  const uint32_t lds_r = (Rd.ho_ppb == 8 ? 80u : 160u) * 1024u / 4u - (uint32_t)(W.KP * W.KP) - 256u;
+  if (lim[2] != 0 || lim[0] + 256u + 32u > lds_w || lim[0] + 32u > 65536u || lim[1] > lds_r || lim[1] > 65536u) return false;
   W.ho_lds_floats = std::max(W.ho_lds_floats, (int)lim[0] + 256 + 32);
   Rd.ho_lds_floats = std::max(Rd.ho_lds_floats, (int)lim[1]);
   if (dalloc(&Rd.ho_region, (size_t)lim[3] + 256) != BNMTF_OK) return false;      // zero-filled: the zeros behind the runs are never written
@@ -428,6 +432,15 @@ static void drain_events(bnmtf_model* h) {
   h->pending_events.clear();
 }
 
+// q hand-over between the half sweeps, for the duration of one run call: from its first rows sweep (a pre-pass) on
+struct HandoverScope {
+  bnmtf_model* h;
+  explicit HandoverScope(bnmtf_model* h_) : h(h_) {
+    h->rows.ho_filled = h->cols.ho_filled = false;
+    h->ho_active = h->ho_enabled && !h->comm && h->use_fast;
+  }
+  ~HandoverScope() { h->ho_active = false; }
+};
 // ------------------------------------------------------------- step pieces
 static void enqueue_gemm(bnmtf_model* h, Dir& d, const Dir& other, int kid) {
   ScopedKernelTimer t(h, kid);
@@ -482,6 +495,21 @@ static int await_gram(bnmtf_model* h, Dir& d) {
   if (d.gram_pending) { HIPCHK(hipStreamWaitEvent(h->stream, d.ev_gram_all, 0)); d.gram_pending = false; }
   return BNMTF_OK;
 }
+// q hand-over between the half sweeps (the run loops switch it on: bnmf_gibbs_run, bnmf_vb_run): read this direction's region
+// if the other direction's last sweep filled it, fill the other's.  Every ho_refresh-th iteration the rows sweep runs its
+// pre-pass all the same: q handed back and forth collects one fp32 rounding per column update, the pre-pass starts from X
+// again (tools/handover_drift.py: no drift to see at 64).
+static void set_handover(bnmtf_model* h, Dir& d, const Dir& other, FastArgs& f, bool kernel_can) {
+  f.ho_read = f.ho_write = 0; f.ho_nb_other = 0; f.ho_lds_floats = 0; f.ho_rows_total = (int)d.f_slots;
+  f.ho_in = f.ho_out = f.ho_pk = f.ho_region_ofs = nullptr; f.ho_region = nullptr; f.ho_dst = nullptr;
+  if (!(h->ho_active && d.ho_ready && other.ho_ready && kernel_can)) return;
+  const bool refresh = &d == &h->rows && h->iteration % h->ho_refresh == 0;
+  f.ho_read = d.ho_filled && !refresh;
+  f.ho_in = d.ho_in; f.ho_region = d.ho_region; f.ho_region_ofs = d.ho_region_ofs;
+  f.ho_write = 1; f.ho_nb_other = other.ho_blocks; f.ho_lds_floats = d.ho_lds_floats;
+  f.ho_out = d.ho_out; f.ho_pk = d.ho_pk; f.ho_dst = other.ho_region;
+  other.ho_filled = true; d.ho_filled = false;
+}
 static void enqueue_sweep(bnmtf_model* h, Dir& d, const Dir& other, SweepArgs& s, bool want_stats) {
   s.unit_list = nullptr;
   h->last_sweep_fast = false;
@@ -495,19 +523,7 @@ static void enqueue_sweep(bnmtf_model* h, Dir& d, const Dir& other, SweepArgs& s
     SweepArgs s2 = s;
     s2.acc = nullptr;
     f.off16 = d.pair_ok ? d.f_off16 : nullptr;
-    // q hand-over (bnmf_gibbs_run switches it on): read this direction's region if the other direction's last sweep filled it,
-    // fill the other's.  Every kHandoverRefresh-th iteration the rows sweep runs its pre-pass all the same: q handed back and
-    // forth collects one fp32 rounding per column update, the pre-pass starts from X again.
-    f.ho_read = f.ho_write = 0; f.ho_nb_other = 0; f.ho_lds_floats = 0; f.ho_rows_total = (int)d.f_slots;
-    f.ho_in = f.ho_out = f.ho_pk = f.ho_region_ofs = nullptr; f.ho_region = nullptr; f.ho_dst = nullptr;
-    if (h->ho_active && d.ho_ready && other.ho_ready && d.use_wide && !d.use_turns && s.mode != kSweepVB) {
-      const bool refresh = &d == &h->rows && h->iteration % h->ho_refresh == 0;
-      f.ho_read = d.ho_filled && !refresh;
-      f.ho_in = d.ho_in; f.ho_region = d.ho_region; f.ho_region_ofs = d.ho_region_ofs;
-      f.ho_write = 1; f.ho_nb_other = other.ho_blocks; f.ho_lds_floats = d.ho_lds_floats;
-      f.ho_out = d.ho_out; f.ho_pk = d.ho_pk; f.ho_dst = other.ho_region;
-      other.ho_filled = true; d.ho_filled = false;
-    }
+    set_handover(h, d, other, f, !d.use_turns && d.nch == 1 && d.f_nw == d.ho_ppb && s.mode != kSweepVB);
     if (d.use_wide && d.use_turns) launch_sweep_turns(s2, f, h->stream);
     else if (d.use_wide) launch_sweep_wide(s2, f, h->stream);
     else launch_sweep_fast(s2, f, h->stream);
@@ -861,10 +877,13 @@ int bnmtf_create(const bnmtf_problem* p, bnmtf_handle* out) {
     if ((rcode = comm_create(&h->comm, id, 0, 1, h->stream))) return fail(rcode);
   }
 
-  // q hand-over tables (BNMF on one GPU with the 16-wave kernels on both directions; BNMTF_HANDOVER=0: off)
+  // q hand-over tables (BNMF on one GPU, both directions on the 16-wave or the plain 8-wave kernel).  By default only for
+  // problems of >= 64 blocks per direction: below that the sweep is launch-bound and the pre-pass costs next to nothing.
+  // BNMTF_HANDOVER=0: never; =1: whenever the tables can be built.
   {
     const char* e = getenv("BNMTF_HANDOVER");
-    const bool want = !(e && atoi(e) == 0) && p->L == 0 && !h->comm;
+    auto blocks = [](const Dir& d) { return d.ho_ppb > 0 ? d.f_npairs / d.ho_ppb : 0; };
+    const bool want = p->L == 0 && !h->comm && (e ? atoi(e) != 0 : std::min(blocks(h->rows), blocks(h->cols)) >= 64);
     const auto t_ho0 = std::chrono::steady_clock::now();
     if (want && build_handover(h, h->rows, h->cols) && build_handover(h, h->cols, h->rows)) h->rows.ho_ready = h->cols.ho_ready = h->ho_enabled = true;
     if (const char* r = getenv("BNMTF_HANDOVER_REFRESH")) h->ho_refresh = (uint64_t)std::max(1, atoi(r));
@@ -1047,9 +1066,7 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
   Dir& r = h->rows; Dir& c = h->cols;
   if (mode == kSweepDraw) CHK(stage_gamma_variates(h, n_iter));
   // q hand-over between the half sweeps: from this call's first rows sweep (a pre-pass) on; off again when the call returns
-  struct HandoverScope { bnmtf_model* h; ~HandoverScope() { h->ho_active = false; } } ho_scope{h};
-  r.ho_filled = c.ho_filled = false;
-  h->ho_active = h->ho_enabled && !h->comm && h->use_fast;
+  HandoverScope ho_scope{h};
   // the [3] accumulator is only written by the generic sweep kernel (and summed across ranks): zero once, reset when used
   const bool acc_used = h->comm != nullptr || !h->use_fast || !c.fast_ok || c.f_gen_count > 0 || !(c.nch == 2 || sweep_fast_supported(c.KP, c.pw));
   HIPCHK(hipMemsetAsync(h->acc, 0, 4 * sizeof(double), h->stream));

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(1024) void ho_destination_kernel(HandoverArgs a) {
   const int bw = blockIdx.x;
   for (int t = threadIdx.x; t < a.r_nb; t += 1024) cnt[t] = 0u;
   __syncthreads();
-  for (int pi = 16 * bw; pi < 16 * bw + 16; ++pi) {
+  for (int pi = a.w_ppb * bw; pi < min(a.w_ppb * (bw + 1), a.w_npairs); ++pi) {
     const uint32_t E = a.w_pE[pi], base = a.w_pB[pi];
     for (uint32_t t = threadIdx.x; t < E * 64u; t += 1024u) {
       const uint32_t l = t & 63u;
@@ -106,11 +106,11 @@ __device__ __forceinline__ size_t half_index(size_t row, uint32_t l) { return ((
 __global__ __launch_bounds__(256) void ho_reader_default_kernel(HandoverArgs a) {       // every slot of Rd: the zeros behind its block's runs
   const int pi = blockIdx.x;
   const uint32_t E = a.r_pE[pi], base = a.r_pB[pi];
-  const uint32_t zero0 = a.rdata[pi / 16];
+  const uint32_t zero0 = a.rdata[pi / a.r_ppb];
   for (uint32_t t = threadIdx.x; t < E * 64u; t += 256u) a.t_in[half_index((size_t)base + (t >> 6), t & 63u)] = (uint16_t)(zero0 + (t & 31u));
 }
 __global__ __launch_bounds__(256) void ho_tables_kernel(HandoverArgs a) {
-  const int pi = blockIdx.x, bw = pi / 16;
+  const int pi = blockIdx.x, bw = pi / a.w_ppb;
   const uint32_t E = a.w_pE[pi], base = a.w_pB[pi];
   for (uint32_t t = threadIdx.x; t < E * 64u; t += 256u) {
     const uint32_t l = t & 63u;
@@ -127,13 +127,13 @@ __global__ __launch_bounds__(256) void ho_tables_kernel(HandoverArgs a) {
 }
 
 void launch_handover_build(const HandoverArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(ho_inverse_kernel, dim3(16 * a.r_nb), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(ho_inverse_kernel, dim3(a.r_npairs), dim3(256), 0, st, a);
   hipLaunchKernelGGL(ho_destination_kernel, dim3(a.w_nb), dim3(1024), sizeof(uint32_t) * (size_t)a.r_nb, st, a);
   hipLaunchKernelGGL(ho_scan_kernel, dim3(a.w_nb + a.r_nb), dim3(64), 0, st, a);
   hipLaunchKernelGGL(ho_region_starts_kernel, dim3(1), dim3(64), 0, st, a);
   hipLaunchKernelGGL(ho_packets_kernel, dim3(a.w_nb), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(ho_reader_default_kernel, dim3(16 * a.r_nb), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(ho_tables_kernel, dim3(16 * a.w_nb), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(ho_reader_default_kernel, dim3(a.r_npairs), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(ho_tables_kernel, dim3(a.w_npairs), dim3(256), 0, st, a);
 }
 
 }  // namespace bnmtf

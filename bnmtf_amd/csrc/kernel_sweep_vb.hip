@@ -101,6 +101,10 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
     if (f.stats) sync_with_dma();
     return;
   }
+  // q hand-over between the half sweeps (FastArgs::ho_*; the 16-wave shape on one GPU): q = E[U_i] . E[V_j] of the missing
+  // entries comes from the region the other direction's sweep filled, not from a pre-pass, and goes on at the end
+  const bool ho_read = NS == 0 && f.ho_read, ho_write = NS == 0 && f.ho_write;
+  if (ho_read) ho_issue_region<NW>(f, pan, wave, lane);
   const int pair = blockIdx.x * NW + wave;
   const bool wave_on = pair < f.npairs;
   const uint32_t base = wave_on ? f.pair_base[pair] : 0u;
@@ -134,6 +138,11 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
     addr[2 * h + 1] = pan_b + 8u * (w >> 16);
     q2[h] = f32x2{0.f, 0.f}; vp2[h] = f32x2{0.f, 0.f};
   }
+  uint32_t win[EH];
+  if (ho_read) {
+#pragma unroll
+    for (int h = 0; h < EH; ++h) win[h] = (2 * h < E) ? f.ho_in[((size_t)(base >> 1) + h) * 64 + lane] : 0u;
+  }
   for (int t = tid; t < KP * KP; t += NW * 64) Cs[t] = a.C32[t];
   if (tid < KP) c2s[tid] = (float)a.colsum2_o[tid];
   // NS == 0: wave 0, lane un: the unit it evaluates the moments for
@@ -144,7 +153,13 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
     mgi = uu >= 0 ? a.n0 + uu : -1;
   }
   // ------------------------------------------------------------ pre-pass: q = E[U_i] . E[V_j]  (pair panels of E)
-  {
+  if (ho_read) {
+    sync_with_dma();
+#pragma unroll
+    for (int h = 0; h < EH; ++h)
+      if (2 * h < E) q2[h] = f32x2{pan[win[h] & 0xFFFFu], pan[win[h] >> 16]};
+    sync_with_dma();
+  } else {
     const uint32_t stride_b = (uint32_t)f.ld2_o * 8u;
     const __amdgpu_buffer_rsrc_t rs2 = panel_rsrc(f.XoT2, (size_t)(KP / 2) * f.ld2_o * 8);
     if (NS == 0) stage_panel_buf<NW>(rs2, 0u, pan, chunks2, wave, lane * 16);
@@ -185,6 +200,12 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
 #ifdef BNMTF_PHASE_TIMING
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = tick(q2[0].x);
 #endif
+  // hand-over epilogue's offset table through LDS: the block's slice of ho_out (first word ho_w0, ho_np pieces of 256 words =
+  // 4 slot-pair rows) lands in column K - 2's panel buffer during that column's moments window, when no panel is left to stage
+  const uint32_t ho_row0 = ho_write ? f.pair_base[blockIdx.x * NW] >> 1 : 0u;
+  const uint32_t ho_rows = ho_write ? ((blockIdx.x * NW + NW < (uint32_t)f.npairs ? f.pair_base[blockIdx.x * NW + NW] : (uint32_t)f.ho_rows_total) >> 1) - ho_row0 : 0u;
+  const int ho_np = (int)((ho_rows + 3u) / 4u);
+  const bool ho_lds = ho_write && K >= 2 && ho_np <= chunks2;
   float dprev = 0.f;
   for (int k = 0; k < K; ++k) {
     const uint32_t boff = (uint32_t)(k & 1) * buf_b;
@@ -241,6 +262,12 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
       for (int c = wave - 1; c < chunks2; c += NW - 1)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(dst + (size_t)c * 256), 16, lane * 16,
                                                   (int)((uint32_t)(k + 2) * cstride_b + (uint32_t)c * 1024u), 0, 0);
+    } else if (NS == 0 && wave >= 1 && ho_lds && k + 2 == K) {
+      typedef __attribute__((address_space(3))) void* lds_ptr;
+      float* dst = pan + (size_t)(k & 1) * 2 * PW;
+      const __amdgpu_buffer_rsrc_t rso = panel_rsrc(reinterpret_cast<const float*>(f.ho_out) + (size_t)ho_row0 * 64, (size_t)ho_rows * 256);
+      for (int c = wave - 1; c < ho_np; c += NW - 1)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rso, (lds_ptr)(dst + (size_t)c * 256), 16, lane * 16, (int)((uint32_t)c * 1024u), 0, 0);
     }
     if (NS == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS traffic only: the pieces just issued have all of column k + 1 to land (its first barrier waits for them)
     else sync_with_dma();                // service-wave shape: also lands the next panel (vmcnt) and retires this one
@@ -261,6 +288,28 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
   if (blockIdx.x % 101 == 0 && (tid & 127) == 0)
     printf("vb block %d wave %d EM %d: A %llu  BC %llu  reduce+post %llu  wait1 %llu  window %llu (cycles, %d columns)\n", (int)blockIdx.x, wave, EM, ph[0], ph[1], ph[2], ph[3], ph[4], K);
 #endif
+  // ------------------------------------------------------------ hand-over: the final q, sorted by the other direction's blocks
+  float* stage = pan + 256;            // (the first 256 floats: the statistics' partial sums below)
+  if (ho_write) {
+    uint32_t wo[EH];
+    if (ho_lds) {
+      sync_with_dma();                 // the slice staged in column K - 2's window has landed
+      const float* src = pan + (size_t)((K - 2) & 1) * 2 * PW + (size_t)((base >> 1) - ho_row0) * 64 + lane;
+#pragma unroll
+      for (int h = 0; h < EH; ++h) wo[h] = (2 * h < E) ? __builtin_bit_cast(uint32_t, src[h * 64]) : 0u;
+    } else {
+#pragma unroll
+      for (int h = 0; h < EH; ++h) wo[h] = (2 * h < E) ? f.ho_out[((size_t)(base >> 1) + h) * 64 + lane] : 0u;
+    }
+    sync_with_dma();                   // the staging area takes the panels' bytes: everybody is done with them (and with `ret`)
+#pragma unroll
+    for (int h = 0; h < EH; ++h)
+      if (2 * h < E) {
+        stage[wo[h] & 0xFFFFu] = fmaf(dprev, vp2[h].x, q2[h].x);
+        stage[wo[h] >> 16] = fmaf(dprev, vp2[h].y, q2[h].y);
+      }
+    if (!f.stats) sync_with_dma();
+  }
   // ------------------------------------------------------------ the three sums of the SSE identity (cols sweep)
   if (f.stats) {
     double px = 0.0, sq = 0.0, sq2 = 0.0;
@@ -281,6 +330,7 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
       f.stats[(size_t)blockIdx.x * 4 + tid] = s;
     }
   }
+  if (ho_write) ho_send_packets<NW>(f, stage, wave, lane);
 }
 
 template <int NX, int NW, int NS>
@@ -305,7 +355,7 @@ template <int NX, int NW, int NS>
 static void launch_vb_inst(const SweepArgs& a, const FastArgs& f, hipStream_t st) {
   static std::atomic<uint64_t> lds_ok{0};
   const int nblocks = sweep_vb_blocks(f.npairs, NW);
-  if (nblocks > 0 && allow_full_lds((const void*)sweep_vb_kernel<NX, NW, NS>, lds_ok)) hipLaunchKernelGGL((sweep_vb_kernel<NX, NW, NS>), dim3(nblocks), dim3((NW + NS) * 64), sweep_vb_lds_bytes(a.KP, f.pw), st, a, f);
+  if (nblocks > 0 && allow_full_lds((const void*)sweep_vb_kernel<NX, NW, NS>, lds_ok)) hipLaunchKernelGGL((sweep_vb_kernel<NX, NW, NS>), dim3(nblocks), dim3((NW + NS) * 64), std::max(sweep_vb_lds_bytes(a.KP, f.pw), sizeof(float) * ((size_t)a.KP * a.KP + a.KP + 2 * 16 * 5 + (size_t)f.ho_lds_floats)), st, a, f);
 }
 
 // f.nw = 16: 16 unit waves per block; anything else: 8 unit waves + 2 service waves

@@ -151,9 +151,10 @@ void launch_post_layout(const PostArgs& a, hipStream_t st);                     
 void launch_post_gram_rows(const PostArgs& a, int own0, int own1, hipStream_t st);   // C64, colsum (, colsum2) of the rows [own0, own1) only
 // q hand-over tables of one writer / reader pair of directions, built on the device (kernel_handover.hip)
 struct HandoverArgs {
-  // the writer's and the reader's slot layouts (FastArgs::off, pair_base, pair_E, unit_map), blocks of 16 pairs, inner extents
-  const uint32_t* w_off; const uint32_t* w_pB; const uint32_t* w_pE; const int* w_umap; int w_nb; uint32_t w_inner;
-  const uint32_t* r_off; const uint32_t* r_pB; const uint32_t* r_pE; const int* r_umap; int r_nb; uint32_t r_inner;
+  // the writer's and the reader's slot layouts (FastArgs::off, pair_base, pair_E, unit_map), pairs, pairs per block (the sweep
+  // kernel's unit waves: 16 or 8), blocks, inner extents
+  const uint32_t* w_off; const uint32_t* w_pB; const uint32_t* w_pE; const int* w_umap; int w_npairs, w_ppb, w_nb; uint32_t w_inner;
+  const uint32_t* r_off; const uint32_t* r_pB; const uint32_t* r_pE; const int* r_umap; int r_npairs, r_ppb, r_nb; uint32_t r_inner;
   const uint16_t* r_row_blk;                 // reader: block of every slot row
   const uint32_t* r_ptr; const uint32_t* r_idx;   // reader: sorted missing inner indices per unit (Dir::slot_ptr, Dir::idx)
   // scratch

@@ -128,6 +128,49 @@ __device__ __forceinline__ void stage_panel_buf(__amdgpu_buffer_rsrc_t rsrc, uin
 // pieces waits for vmcnt(0) explicitly.
 __device__ __forceinline__ void sync_with_dma() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// ---- q hand-over between the half sweeps (FastArgs::ho_*, model.h Dir::ho_*, kernel_handover.hip): the pieces the Gibbs
+// kernel (sweep_chip.inc) and the VB kernel (kernel_sweep_vb.hip) share
+// the block's region -- q of its missing entries as the other direction's sweep left them -- on its way into LDS at `dst`
+template <int NW>
+__device__ __forceinline__ void ho_issue_region(const FastArgs& f, float* dst, int wave, int lane) {
+  const uint32_t r0 = f.ho_region_ofs[blockIdx.x], r1 = f.ho_region_ofs[blockIdx.x + 1];       // entries, multiples of 256
+  stage_panel_buf<NW>(panel_rsrc(f.ho_region + r0, (size_t)(r1 - r0) * 4), 0u, dst, (int)((r1 - r0) / 256), wave, lane * 16);
+}
+// the staged runs go out, one contiguous packet per destination block.  A packet per half wave and pass (32 lanes x 4 entries
+// cover most runs at once); the descriptors of 16 packets -- (start in the staging area, entries, start in the other
+// direction's regions), multiples of 4 -- are fetched by one load per wave.
+template <int NW>
+__device__ __forceinline__ void ho_send_packets(const FastArgs& f, const float* stage, int wave, int lane) {
+  const int half = lane >> 5, l5 = lane & 31;
+  const uint32_t* pk = f.ho_pk + (size_t)blockIdx.x * f.ho_nb_other * 3;
+  for (int p0 = 16 * wave; p0 < f.ho_nb_other; p0 += 16 * NW) {
+    const int np = min(16, f.ho_nb_other - p0);
+    uint32_t d0 = 0;
+    if (lane < 3 * np) d0 = pk[3 * p0 + lane];
+    auto word = [&](int wd) { return (uint32_t)__shfl((int)d0, wd & 63); };
+    for (int i = 0; i < np; i += 4) {
+      // half 0 takes packets i and i + 2, half 1 packets i + 1 and i + 3 (words 3 p .. 3 p + 2 of the descriptor list)
+      // (every lane takes part in every shuffle: a lane switched off by a condition would hand its neighbours nothing)
+      const int pa = i + half, pb = i + 2 + half;
+      const uint32_t sa = word(3 * pa), ca_all = word(3 * pa + 1), ga = word(3 * pa + 2);
+      const uint32_t sb = word(3 * pb), cb_all = word(3 * pb + 1), gb = word(3 * pb + 2);
+      const uint32_t ca = pa < np ? ca_all : 0u, cb = pb < np ? cb_all : 0u;
+      const uint32_t l0 = (uint32_t)l5 * 4u;
+      float4 va = {}, va2 = {}, vb = {}, vb2 = {};
+      if (l0 < ca) va = *reinterpret_cast<const float4*>(stage + sa + l0);
+      if (l0 + 128u < ca) va2 = *reinterpret_cast<const float4*>(stage + sa + l0 + 128u);
+      if (l0 < cb) vb = *reinterpret_cast<const float4*>(stage + sb + l0);
+      if (l0 + 128u < cb) vb2 = *reinterpret_cast<const float4*>(stage + sb + l0 + 128u);
+      if (l0 < ca) *reinterpret_cast<float4*>(f.ho_dst + ga + l0) = va;
+      if (l0 + 128u < ca) *reinterpret_cast<float4*>(f.ho_dst + ga + l0 + 128u) = va2;
+      if (l0 < cb) *reinterpret_cast<float4*>(f.ho_dst + gb + l0) = vb;
+      if (l0 + 128u < cb) *reinterpret_cast<float4*>(f.ho_dst + gb + l0 + 128u) = vb2;
+      for (uint32_t l = l0 + 256u; l < ca; l += 128u) *reinterpret_cast<float4*>(f.ho_dst + ga + l) = *reinterpret_cast<const float4*>(stage + sa + l);   // (long runs: rare)
+      for (uint32_t l = l0 + 256u; l < cb; l += 128u) *reinterpret_cast<float4*>(f.ho_dst + gb + l) = *reinterpret_cast<const float4*>(stage + sb + l);
+    }
+  }
+}
+
 #ifdef BNMTF_PHASE_TIMING
 // debug build only (make timing): shader-clock stamps at the phase boundaries; a few blocks print their sums
 __device__ __forceinline__ unsigned long long tick(float dep) {

@@ -11,12 +11,15 @@ pytestmark = pytest.mark.gpu
 
 # BNMTF_WIDE=1 (read when the handle is created) selects the 16-unit-wave block shape of the VB sweep -- the shape the
 # 8192 x 8192 configuration runs, sweep_vb_kernel<., 16, 0> with the fp32 moments routine on wave 0 -- on any size
-SHAPES = pytest.mark.parametrize("wide", [None, "1"], ids=["8wave", "16wave"])
+# -- with q handed over between the half sweeps (the default there) and, "1-prepass", rebuilt by every sweep's
+# pre-pass (BNMTF_HANDOVER=0)
+SHAPES = pytest.mark.parametrize("wide", [None, "1", "1-prepass"], ids=["8wave", "16wave", "16wave-prepass"])
 
 
 def _shape(monkeypatch, wide):
     if wide is not None:
-        monkeypatch.setenv("BNMTF_WIDE", wide)
+        monkeypatch.setenv("BNMTF_WIDE", "1")
+        monkeypatch.setenv("BNMTF_HANDOVER", "0" if wide.endswith("prepass") else "1")
 
 
 @SHAPES
@@ -58,7 +61,7 @@ def test_ragged_case_matches_reference(golden, monkeypatch, wide):
     K = 4
     b = bnmf_vb_optimised(g["R"], g["M"], K, dict(alpha=2., beta=.5, lambdaU=g["lambdaU"], lambdaV=g["lambdaV"]), verbose=False)
     b.initialise('exp', {"tauU": g["tauU0"], "tauV": g["tauV0"]})
-    assert ("sweep_nw=16" in b.describe()) == (wide == "1")
+    assert ("sweep_nw=16" in b.describe()) == (wide is not None) and ("handover=1" in b.describe()) == (wide == "1")   # (small problems: only when asked for)
     b.run(10)
     np.testing.assert_allclose(b.all_performances['MSE'], g["mse"], rtol=1e-3)
     np.testing.assert_allclose(b.all_elbo, g["elbo"], rtol=1e-4)
@@ -134,7 +137,7 @@ def test_fast_vb_sweep_equals_generic_sweep(monkeypatch, wide):
             monkeypatch.setenv("BNMTF_VB_GENERIC", "1")
         b = bnmf_vb_optimised(R, M, K, pri, verbose=False)
         b.initialise('exp')
-        assert ("sweep_nw=16" in b.describe()) == (wide == "1")
+        assert ("sweep_nw=16" in b.describe()) == (wide is not None)
         b.run(6)
         res[mode] = (np.array(b.all_performances['MSE']), np.array(b.all_exp_tau), np.array(b.all_elbo), b.expU.copy(), b.varU.copy(), b.tauV.copy())
     f, g = res["fast"], res["generic"]
