@@ -163,6 +163,10 @@ void launch_post(const PostArgs& a0, hipStream_t st) {
   PostArgs a = a0;
   a.do_layout = 1; a.do_gram = 1; a.blk0 = 0; a.own0 = 0; a.own1 = a.rows;
   const int nblk = post_blocks(a.rows);
+  if (const char* e = getenv("BNMTF_POST_ONLY")) {        // timing experiment (wrong results): one half of the kernel only
+    a.do_layout = e[0] == 'l'; a.do_gram = e[0] == 'g';
+    hipLaunchKernelGGL(post_kernel<false>, dim3(nblk, 1), dim3(256), 0, st, a);
+  } else
   if (a.S2) hipLaunchKernelGGL(post_kernel<true>, dim3(nblk, 2), dim3(256), 0, st, a); else hipLaunchKernelGGL(post_kernel<false>, dim3(nblk, 2), dim3(256), 0, st, a);
   const int nt = a.KP / 4, ps = nt * (nt + 1) / 2 * 16;
   hipLaunchKernelGGL(gram_reduce_kernel, dim3((ps + 31) / 32 + 1), dim3(1024), 0, st, a, nblk);
