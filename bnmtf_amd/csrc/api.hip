@@ -925,6 +925,9 @@ int bnmtf_destroy(bnmtf_handle h) {
   dfree(h->snap_dev);
   if (h->snap_host) (void)hipHostFree(h->snap_host);
   if (h->xchg_stream) { (void)hipStreamSynchronize(h->xchg_stream); (void)hipStreamDestroy(h->xchg_stream); }
+  if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
+  if (h->ev_aux0) (void)hipEventDestroy(h->ev_aux0);
+  if (h->ev_aux1) (void)hipEventDestroy(h->ev_aux1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return BNMTF_OK;

@@ -40,6 +40,33 @@ void launch_small_product(const SmallProductArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(small_product_kernel, dim3(blocks), dim3(256), 0, st, a);
 }
 
+// out[j][c] = sum_t (sum_s slabs[s][j][t]) S[t][c]: the G sweep's contraction R~^T (F S) as (R~^T F) S -- R~^T F is there
+// already (the S step's own contraction, F has not changed since), so the second pass over R~ shrinks to a K x L product per
+// column.  Half wave per unit: lane c holds the summed slab entry t = c and column c of the product.
+__global__ __launch_bounds__(256) void slab_product_kernel(SlabProductArgs a) {
+  __shared__ float Ss[64 * 64];
+  for (int t = threadIdx.x; t < a.K * a.L; t += 256) Ss[t] = a.S[t];
+  __syncthreads();
+  const int l5 = threadIdx.x & 31;
+  const int u = blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (u >= a.n) return;
+  const size_t stride = (size_t)a.n_pad * a.KPin;
+  for (int c0 = 0; c0 < a.KPout; c0 += 32) {
+    float acc = 0.f;
+    for (int t0 = 0; t0 < a.K; t0 += 32) {
+      const float tv = t0 + l5 < a.K ? slab_sum_ordered(a.slabs, a.split, stride, (size_t)u * a.KPin + t0 + l5) : 0.f;
+      for (int t = 0; t < 32 && t0 + t < a.K; ++t) {
+        const float x = __shfl(tv, t, 32);
+        if (c0 + l5 < a.L) acc = fmaf(x, Ss[(t0 + t) * a.L + c0 + l5], acc);
+      }
+    }
+    a.out[(size_t)u * a.KPout + c0 + l5] = c0 + l5 < a.L ? acc : 0.f;
+  }
+}
+void launch_slab_product(const SlabProductArgs& a, hipStream_t st) {
+  if (a.n > 0) hipLaunchKernelGGL(slab_product_kernel, dim3((a.n + 7) / 8), dim3(256), 0, st, a);
+}
+
 // CfS[k][l] = sum_k' Cf[k][k'] S[k'][l]
 __global__ void cfs_kernel(const double* Cf64, int KPk, const float* S, int K, int L, float* CfS) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -19,8 +19,14 @@ __device__ __forceinline__ void tri_tile(int p, int NT, int* ty, int* tx) {
 template <bool VB>
 __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
   constexpr int RB = kPostRows;
-  __shared__ float tile0[RB * 68], tile1[VB ? RB * 68 : 1];     // X rows ; VB: S2 rows (the Gibbs launches do not carry the second tile)
-  constexpr int LD = 68;
+  constexpr int LD = 68, LDD = 66;           // floats per row of a layout tile ; doubles per row of the Gram tile
+  // a layout block holds X rows (VB: and S2 rows) as floats; a Gram block holds its X rows as DOUBLES (converted once, when the
+  // tile is filled: the 4 x 4 products below would otherwise convert every operand of every row again, 17 x as many conversions)
+  __shared__ double smem[(RB * LDD * sizeof(double) >= (VB ? 2 : 1) * RB * LD * sizeof(float) ? RB * LDD : ((VB ? 2 : 1) * RB * LD + 1) / 2) + 4 * 64];
+  float* tile0 = reinterpret_cast<float*>(smem);
+  float* tile1 = tile0 + RB * LD;            // (VB layout blocks only)
+  double* dtile = smem;
+  double* dred = smem + RB * LDD;            // [4][64] column-sum partials
   const int KP = a.KP, tid = threadIdx.x;
   const int r0 = (a.blk0 + blockIdx.x) * RB;
   const int nr = min(RB, a.rows - r0);
@@ -28,66 +34,87 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
   // Each is half as long, and twice as many blocks hide each other's load -> store / load -> FMA latencies.
   // (a launch that does only one of the two has one block per group)
   const bool do_layout = a.do_layout && (!a.do_gram || blockIdx.y == 0), do_gram = a.do_gram && (!a.do_layout || blockIdx.y == 1);
+  if (do_gram) {
+    for (int pass = 0; pass < (VB ? 2 : 1); ++pass) {
+      const float* src = pass == 0 ? a.X : a.S2;
+      if (pass == 1) __syncthreads();
+      for (int t = tid; t < RB * KP; t += 256) {
+        const int r = t / KP, k = t % KP;
+        // (Gram-only launches of a multi-GPU run: rows of other ranks count as zero)
+        dtile[r * LDD + k] = (r < nr && (a.do_layout || (r0 + r >= a.own0 && r0 + r < a.own1))) ? (double)src[(size_t)(r0 + r) * KP + k] : 0.0;
+      }
+      __syncthreads();
+      if (pass == 0) {
+        // Gram partial of this block's rows: C is symmetric, so only the 4x4 tiles on and above the diagonal are formed
+        // (NT (NT + 1) / 2 of NT^2, NT = KP / 4), one per thread, and stored packed -- 16 contiguous doubles per tile
+        const int NT = KP / 4, NU = NT * (NT + 1) / 2;
+        if (tid < NU) {
+          int ty, tx;
+          tri_tile(tid, NT, &ty, &tx);
+          double acc[4][4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+          const double* pa = dtile + 4 * ty;
+          const double* pb = dtile + 4 * tx;
+          // (rows beyond nr are zero: the loop runs over the whole tile, unrolled, operands of four rows in flight)
+#pragma unroll 4
+          for (int r = 0; r < RB; ++r) {
+            const double2 a01 = *reinterpret_cast<const double2*>(pa + r * LDD), a23 = *reinterpret_cast<const double2*>(pa + r * LDD + 2);
+            const double2 b01 = *reinterpret_cast<const double2*>(pb + r * LDD), b23 = *reinterpret_cast<const double2*>(pb + r * LDD + 2);
+            const double ad[4] = {a01.x, a01.y, a23.x, a23.y}, bd[4] = {b01.x, b01.y, b23.x, b23.y};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[i][j] = fma(ad[i], bd[j], acc[i][j]);
+          }
+          double2* out = reinterpret_cast<double2*>(a.Cpart + ((size_t)blockIdx.x * NU + tid) * 16);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { out[2 * i] = double2{acc[i][0], acc[i][1]}; out[2 * i + 1] = double2{acc[i][2], acc[i][3]}; }
+        }
+      }
+      // column sums: thread = column + 64 * group, a group adds every fourth row, the four partials meet in LDS
+      {
+        const int col = tid & 63, grp = tid >> 6;
+        double sp = 0.0;
+        if (col < KP)
+#pragma unroll
+          for (int r = grp; r < RB; r += 4) sp += dtile[r * LDD + col];
+        dred[grp * 64 + col] = sp;
+        __syncthreads();
+        if (tid < KP) (pass == 0 ? a.spart : a.s2part)[(size_t)blockIdx.x * KP + tid] = (dred[tid] + dred[64 + tid]) + (dred[128 + tid] + dred[192 + tid]);
+      }
+    }
+    return;
+  }
+  if (!do_layout) return;
   const float* src = a.X;
   for (int pass = 0; pass < (VB ? 2 : 1); ++pass) {
     float* tile = pass == 0 ? tile0 : tile1;
     if (pass == 1) src = a.S2;
     for (int t = tid; t < RB * KP; t += 256) {
       const int r = t / KP, k = t % KP;
-      // (Gram-only launches of a multi-GPU run: rows of other ranks count as zero)
-      tile[r * LD + k] = (r < nr && (do_layout || (r0 + r >= a.own0 && r0 + r < a.own1))) ? src[(size_t)(r0 + r) * KP + k] : 0.f;
+      tile[r * LD + k] = r < nr ? src[(size_t)(r0 + r) * KP + k] : 0.f;
     }
     __syncthreads();
     float* T1 = pass == 0 ? a.XT : a.S2T;
-    if (T1 && do_layout)
+    if (T1)
       for (int t = tid; t < RB * KP; t += 256) {
         const int k = t / RB, r = t % RB;
         if (r < nr) T1[(size_t)k * a.ldT + r0 + r] = tile[r * LD + k];
       }
-    if (pass == 0 && a.snap && do_layout)
+    if (pass == 0 && a.snap)
       for (int t = tid; t < RB * a.snapW; t += 256) {
         const int r = t / a.snapW, k = t % a.snapW;
         if (r < nr) a.snap[(size_t)(r0 + r) * a.snapW + k] = tile[r * LD + k];
       }
-    if (pass == 0 && a.XT2 && do_layout)
+    if (pass == 0 && a.XT2)
       for (int t = tid; t < RB * KP; t += 256) {
         const int kp = t / (2 * RB), rem = t % (2 * RB), r = rem >> 1, c = rem & 1;
         if (r < nr) a.XT2[((size_t)kp * a.ld2 + r0 + r) * 2 + c] = tile[r * LD + 2 * kp + c];
       }
-    if (pass == 0 && do_gram) {
-      // Gram partial of this block's rows: C is symmetric, so only the 4x4 tiles on and above the diagonal are formed
-      // (NT (NT + 1) / 2 of NT^2, NT = KP / 4), one per thread, and stored packed -- 16 contiguous doubles per tile
-      const int NT = KP / 4, NU = NT * (NT + 1) / 2;
-      if (tid < NU) {
-        int ty, tx;
-        tri_tile(tid, NT, &ty, &tx);
-        double acc[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-        for (int r = 0; r < nr; ++r) {
-          const float4 av = *reinterpret_cast<const float4*>(&tile[r * LD + 4 * ty]);
-          const float4 bv = *reinterpret_cast<const float4*>(&tile[r * LD + 4 * tx]);
-          const double ad[4] = {av.x, av.y, av.z, av.w}, bd[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = fma(ad[i], bd[j], acc[i][j]);
-        }
-        double* out = a.Cpart + ((size_t)blockIdx.x * NU + tid) * 16;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) out[i * 4 + j] = acc[i][j];
-      }
-    }
-    if (tid < KP && do_gram) {
-      double s = 0.0;
-      for (int r = 0; r < nr; ++r) s += (double)tile[r * LD + tid];
-      (pass == 0 ? a.spart : a.s2part)[(size_t)blockIdx.x * KP + tid] = s;
-    }
-    if (pass == 1 && a.XS && do_layout)        // VB: the (E, S2) pair panels of the fast VB sweep, [KP][ldT][2]
+    if (pass == 1 && a.XS)        // VB: the (E, S2) pair panels of the fast VB sweep, [KP][ldT][2]
       for (int t = tid; t < RB * KP; t += 256) {
         const int k = t / RB, r = t % RB;
         if (r < nr) *reinterpret_cast<float2*>(a.XS + ((size_t)k * a.ldT + r0 + r) * 2) = float2{tile0[r * LD + k], tile1[r * LD + k]};
@@ -163,10 +190,6 @@ void launch_post(const PostArgs& a0, hipStream_t st) {
   PostArgs a = a0;
   a.do_layout = 1; a.do_gram = 1; a.blk0 = 0; a.own0 = 0; a.own1 = a.rows;
   const int nblk = post_blocks(a.rows);
-  if (const char* e = getenv("BNMTF_POST_ONLY")) {        // timing experiment (wrong results): one half of the kernel only
-    a.do_layout = e[0] == 'l'; a.do_gram = e[0] == 'g';
-    hipLaunchKernelGGL(post_kernel<false>, dim3(nblk, 1), dim3(256), 0, st, a);
-  } else
   if (a.S2) hipLaunchKernelGGL(post_kernel<true>, dim3(nblk, 2), dim3(256), 0, st, a); else hipLaunchKernelGGL(post_kernel<false>, dim3(nblk, 2), dim3(256), 0, st, a);
   const int nt = a.KP / 4, ps = nt * (nt + 1) / 2 * 16;
   hipLaunchKernelGGL(gram_reduce_kernel, dim3((ps + 31) / 32 + 1), dim3(1024), 0, st, a, nblk);

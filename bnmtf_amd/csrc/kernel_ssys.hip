@@ -36,9 +36,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // their 64, the texture path takes ~9 cycles per wave-level load): per step one shift-add (row offset), one row load.
 // Everything else sits in buffer descriptors, scalar offsets and immediates.  Rows are loaded a batch (8 steps) ahead,
 // indices two.
+__device__ __forceinline__ void gamma_pack_body(const GammaPackArgs& a, int block);
+// (blocks behind the column Grams' pack the second moments of G's rows -- gamma_pack_body, below: the two do not depend on each
+// other, and one launch less is ~5 us of the S step)
 template <int VB>
-__global__ __launch_bounds__(256) void scol_gram_kernel(SColGramArgs a) {
+__global__ __launch_bounds__(256) void scol_gram_kernel(SColGramArgs a, GammaPackArgs gp) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const int gram_blocks = (a.n + 3) / 4;
+  if ((int)blockIdx.x >= gram_blocks) { gamma_pack_body(gp, (int)blockIdx.x - gram_blocks); return; }
   const int lane = threadIdx.x & 63, half = lane >> 5, c = lane & 31;
   const int u = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (u >= a.n) return;
@@ -99,17 +104,19 @@ __global__ __launch_bounds__(256) void scol_gram_kernel(SColGramArgs a) {
     if (row <= c && c < a.K) w[tri_pos(tri_index(row, c, a.K))] = cf - m;    // the upper triangle, packed: what the S-system GEMM reads
   }
 }
-void launch_scol_gram(const SColGramArgs& a, hipStream_t st) {
+// gp: the packing of G's second moments rides along (gp.n == 0: none)
+void launch_scol_gram(const SColGramArgs& a, const GammaPackArgs& gp, hipStream_t st) {
   if (a.n <= 0) return;
-  if (a.varF) hipLaunchKernelGGL(scol_gram_kernel<1>, dim3((a.n + 3) / 4), dim3(256), 0, st, a);
-  else        hipLaunchKernelGGL(scol_gram_kernel<0>, dim3((a.n + 3) / 4), dim3(256), 0, st, a);
+  const int blocks = (a.n + 3) / 4 + (gp.n + 7) / 8;
+  if (a.varF) hipLaunchKernelGGL(scol_gram_kernel<1>, dim3(blocks), dim3(256), 0, st, a, gp);
+  else        hipLaunchKernelGGL(scol_gram_kernel<0>, dim3(blocks), dim3(256), 0, st, a, gp);
 }
 
 // Gc[j][r(l, l')] = G_jl G_jl' (l <= l'), the packed second-moment matrix of column j's row of G.  Block = 8 columns (512 blocks at 4096 columns: two per CU hide each other's load -> store latency).
-__global__ __launch_bounds__(256) void gamma_pack_kernel(GammaPackArgs a) {
+__device__ __forceinline__ void gamma_pack_body(const GammaPackArgs& a, int block) {
   constexpr int NC = 8;
   __shared__ float g[NC][32], v[NC][32];
-  const int j0 = blockIdx.x * NC, PL = tri_count(a.L), PLp = tri_padded(a.L);
+  const int j0 = block * NC, PL = tri_count(a.L), PLp = tri_padded(a.L);
   for (int e = threadIdx.x; e < NC * 32; e += 256) {
     const int j = j0 + (e >> 5);
     g[e >> 5][e & 31] = j < a.n ? a.G[(size_t)(a.n0 + j) * 32 + (e & 31)] : 0.f;
@@ -125,6 +132,7 @@ __global__ __launch_bounds__(256) void gamma_pack_kernel(GammaPackArgs a) {
       if (j0 + t < a.n) a.Gc[(size_t)(j0 + t) * PLp + pos] = fmaf(g[t][l], g[t][lp], l == lp ? v[t][l] : 0.f);
   }
 }
+__global__ __launch_bounds__(256) void gamma_pack_kernel(GammaPackArgs a) { gamma_pack_body(a, (int)blockIdx.x); }
 void launch_gamma_pack(const GammaPackArgs& a, hipStream_t st) {
   if (a.n > 0) hipLaunchKernelGGL(gamma_pack_kernel, dim3((a.n + 7) / 8), dim3(256), 0, st, a);
 }
@@ -282,7 +290,9 @@ void launch_ssys_sum_parts(const float* slabs, int nsplit, size_t n, float* A, h
 // r = b - A S (fp64 dots), one wave per row.  Lanes 0-3 of the wave also make the first four sampler candidates of the
 // row's entry for the coming chain (random words only: they depend on (entry, iteration, key), not on A) -- a Philox call
 // each, hidden behind the dot product instead of standing at the head of the one-block chain kernel.
-__global__ __launch_bounds__(256) void ssys_residual_kernel(const float* A, const float* b, const float* S, int n2, float* r,
+// (bparts != nullptr: b is still in its nparts per-block parts -- summed here, in part order, as ssys_sum_parts_kernel would, and
+// written to b as well)
+__global__ __launch_bounds__(256) void ssys_residual_kernel(const float* A, float* b, const float* bparts, int nparts, const float* S, int n2, float* r,
                                                             float4* cands, uint32_t it, uint32_t key0, uint32_t key1) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n2) return;
@@ -295,10 +305,24 @@ __global__ __launch_bounds__(256) void ssys_residual_kernel(const float* A, cons
   for (int t = lane; t < n2; t += 64) s = fma((double)A[(size_t)row * n2 + t], (double)S[t], s);
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-  if (lane == 0) r[row] = (float)((double)b[row] - s);
+  if (lane == 0) {
+    float bv;
+    if (bparts) {
+      bv = 0.f;
+      for (int t0 = 0; t0 < nparts; t0 += 8) {                       // eight loads in flight, added in part order
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = t0 + j < nparts ? bparts[(size_t)(t0 + j) * n2 + row] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bv += v[j];
+      }
+      b[row] = bv;
+    } else bv = b[row];
+    r[row] = (float)((double)bv - s);
+  }
 }
-void launch_ssys_residual(const float* A, const float* b, const float* S, int n2, float* r, hipStream_t st, float* cands, uint32_t it, uint32_t key0, uint32_t key1) {
-  hipLaunchKernelGGL(ssys_residual_kernel, dim3((n2 + 3) / 4), dim3(256), 0, st, A, b, S, n2, r, reinterpret_cast<float4*>(cands), it, key0, key1);
+void launch_ssys_residual(const float* A, float* b, const float* bparts, int nparts, const float* S, int n2, float* r, hipStream_t st, float* cands, uint32_t it, uint32_t key0, uint32_t key1) {
+  hipLaunchKernelGGL(ssys_residual_kernel, dim3((n2 + 3) / 4), dim3(256), 0, st, A, b, bparts, nparts, S, n2, r, reinterpret_cast<float4*>(cands), it, key0, key1);
 }
 
 // The K.L sequential conditionals, row-major (k, l) (bnmtf_gibbs_optimised.py:157-160), one block of 8 waves.

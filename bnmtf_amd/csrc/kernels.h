@@ -214,6 +214,10 @@ struct SmallProductArgs {   // out = X . S (transposeS = 0, out width L) or X . 
   const float* X; int rows, KPin; const float* S; int K, L; int transposeS; float* out; int KPout;
 };
 void launch_small_product(const SmallProductArgs& a, hipStream_t st);
+struct SlabProductArgs {    // out[n][KPout] = (sum of the `split` slabs [n_pad][KPin]) . S: contraction slabs times S (kernel_bnmtf.hip)
+  const float* slabs; int split, n_pad, KPin; const float* S; int K, L; int n; float* out; int KPout;
+};
+void launch_slab_product(const SlabProductArgs& a, hipStream_t st);
 void launch_cfs(const double* Cf64, int KPk, const float* S, int K, int L, float* CfS, hipStream_t st);
 struct SRowArgs {           // one row k of S: J-vectors h_k, w_k and per-block partial eta / Omega
   int n, n0, k, K, L, KPk, KPl;
@@ -274,7 +278,8 @@ struct SColGramArgs {       // W~_j = C~f - sum_{i in miss(j)} (F_i F_i^T + diag
   const uint32_t* slot_ptr; const uint32_t* idx;   // 64-wide slots of the cols direction
   float* Wc;                           // [n + 2][tri_padded(K)]: the packed upper triangle of W~_j (pads and the two extra rows stay zero)
 };
-void launch_scol_gram(const SColGramArgs& a, hipStream_t st);
+struct GammaPackArgs;
+void launch_scol_gram(const SColGramArgs& a, const GammaPackArgs& pack_too, hipStream_t st);   // pack_too.n > 0: the packing of G's second moments in the same launch
 struct GammaPackArgs {      // Gc[j][r(l, l')] = G_jl G_jl' (+ varG_jl when l = l': the second moment, VB) for the local columns
   int n, n0, L;
   const float* G; const float* varG;   // [J][32] (global rows n0 + j); varG null for Gibbs
@@ -293,8 +298,9 @@ inline int ssys_b_blocks(int n) { return (n + 63) / 64 > 0 ? (n + 63) / 64 : 1; 
 void launch_ssys_b(const SSysBArgs& a, hipStream_t st);
 void launch_ssys_reduce(const float* slabs, int nsplit, int K, int L, float* A, hipStream_t st);   // sum the slabs on k <= k', mirror
 void launch_ssys_sum_parts(const float* parts, int nparts, size_t n, float* out, hipStream_t st);
-void launch_ssys_residual(const float* A, const float* b, const float* S, int n2, float* r, hipStream_t st,
-                          float* cands = nullptr, uint32_t it = 0, uint32_t key0 = 0, uint32_t key1 = 0);   // cands [n2][4][4]: the chain's first candidates (draws)
+// r = b - A S.  bparts != nullptr: b is summed from its nparts per-block parts first (and stored).  cands [n2][4][4]: the chain's first candidates (draws)
+void launch_ssys_residual(const float* A, float* b, const float* bparts, int nparts, const float* S, int n2, float* r, hipStream_t st,
+                          float* cands = nullptr, uint32_t it = 0, uint32_t key0 = 0, uint32_t key1 = 0);
 struct SSysChainArgs {
   int K, L, update, cond;              // update: 0 draw, else mode (clamped from below by min_x); cond >= 0: evaluate entry cond only
   float min_x;

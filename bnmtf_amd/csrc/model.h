@@ -103,6 +103,7 @@ struct bnmtf_model {
   uint64_t seed = 0, iteration = 0;
   int device = 0, rank = 0, world = 1;
   hipStream_t stream = nullptr;
+  hipStream_t aux_stream = nullptr; hipEvent_t ev_aux0 = nullptr, ev_aux1 = nullptr;   // BNMTF S step: the b side of the system beside the A side (api_models.inc)
   hipStream_t xchg_stream = nullptr;    // several GPUs: every collective is issued here, beside the compute stream
   bnmtf::Dir rows, cols;
   // full-matrix copies for predict()/validation
