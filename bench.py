@@ -39,6 +39,7 @@ WORKLOADS = {
     "bnmf_8192_k64": dict(kind="bnmf", I=8192, J=8192, K=64),          # BASELINE.json metric config (headline)
     "bnmf_4096_k32": dict(kind="bnmf", I=4096, J=4096, K=32),          # configs[1]
     "bnmf_1024_k16": dict(kind="bnmf", I=1024, J=1024, K=16),
+    "bnmf_8192_k32": dict(kind="bnmf", I=8192, J=8192, K=32),          # the 16-wave sweep with one register of columns per lane
     "bnmtf_4096_k32": dict(kind="bnmtf", I=4096, J=4096, K=32, L=32),  # configs[3]
     "vb_8192_k64": dict(kind="vb", I=8192, J=8192, K=64),              # configs[4]
     "vb_4096_k32": dict(kind="vb", I=4096, J=4096, K=32),
