@@ -263,7 +263,10 @@ def main():
         trajectory += [float(x) for x in perf_w[:a.warmup, 0]]
     # timed regions: HIP events bracket the roofline kernel only, on its own stream, in every fourth iteration (an event
     # record drains the queue for ~4 us: two per iteration were 2 % of the headline iteration)
-    model.set_profiling(True, kernel=_lib.KERNEL_GEMM_COLS, every=4)
+    # (BNMTF: the cols direction's contraction is no pass over R~ any more -- (R~^T F) S from the S step's slabs -- so the
+    # roofline kernel there is the rows direction's, R~ . (G S^T))
+    ROOF = _lib.KERNEL_GEMM_ROWS if kind == "bnmtf" else _lib.KERNEL_GEMM_COLS
+    model.set_profiling(True, kernel=ROOF, every=4)
     perf_first = None
     dts = []
     for rep in range(max(1, a.repeats)):
@@ -280,19 +283,19 @@ def main():
     if with_samples:
         assert np.isfinite(bufs[0][-1]).all() and float(np.abs(bufs[0][-1]).max()) > 0.0
 
-    names = {_lib.KERNEL_GEMM_ROWS: "gemm_rows(R~.V)", _lib.KERNEL_GEMM_COLS: "gemm_cols(R~^T.U)",
+    names = {_lib.KERNEL_GEMM_ROWS: "gemm_rows(R~.V)", _lib.KERNEL_GEMM_COLS: "gemm_cols((R~^T.F).S from the S step's slabs)" if kind == "bnmtf" else "gemm_cols(R~^T.U)",
              _lib.KERNEL_SWEEP_ROWS: "sweep_rows", _lib.KERNEL_SWEEP_COLS: "sweep_cols"}
     if kind == "bnmtf":
         names[_lib.KERNEL_SWEEP_S] = "sweep_S"
     stats = {}
-    ms, n = model.kernel_stats(_lib.KERNEL_GEMM_COLS)
-    stats[names[_lib.KERNEL_GEMM_COLS]] = {"avg_us": 1e3 * ms / max(n, 1), "launches": n}
+    ms, n = model.kernel_stats(ROOF)
+    stats[names[ROOF]] = {"avg_us": 1e3 * ms / max(n, 1), "launches": n}
     # the other kernels of the iteration: a short untimed run with every timer on
     model.set_profiling(True)
     run(min(a.steps, 10))
     sync()
     for kid, nm in names.items():
-        if kid == _lib.KERNEL_GEMM_COLS:
+        if kid == ROOF:
             continue
         ms, n = model.kernel_stats(kid)
         stats[nm] = {"avg_us": 1e3 * ms / max(n, 1), "launches": n}
@@ -312,7 +315,7 @@ def main():
         # dominant HBM kernel, "the U^T.R step" (SURVEY.md 8(d)): algorithmic 4*I*J bytes (R~ read once) and 2*I*J*K flop
         # per launch (per rank: its column shard); fp32-exact products on the bf16 matrix cores (3-term splits), so a
         # stream of R~ from HBM
-        g = stats[names[_lib.KERNEL_GEMM_COLS]]
+        g = stats[names[ROOF]]
         flops = 2.0 * I * (J / world) * K
         bytes_alg = 4.0 * I * (J / world)
         f32_gemm = os.environ.get("BNMTF_GEMM") == "f32"
@@ -335,7 +338,7 @@ def main():
                     "unit": "TFLOP/s", "frac": ach / PEAK_F32_VECTOR_TFLOPS, "traffic": None}
         else:
             ach = bytes_alg / (g["avg_us"] * 1e-6) / 1e9 if g["avg_us"] > 0 else 0.0
-            roof = {"bound": "hbm", "kernel": "gemm_cols: Pv = R~^T.U (bf16x3 MFMA 32x32x16, fp32-exact products)", "achieved": ach,
+            roof = {"bound": "hbm", "kernel": ("gemm_rows: P = R~.(G S^T)" if kind == "bnmtf" else "gemm_cols: Pv = R~^T.U") + " (bf16x3 MFMA 32x32x16, fp32-exact products)", "achieved": ach,
                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": traffic}
         roof.update({"algorithmic_per_launch": {"flop": flops, "bytes": bytes_alg}, "avg_launch_us": g["avg_us"], "traffic_source": traffic_note})
         # the sweep kernels (K sequential conditional updates per unit) are bound by vector issue + LDS gathers, not by HBM

@@ -21,14 +21,21 @@ def _data(I, J, K, frac_missing, seed):
     return R, M, rs
 
 
+@pytest.mark.parametrize("handover", ["0", "1"], ids=["prepass", "handover"])
 @pytest.mark.parametrize("I,J,K,miss", [(70, 90, 6, 0.0), (45, 33, 1, 0.2), (1, 40, 3, 0.1), (50, 1, 2, 0.0), (160, 1500, 5, 0.9)])
-def test_bnmf_gibbs_edge_shapes(I, J, K, miss):
+def test_bnmf_gibbs_edge_shapes(monkeypatch, I, J, K, miss, handover):
+    """handover = "1": q handed over between the half sweeps wherever its tables can be built -- with nothing missing
+    the regions are empty, with 90 % missing the units need more slot rows than the on-chip kernels take and the hand-over has to
+    stay off by itself."""
+    monkeypatch.setenv("BNMTF_HANDOVER", handover)
     R, M, rs = _data(I, J, K, miss, 3)
     U0, V0 = rs.exponential(1.0, (I, K)), rs.exponential(1.0, (J, K))
     o = O.BNMFGibbsOracle(R, M, K, PRI2)
     o.U, o.V, o.tau = U0.copy(), V0.copy(), 0.8
     o.run(4, draw=False)
     b = bnmf_gibbs_optimised(R, M, K, PRI2, verbose=False, seed=1)
+    if handover == "0" or miss >= 0.9:
+        assert "handover=0" in b.describe()
     b.U, b.V, b.tau = U0.copy(), V0.copy(), 0.8
     b.run(4, update='mode')
     # the masked SSE comes from Gram identities in fp32 products: its error scales with the terms that cancel (sum R^2), not
