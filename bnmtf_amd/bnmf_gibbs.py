@@ -61,12 +61,19 @@ class bnmf_gibbs_optimised(DeviceModel):
 
     def _push(self, tau=None):
         tau = getattr(self, "tau", 1.0) if tau is None else tau
+        # the state the device holds already (nothing touched U, V, tau since the last run() pulled them): no upload -- and the
+        # device keeps what it carries between its half sweeps, so run(a); run(b) is the chain of run(a + b)
+        held = getattr(self, "_device_state", None)
+        if held is not None and held[0] is self._h and float(tau) == held[3] and np.array_equal(self.U, held[1]) and np.array_equal(self.V, held[2]):
+            return
+        self._device_state = None
         _lib.check(_lib.lib().bnmf_set_state(self._handle(), _lib.ptr(_lib.f64(self.U)), _lib.ptr(_lib.f64(self.V)), float(tau)))
 
     def _pull(self):
         U = np.zeros((self.I, self.K)); V = np.zeros((self.J, self.K)); tau = C.c_double()
         _lib.check(_lib.lib().bnmf_get_state(self._handle(), _lib.ptr(U), _lib.ptr(V), C.byref(tau)))
         self.U, self.V, self.tau = U, V, tau.value
+        self._device_state = (self._h, U.copy(), V.copy(), tau.value)
 
     def run(self, iterations, update='draw', store_samples=True, expectation=None):
         """:121-157.  One device call runs all iterations; samples, tau, metrics and

@@ -435,11 +435,17 @@ static void drain_events(bnmtf_model* h) {
 // q hand-over between the half sweeps, for the duration of one run call: from its first rows sweep (a pre-pass) on
 struct HandoverScope {
   bnmtf_model* h;
+  // (a call that follows another one of the same handle with the state untouched in between picks the regions up where that
+  // call left them: run(50) + run(50) is the chain of run(100), bit for bit)
   explicit HandoverScope(bnmtf_model* h_) : h(h_) {
-    h->rows.ho_filled = h->cols.ho_filled = false;
     h->ho_active = h->ho_enabled && !h->comm && h->use_fast;
+    if (!h->ho_active || !h->ho_regions_current) h->rows.ho_filled = h->cols.ho_filled = false;
+    h->ho_regions_current = false;            // (an error return out of the loop leaves them unknown)
   }
-  ~HandoverScope() { h->ho_active = false; }
+  ~HandoverScope() {
+    h->ho_regions_current = h->ho_active && h->rows.ho_filled;
+    h->ho_active = false;
+  }
 };
 // ------------------------------------------------------------- step pieces
 static void enqueue_gemm(bnmtf_model* h, Dir& d, const Dir& other, int kid) {
@@ -1001,7 +1007,7 @@ int bnmtf_set_profiling(bnmtf_handle h, int enable) {
   for (int i = 0; i < BNMTF_KERNEL_COUNT; ++i) { h->kernel_ms[i] = 0; h->kernel_launches[i] = 0; }
   return BNMTF_OK;
 }
-int bnmtf_set_sweep_path(bnmtf_handle h, int fast) { h->use_fast = fast != 0; return BNMTF_OK; }
+int bnmtf_set_sweep_path(bnmtf_handle h, int fast) { h->use_fast = fast != 0; h->ho_regions_current = false; return BNMTF_OK; }
 int bnmtf_kernel_stats(bnmtf_handle h, int kernel, double* total_ms, uint64_t* launches) {
   if (kernel < 0 || kernel >= BNMTF_KERNEL_COUNT) { set_error("bad kernel id"); return BNMTF_EINVAL; }
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -1022,6 +1028,7 @@ int bnmf_set_state(bnmtf_handle h, const double* U, const double* V, double tau)
   CHK(upload_factor(h, h->cols, V));
   CHK(set_tau(h, tau));
   h->have_state = true;
+  h->ho_regions_current = false;          // (q hand-over: whatever the regions hold belongs to the state that was just replaced)
   return BNMTF_OK;
 }
 

@@ -145,6 +145,7 @@ struct bnmtf_model {
   double min_tn = 0.0;                   // ICM: lower clamp of every mode update (run(iterations, minimum_TN))
   float cur_min_x = 0.f;                 // clamp in force for the sweeps being enqueued
   uint32_t profiling = 0;                // bit k: bracket the launches of kernel k with events
+  bool ho_regions_current = false;              // the regions hold q of the state as the last run call left it (no set_state since)
   bool ho_enabled = false, ho_active = false;   // q hand-over between the half sweeps (Dir::ho_*): tables built / in use by the running loop
   uint64_t ho_refresh = 64;                     // the rows sweep runs its pre-pass every ho_refresh-th iteration
   uint64_t profile_stride = 1;           // ... in every profile_stride-th iteration

@@ -112,6 +112,33 @@ def test_q_handed_over_between_the_half_sweeps_equals_the_pre_pass(monkeypatch, 
     np.testing.assert_allclose(h[6], o.all_performances["MSE"], rtol=5e-4)
 
 
+@pytest.mark.parametrize("handover", ["1", "0"])
+def test_a_run_split_in_two_calls_is_the_same_chain(monkeypatch, handover):
+    """run(3); run(4) continues bit for bit as run(7) does: the second call finds the device state it left (no upload) and, with
+    the hand-over, q of the missing entries where the first call's last half sweep put it.  Touching the state in between
+    (here: writing U back) makes the next call start from the uploaded state with a pre-pass -- the same chain up to rounding."""
+    monkeypatch.setenv("BNMTF_WIDE", "1")
+    monkeypatch.setenv("BNMTF_HANDOVER", handover)
+    I, J, K = 700, 520, 40
+    rs = np.random.RandomState(11)
+    R = rs.exponential(1.0, (I, K)) @ rs.exponential(1.0, (J, K)).T + rs.randn(I, J)
+    M = _ragged_mask(rs, I, J, 0.05, 0.3)
+    def model():
+        b = bnmf_gibbs_optimised(R, M, K, PRI, verbose=False, seed=9)
+        np.random.seed(4); b.initialise("random")
+        return b
+    one = model(); one.run(7)
+    two = model(); two.run(3); first = two.all_U.copy(); two.run(4)
+    assert np.array_equal(first, one.all_U[:3])
+    assert np.array_equal(two.all_U, one.all_U[3:]) and np.array_equal(two.all_V, one.all_V[3:]) and np.array_equal(two.all_tau, one.all_tau[3:])
+    three = model(); three.run(3); three.U = three.U.copy() * 1.0; three.U[0, 0] = np.float32(three.U[0, 0])     # same values, re-uploaded
+    three.run(4)
+    d = np.abs(three.all_U[0] - one.all_U[3]) / (np.abs(one.all_U[3]) + 1e-3)
+    assert np.mean(d < 1e-3) > 0.99
+    if handover == "0":
+        assert np.array_equal(three.all_U, one.all_U[3:])       # without the hand-over nothing but (U, V, tau) is carried: identical
+
+
 def test_headline_shape_properties():
     """8192 x 8192, K = 64, 10 % missing (the bench configuration): the observed counts are exact, the metrics from the
     Gram identities equal the direct fp64 metric kernel on the same sample, the chain reaches the noise floor, and the
