@@ -38,8 +38,15 @@ class bnmf_vb_optimised(DeviceModel):
     _NAMES = ("muU", "tauU", "expU", "varU", "muV", "tauV", "expV", "varV")
 
     def _push(self):
+        exptau = float(getattr(self, "exptau", 1.0))
+        # the state the device holds already (nothing touched the q parameters since the last run() pulled them): no upload,
+        # and the device keeps what it carries between its half sweeps -- run(a); run(b) is the trajectory of run(a + b)
+        held = getattr(self, "_device_state", None)
+        if held is not None and held[0] is self._h and held[1] == exptau and all(np.array_equal(getattr(self, n), a) for n, a in zip(self._NAMES, held[2])):
+            return
+        self._device_state = None
         arrs = [_lib.f64(getattr(self, n)) for n in self._NAMES]
-        _lib.check(_lib.lib().bnmf_vb_set_state(self._handle(), *[_lib.ptr(a) for a in arrs], float(getattr(self, "exptau", 1.0))))
+        _lib.check(_lib.lib().bnmf_vb_set_state(self._handle(), *[_lib.ptr(a) for a in arrs], exptau))
 
     def _pull(self):
         shapes = [(self.I, self.K)] * 4 + [(self.J, self.K)] * 4
@@ -47,6 +54,7 @@ class bnmf_vb_optimised(DeviceModel):
         _lib.check(_lib.lib().bnmf_vb_get_state(self._handle(), *[_lib.ptr(a) for a in arrs]))
         for n, a in zip(self._NAMES, arrs):
             setattr(self, n, a)
+        self._device_state = (self._h, None, [a.copy() for a in arrs])       # (exptau: filled in by run() once it has been formed from the device's beta_s)
 
     def initialise(self, init='exp', tauUV={}):
         """bnmf_vb_optimised.py:93-117."""
@@ -81,6 +89,8 @@ class bnmf_vb_optimised(DeviceModel):
             self.alpha_s = self.alpha + self.size_Omega / 2.0
             self.beta_s = terms[-1, 1]
             self.update_exp_tau()
+            if getattr(self, "_device_state", None) is not None:      # alpha_s / beta_s from the device's own beta_s: the exptau it holds
+                self._device_state = (self._device_state[0], float(self.exptau), self._device_state[2])
         if self.verbose:
             for i in range(it):
                 print("Iteration %s. ELBO: %s. MSE: %s. R^2: %s. Rp: %s." % (i + 1, self.all_elbo[i], perf[i, 0], perf[i, 1], perf[i, 2]))

@@ -68,6 +68,26 @@ def test_ragged_case_matches_reference(golden, monkeypatch, wide):
     assert np.abs(b.expU - g["it10/expU"]).max() < 2e-3 * np.abs(g["it10/expU"]).max()
 
 
+@pytest.mark.parametrize("handover", ["1", "0"])
+def test_a_run_split_in_two_calls_is_the_same_trajectory(monkeypatch, handover):
+    """run(3); run(4) is run(7), bit for bit: the second call finds the device state it left (no upload) and, with the hand-over,
+    q of the missing entries where the first call's last half sweep put it."""
+    from bnmtf_amd.synthetic import generate_bnmf
+    monkeypatch.setenv("BNMTF_WIDE", "1")
+    monkeypatch.setenv("BNMTF_HANDOVER", handover)
+    I, J, K = 600, 500, 20
+    R, M, _, _ = generate_bnmf(I, J, K, 0.15, seed_data=3, seed_mask=4)
+    pri = dict(alpha=1., beta=1., lambdaU=0.1, lambdaV=0.1)
+    def model():
+        b = bnmf_vb_optimised(R, M, K, pri, verbose=False)
+        b.initialise('exp')
+        return b
+    one = model(); one.run(7)
+    two = model(); two.run(3); two.run(4)
+    assert two.all_exp_tau == one.all_exp_tau[3:] and two.all_elbo == one.all_elbo[3:]
+    assert np.array_equal(two.expU, one.expU) and np.array_equal(two.tauV, one.tauV)
+
+
 def test_known_answers_of_reference_tests():
     """tests/code/test_bnmf_vb_optimised.py:218-311."""
     I, J, K = 5, 3, 2
