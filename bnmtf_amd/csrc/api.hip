@@ -286,6 +286,10 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
       d.f_nw = d.f_npairs >= 8 * 256 ? 8 : (d.f_npairs >= 4 * 256 ? 4 : (d.f_npairs >= 2 * 64 ? 2 : 8));
       if (const char* e = getenv("BNMTF_FAST_NW")) d.f_nw = atoi(e) == 2 ? 2 : (atoi(e) == 4 ? 4 : 8);
       if (d.use_wide) d.f_nw = 16;
+      // the twin shape (BNMTF_TWIN=1): the 16-wave layout run by 8-wave blocks, two to a CU (sweep_chip.inc, TW = 1)
+      d.use_twin = false;
+      if (const char* e = getenv("BNMTF_TWIN")) d.use_twin = d.use_wide && !d.use_turns && world == 1 && d.pw <= kTwinPanelStride && atoi(e) != 0;
+      if (d.use_twin) d.f_nw = 8;
       if (nch == 2) d.f_nw = 8;                       // the two-chunk variant is an 8-wave kernel
       for (int pi = 0; pi < d.f_npairs && !d.use_wide; ++pi)
         if ((int)pE[pi] > kFastMaxSlots)
@@ -523,7 +527,7 @@ static void enqueue_sweep(bnmtf_model* h, Dir& d, const Dir& other, SweepArgs& s
     FastArgs f;
     f.unit_map = d.f_unit_map; f.pair_E = d.f_pair_E; f.pair_base = d.f_pair_base; f.off = d.f_off;
     f.npairs = d.f_npairs; f.mz = d.mz; f.pw = d.nch == 2 ? d.pw_chunk : d.pw; f.nw = d.f_nw;
-    f.nch = d.nch; f.mh = d.mh; f.pw1 = d.pw1;
+    f.nch = d.nch; f.mh = d.mh; f.pw1 = d.pw1; f.twin = d.use_twin ? 1 : 0;
     f.XoT = other.XT; f.ldT_o = other.ldT; f.XoT2 = other.XT2; f.ld2_o = other.ldT;
     f.stats = want_stats ? d.stats : nullptr;
     SweepArgs s2 = s;
@@ -531,7 +535,7 @@ static void enqueue_sweep(bnmtf_model* h, Dir& d, const Dir& other, SweepArgs& s
     f.off16 = d.pair_ok ? d.f_off16 : nullptr;
     set_handover(h, d, other, f, !d.use_turns && d.nch == 1 && d.f_nw == d.ho_ppb && s.mode != kSweepVB);
     if (d.use_wide && d.use_turns) launch_sweep_turns(s2, f, h->stream);
-    else if (d.use_wide) launch_sweep_wide(s2, f, h->stream);
+    else if (d.use_wide && !d.use_twin) launch_sweep_wide(s2, f, h->stream);
     else launch_sweep_fast(s2, f, h->stream);
     h->last_sweep_fast = true;
     if (d.f_gen_count == 0) return;
@@ -898,10 +902,10 @@ int bnmtf_create(const bnmtf_problem* p, bnmtf_handle* out) {
   h->create_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create0).count();
   char buf[768];
   snprintf(buf, sizeof(buf),
-           "I=%d J=%d K=%d L=%d rank=%d/%d rows[n=%d n_pad=%d split=%d ipw=%d inner_pad=%d nmiss=%zu nslots=%zu sweep_nw=%d turns=%d handover=%d emax=%d generic_units=%d] "
+           "I=%d J=%d K=%d L=%d rank=%d/%d rows[n=%d n_pad=%d split=%d ipw=%d inner_pad=%d nmiss=%zu nslots=%zu sweep_nw=%d turns=%d twin=%d handover=%d emax=%d generic_units=%d] "
            "cols[n=%d n_pad=%d split=%d ipw=%d inner_pad=%d nmiss=%zu nslots=%zu sweep_nw=%d turns=%d emax=%d generic_units=%d] n_obs=%.0f create_ms=%.0f",
            I, J, p->K, p->L, p->rank, p->world, h->rows.n, h->rows.n_pad, h->rows.split, h->rows.ipw, h->rows.inner_pad,
-           h->rows.nmiss, h->rows.nslots, h->rows.f_nw, (int)h->rows.use_turns, (int)h->ho_enabled, h->rows.f_emax, h->rows.f_gen_count, h->cols.n, h->cols.n_pad, h->cols.split,
+           h->rows.nmiss, h->rows.nslots, h->rows.f_nw, (int)h->rows.use_turns, (int)h->rows.use_twin, (int)h->ho_enabled, h->rows.f_emax, h->rows.f_gen_count, h->cols.n, h->cols.n_pad, h->cols.split,
            h->cols.ipw, h->cols.inner_pad, h->cols.nmiss, h->cols.nslots, h->cols.f_nw, (int)h->cols.use_turns, h->cols.f_emax, h->cols.f_gen_count, n_obs, h->create_ms);
   h->description = buf;
   *out = h;

@@ -94,6 +94,7 @@ struct FastArgs {
   int nch, mh, pw1;            // chunks (1 or 2), first inner index of chunk 1 (multiple of 256), panel floats of chunk 1
   // q hand-over between the half sweeps (16-wave kernel, one GPU; model.h Dir::ho_*): read q from the block's region instead of
   // the pre-pass / write q sorted by the other direction's blocks at the end
+  int twin;                    // the twin shape: 8-wave blocks, two to a CU, on the 16-wave layout (sweep_chip.inc)
   int ho_lds_floats;           // floats behind the Gram in LDS that the hand-over's region / staging area needs (0: none)
   int ho_read, ho_write, ho_nb_other, ho_rows_total;       // ho_rows_total: slot rows of the whole direction (= the end of the last block's slice)
   const uint32_t* ho_in; const float* ho_region; const uint32_t* ho_region_ofs;
@@ -115,6 +116,7 @@ void launch_sweep_fast(const SweepArgs& a, const FastArgs& f, hipStream_t st);
 void launch_sweep_small(const SweepArgs& a, const FastArgs& f, hipStream_t st);   // nw = 2, 4 (kernel_sweep_small.hip)
 // 16-wave instantiation (kernel_sweep_wide.hip): at most kWideMaxSlots slots per lane, 16 pairs per block
 constexpr int kWideMaxSlots = 32;
+constexpr int kTwinPanelStride = 8448;       // the twin shape (sweep_chip.inc, TW = 1): floats between its two panel buffers = the largest panel it takes
 bool sweep_wide_supported(int KP, int pw);
 void launch_sweep_wide(const SweepArgs& a, const FastArgs& f, hipStream_t st);
 // the same pair layout run by 8-wave blocks of four units per wave, two groups of units taking turns so that a group's draw

@@ -77,6 +77,7 @@ struct Dir {
   mutable bool ho_filled = false;       // the regions hold q of the current (X, Xo)
   uint16_t* f_row_blk = nullptr;        // block (of ho_ppb pairs: the sweep kernel's unit waves, 16 or 8) of every slot row: build_handover's input
   int ho_ppb = 0;
+  bool use_twin = false;                // the 16-wave layout run by 8-wave blocks, two to a CU (BNMTF_TWIN=1)
   bool gram_packed = false;             // colsum / colsum2 live behind C64 in one allocation (what exchange_factor all-reduces)
   hipEvent_t ev_sweep = nullptr, ev_gram = nullptr, ev_gathered = nullptr, ev_gram_all = nullptr;   // exchange_factor (several GPUs)
   float* snap_dst = nullptr;            // set for ONE relayout: where its rows also go, packed [rows][W] (run()'s sample hand-off)

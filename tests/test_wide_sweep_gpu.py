@@ -70,13 +70,15 @@ def test_wide_kernel_equals_generic_kernel_and_oracle(monkeypatch, I, J, K, lo, 
 
 
 @pytest.mark.parametrize("I,J,K,lo,hi,wide", [(640, 800, 64, 0.0, 0.9, "1"), (513, 389, 32, 0.05, 0.5, "1"), (1500, 2048, 40, 0.08, 0.12, "1"),
-                                              (201, 180, 24, 0.05, 0.4, "0"), (150, 77, 64, 0.0, 0.6, "0")])
+                                              (201, 180, 24, 0.05, 0.4, "0"), (150, 77, 64, 0.0, 0.6, "0"), (640, 800, 64, 0.0, 0.9, "twin"), (513, 389, 32, 0.05, 0.5, "twin")])
 def test_q_handed_over_between_the_half_sweeps_equals_the_pre_pass(monkeypatch, I, J, K, lo, hi, wide):
     """One GPU, 16-wave blocks (wide = "1") or plain 8-wave blocks ("0": here problems of < 128 pairs) on both directions: q of
     the missing entries goes from the end of one half sweep to the start of the next through block-sorted packets
     instead of being rebuilt by the pre-pass.  Same chain as with the pre-pass (BNMTF_HANDOVER=0) up to fp32 rounding; never
     refreshed, twelve mode updates still follow the fp64 oracle."""
-    monkeypatch.setenv("BNMTF_WIDE", wide)
+    monkeypatch.setenv("BNMTF_WIDE", "1" if wide == "twin" else wide)
+    if wide == "twin":                   # the 16-wave layout run by 8-wave blocks, two to a CU (BNMTF_TWIN=1: an experiment kept in the tree)
+        monkeypatch.setenv("BNMTF_TWIN", "1")
     rs = np.random.RandomState(I * 3 + J)
     U0 = rs.exponential(1.0, (I, K)); V0 = rs.exponential(1.0, (J, K))
     R = U0 @ V0.T + rs.randn(I, J)
@@ -86,7 +88,7 @@ def test_q_handed_over_between_the_half_sweeps_equals_the_pre_pass(monkeypatch, 
         monkeypatch.setenv("BNMTF_HANDOVER", ho)
         monkeypatch.setenv("BNMTF_HANDOVER_REFRESH", "1000000")
         b = bnmf_gibbs_optimised(R, M, K, PRI, verbose=False, seed=5)
-        assert ("handover=1" in b.describe()) == (ho == "1") and ("sweep_nw=16" if wide == "1" else "sweep_nw=8") in b.describe()
+        assert ("handover=1" in b.describe()) == (ho == "1") and ("sweep_nw=16" if wide == "1" else "sweep_nw=8") in b.describe() and ("twin=1" in b.describe()) == (wide == "twin")
         np.random.seed(2); b.initialise("random")
         b.run(3)
         draw = (b.all_U.copy(), b.all_V.copy(), np.array(b.all_performances["MSE"]))
