@@ -1,6 +1,7 @@
 """ctypes binding of libbnmtf_hip.so (include/bnmtf_hip.h).  No PyTorch, no fallback:
 if the HIP library is missing or a call fails, an exception is raised."""
 import ctypes as C
+import atexit
 import os
 
 import numpy as np
@@ -116,10 +117,38 @@ def device_count():
     return n.value
 
 
+# Page-locking is slow (35-40 ms per 200 MB here, and the first device write to a fresh page costs again): a block whose last
+# array has gone away is kept for the next sample_buffer() of the same size instead of being unpinned -- run(n) called again and
+# again (model-selection drivers, chains continued in pieces) then allocates nothing after its second call.  At most
+# BNMTF_PIN_POOL_MB (default 1 024 MB) wait in the pool; 0 switches it off.
+_PIN_POOL = {}          # nbytes -> [address, ...]
+_PIN_POOL_BYTES = [0]
+
+
+def _pin_pool_cap():
+    return int(os.environ.get("BNMTF_PIN_POOL_MB", "1024")) * (1 << 20)
+
+
+def _pin_pool_clear():
+    for addrs in _PIN_POOL.values():
+        for a in addrs:
+            try:
+                lib().bnmtf_host_free(C.c_void_p(a))
+            except Exception:
+                pass
+    _PIN_POOL.clear()
+    _PIN_POOL_BYTES[0] = 0
+
+
 class _PinnedBlock(object):
-    """Owner of one bnmtf_host_alloc block (freed when the last array viewing it goes away)."""
+    """Owner of one bnmtf_host_alloc block (back to the pool, or freed, when the last array viewing it goes away)."""
 
     def __init__(self, nbytes):
+        pooled = _PIN_POOL.get(nbytes)
+        if pooled:
+            self.ptr, self.nbytes = pooled.pop(), nbytes
+            _PIN_POOL_BYTES[0] -= nbytes
+            return
         p = C.c_void_p()
         check(lib().bnmtf_host_alloc(nbytes, C.byref(p)))
         self.ptr, self.nbytes = p.value, nbytes
@@ -127,7 +156,11 @@ class _PinnedBlock(object):
     def __del__(self):
         try:
             if self.ptr:
-                lib().bnmtf_host_free(C.c_void_p(self.ptr))
+                if _PIN_POOL_BYTES[0] + self.nbytes <= _pin_pool_cap():
+                    _PIN_POOL.setdefault(self.nbytes, []).append(self.ptr)
+                    _PIN_POOL_BYTES[0] += self.nbytes
+                else:
+                    lib().bnmtf_host_free(C.c_void_p(self.ptr))
                 self.ptr = None
         except Exception:
             pass
@@ -148,3 +181,6 @@ def sample_buffer(shape, dtype=np.float32):
     buf = (C.c_char * max(n, 1)).from_address(blk.ptr)
     buf._owner = blk                      # the ctypes buffer (kept alive by the array's .base chain) keeps the block
     return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
+atexit.register(_pin_pool_clear)

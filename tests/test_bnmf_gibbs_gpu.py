@@ -246,3 +246,22 @@ def test_rccl_exchange_path_with_one_rank(golden, monkeypatch):
     np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-10)
     np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(res[0][2], res[1][2], rtol=1e-8)
+
+
+def test_pinned_sample_arrays_are_reused(monkeypatch):
+    """run()'s page-locked sample arrays go back to a pool when their last view goes away and are handed out again for the same
+    size (page-locking is tens of milliseconds per call otherwise); BNMTF_PIN_POOL_MB bounds what waits there."""
+    from bnmtf_amd import _lib
+    _lib._pin_pool_clear()
+    a = _lib.sample_buffer((7, 33, 5))
+    addr = a.ctypes.data
+    a[:] = 3.0
+    del a
+    assert _lib._PIN_POOL_BYTES[0] == 7 * 33 * 5 * 4
+    b = _lib.sample_buffer((7, 33, 5))
+    assert b.ctypes.data == addr and _lib._PIN_POOL_BYTES[0] == 0
+    c = _lib.sample_buffer((7, 33, 5))                    # a second one of the same size while the first is alive: a new block
+    assert c.ctypes.data != addr
+    monkeypatch.setenv("BNMTF_PIN_POOL_MB", "0")
+    del b, c
+    assert _lib._PIN_POOL_BYTES[0] == 0 and not any(_lib._PIN_POOL.values())
