@@ -114,9 +114,10 @@ class DeviceModel(object):
                 self._seed = int(np.random.randint(0, 2 ** 62))
             lr, lc, ls = self._lambda_arrays()
             # the device holds a 0/1 mask; the reference would weight by the values of M (all its callers pass 0/1)
-            assert ((self.M == 0) | (self.M == 1)).all(), "The indicator matrix M must contain only 0 and 1."
+            Mb = np.ascontiguousarray(self.M != 0)              # one byte per entry already: handed over as uint8 without a copy
+            assert (self.M == Mb).all(), "The indicator matrix M must contain only 0 and 1."
             self._keep = (np.ascontiguousarray(self.R, dtype=np.float32),
-                          np.ascontiguousarray(self.M != 0, dtype=np.uint8),
+                          Mb.view(np.uint8),
                           _lib.f64(lr), _lib.f64(lc), None if ls is None else _lib.f64(ls),
                           None if self._comm_id is None else np.frombuffer(bytes(self._comm_id), dtype=np.uint8).copy())
             R32, M8, lr, lc, ls, cid = self._keep

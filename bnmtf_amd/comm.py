@@ -201,18 +201,23 @@ def spawn_local(n, argv, env=None):
         procs.append(subprocess.Popen([sys.executable] + list(argv), env=e))
     # all ranks are polled together: one that dies early takes the others with it instead of leaving them at a barrier
     # until their own timeout
+    # (the exit code of a rank that was terminated HERE does not count: the code reported is the failing rank's own)
     rc = 0
     alive = list(procs)
+    killed = set()
     while alive:
         for p in list(alive):
             code = p.poll()
             if code is None:
                 continue
             alive.remove(p)
-            rc = max(rc, abs(code))
-            if code != 0:
+            if p not in killed:
+                rc = max(rc, abs(code))
+            if code != 0 and p not in killed:
                 for q in alive:
-                    q.terminate()
+                    if q.poll() is None:
+                        killed.add(q)
+                        q.terminate()
         if alive:
             time.sleep(0.05)
     return rc

@@ -79,11 +79,24 @@ static void parallel_chunks(int n, int chunk, Fn fn) {
   for (auto& t : ts) t.join();
 }
 
+// BNMTF_CREATE_TIMING=1: wall-clock laps of bnmtf_create's phases on stderr
+struct CreateLaps {
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  bool on = getenv("BNMTF_CREATE_TIMING") != nullptr;
+  void lap(const char* what) {
+    const auto now = std::chrono::steady_clock::now();
+    if (on) fprintf(stderr, "bnmtf_create: %-44s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+    t = now;
+  }
+};
 // ------------------------------------------------------------------ layout
 // Fill one direction.  get(u, r) returns (observed, value) of unit u (global) at
 // inner index r.
-template <typename Get>
-static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const double* lambda, Get get) {
+// dR / dM: the data and the mask on the device ([I][J] row major); by_rows: a unit is a row of R (else a column); obs: observed
+// entries per unit (global).  The I x J passes -- masked / transposed contraction operand, missing lists -- run on the device
+// (kernel_layout.hip); the slot layout below is built on the host from the downloaded lists.
+static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const double* lambda,
+                     const float* dR, const uint8_t* dM, int I, int J, bool by_rows, const std::vector<uint32_t>& obs, hipStream_t st) {
   d.nglob = nglob; d.m = m; d.W = W; d.KP = W <= 32 ? 32 : 64;
   {
     int64_t first = 0, count = 0;
@@ -106,35 +119,29 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
   d.ipw = round_up((m + d.split * 4 - 1) / (d.split * 4), 32);   // multiple of the GEMM's 2*U register-pipeline group
   d.inner_pad = d.split * 4 * d.ipw;
 
-  std::vector<float> big((size_t)d.inner_pad * d.n_pad, 0.0f);
+  CreateLaps laps;
   std::vector<uint32_t> ptr(d.n + 1, 0), idx;
   d.obs_count.assign(nglob, 0);
   d.nmiss = 0;
-  // 64 x 64 tiles (unit x inner): both the read of R/M (contiguous along one of the two) and the write of the
-  // transposed shard stay in cache whichever direction this is; a unit's missing list still comes out in inner order
-  std::vector<std::vector<uint32_t>> missv(d.n);
-  parallel_chunks(d.n, 64, [&](int a, int b) {
-    for (int r0 = 0; r0 < m; r0 += 64)
-      for (int ul = a; ul < b; ++ul) {
-        const int u = d.n0 + ul;
-        std::vector<uint32_t>& ms = missv[ul];
-        const int r1 = std::min(m, r0 + 64);
-        for (int r = r0; r < r1; ++r) {
-          float v;
-          if (get(u, r, &v)) big[(size_t)r * d.n_pad + ul] = v;
-          else ms.push_back((uint32_t)r);
-        }
-      }
-  });
   for (int ul = 0; ul < d.n; ++ul) {
-    d.nmiss += missv[ul].size();
-    ptr[ul + 1] = ptr[ul] + (uint32_t)((missv[ul].size() + 63) / 64 * 64);
+    const uint32_t cnt = (uint32_t)m - obs[d.n0 + ul];
+    d.nmiss += cnt;
+    ptr[ul + 1] = ptr[ul] + (cnt + 63u) / 64u * 64u;                 // 64-wide slots, padded with the zero sentinel m
   }
-  idx.assign(ptr[d.n], (uint32_t)m);                    // m = zero sentinel
-  parallel_chunks(d.n, 256, [&](int a, int b) {
-    for (int ul = a; ul < b; ++ul) std::copy(missv[ul].begin(), missv[ul].end(), idx.begin() + ptr[ul]);
-  });
-  d.nslots = idx.size();
+  d.nslots = ptr[d.n];
+  CHK(dalloc(&d.big, (size_t)d.inner_pad * d.n_pad));               // zero-filled: the pads stay zero
+  CHK(dalloc(&d.slot_ptr, ptr.size(), false));
+  HIPCHK(hipMemcpyAsync(d.slot_ptr, ptr.data(), ptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  CHK(dalloc(&d.idx, std::max<size_t>(d.nslots, 1), false));
+  launch_masked_operand(dR, dM, I, J, by_rows ? 1 : 0, d.n0, d.n, m, d.big, d.n_pad, st);
+  launch_missing_lists(dM, I, J, by_rows ? 1 : 0, d.n0, d.n, m, d.slot_ptr, d.idx, st);
+  idx.resize(d.nslots);
+  if (d.nslots) HIPCHK(hipMemcpyAsync(idx.data(), d.idx, d.nslots * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipGetLastError());
+  laps.lap("  build_dir: R~ operand + missing lists (device)");
+  auto miss_begin = [&](int ul) { return idx.data() + ptr[ul]; };
+  auto miss_end = [&](int ul) { return idx.data() + ptr[ul] + ((uint32_t)m - obs[d.n0 + ul]); };
 
   // fast layout: a unit owns a 32-lane half wave.  Lane r prefers the entries with j mod 32 == r (bank-conflict-free
   // LDS gathers).  Residue classes are binomially unbalanced, so instead of padding every lane to the fullest class
@@ -162,7 +169,11 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
       std::vector<uint32_t>* L = &lanes[((size_t)ul * nch + ch) * 32];
       const uint32_t lo = ch == 0 ? 0u : (uint32_t)d.mh, hi = (nch == 2 && ch == 0) ? (uint32_t)d.mh : 0xFFFFFFFFu;
       size_t cnt = 0;
-      for (uint32_t j : missv[ul]) if (j >= lo && j < hi) { L[(j - lo) & 31].push_back(j - lo); ++cnt; }
+      {   // one allocation per lane instead of a doubling chain (32 lanes x 8192 units: the layout pass was mostly malloc)
+        const size_t guess = (size_t)(miss_end(ul) - miss_begin(ul)) / (32 * (size_t)nch) + 8;
+        for (int r = 0; r < 32; ++r) L[r].reserve(guess);
+      }
+      for (const uint32_t* pj = miss_begin(ul); pj != miss_end(ul); ++pj) { const uint32_t j = *pj; if (j >= lo && j < hi) { L[(j - lo) & 31].push_back(j - lo); ++cnt; } }
       int emax = 0;
       for (int r = 0; r < 32; ++r) emax = std::max(emax, (int)L[r].size());
       int E = std::max(2, (emax + 1) & ~1);
@@ -313,13 +324,8 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
     CHK(dalloc(&d.stats, (size_t)d.stats_blocks * 4));
   }
 
-  CHK(dalloc(&d.big, big.size(), false));
-  HIPCHK(hipMemcpy(d.big, big.data(), big.size() * sizeof(float), hipMemcpyHostToDevice));
+  laps.lap("  build_dir: slot layout + its uploads");
   CHK(dalloc(&d.slabs, (size_t)d.split * d.n_pad * d.KP));
-  CHK(dalloc(&d.slot_ptr, ptr.size(), false));
-  HIPCHK(hipMemcpy(d.slot_ptr, ptr.data(), ptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  CHK(dalloc(&d.idx, idx.size(), false));
-  if (!idx.empty()) HIPCHK(hipMemcpy(d.idx, idx.data(), idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   CHK(dalloc(&d.q, idx.size()));
   std::vector<float> lam((size_t)std::max(d.n, 1) * d.KP, 0.0f);
   for (int ul = 0; ul < d.n; ++ul)
@@ -844,21 +850,25 @@ int bnmtf_create(const bnmtf_problem* p, bnmtf_handle* out) {
   for (int j = 0; j < J; ++j) if (!cc[j]) { set_error("Fully unobserved column in R, column %d.", j); return fail(BNMTF_EINVAL); }
   h->n_obs = n_obs; h->sumR = sR; h->sumR2 = sR2;
 
+  CreateLaps laps;
+  laps.t = t_create0;
+  laps.lap("counts and sums over the mask");
   const int Wr = p->K, Wc = p->L > 0 ? p->L : p->K;
-  int rcode = build_dir(h->rows, I, J, Wr, p->rank, p->world, p->lambda_rows,
-                        [&](int i, int j, float* v) { *v = R[(size_t)i * J + j]; return M[(size_t)i * J + j] != 0; });
+  int rcode;
+  if ((rcode = dalloc(&h->Rfull, (size_t)I * J, false))) return fail(rcode);
+  if (hipMemcpyAsync(h->Rfull, R, (size_t)I * J * sizeof(float), hipMemcpyHostToDevice, h->stream) != hipSuccess) { set_error("copy R failed"); return fail(BNMTF_EHIP); }
+  if ((rcode = dalloc(&h->Mtrain, (size_t)I * J, false))) return fail(rcode);
+  if (hipMemcpyAsync(h->Mtrain, M, (size_t)I * J, hipMemcpyHostToDevice, h->stream) != hipSuccess) { set_error("copy M failed"); return fail(BNMTF_EHIP); }
+  rcode = build_dir(h->rows, I, J, Wr, p->rank, p->world, p->lambda_rows, h->Rfull, h->Mtrain, I, J, true, rc, h->stream);
   if (rcode) return fail(rcode);
-  rcode = build_dir(h->cols, J, I, Wc, p->rank, p->world, p->lambda_cols,
-                    [&](int j, int i, float* v) { *v = R[(size_t)i * J + j]; return M[(size_t)i * J + j] != 0; });
+  rcode = build_dir(h->cols, J, I, Wc, p->rank, p->world, p->lambda_cols, h->Rfull, h->Mtrain, I, J, false, cc, h->stream);
   if (rcode) return fail(rcode);
+  laps.lap("both directions built (total)");
   h->rows.obs_count = rc; h->cols.obs_count = cc;
   if ((rcode = alloc_factor(h->rows, h->cols.inner_pad))) return fail(rcode);
   if ((rcode = alloc_factor(h->cols, h->rows.inner_pad))) return fail(rcode);
 
-  if ((rcode = dalloc(&h->Rfull, (size_t)I * J, false))) return fail(rcode);
-  if (hipMemcpy(h->Rfull, R, (size_t)I * J * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { set_error("copy R failed"); return fail(BNMTF_EHIP); }
-  if ((rcode = dalloc(&h->Mtrain, (size_t)I * J, false))) return fail(rcode);
-  if (hipMemcpy(h->Mtrain, M, (size_t)I * J, hipMemcpyHostToDevice) != hipSuccess) { set_error("copy M failed"); return fail(BNMTF_EHIP); }
+  laps.lap("factor buffers");
   if ((rcode = dalloc(&h->Ad, (size_t)I * 64))) return fail(rcode);
   if ((rcode = dalloc(&h->Bd, (size_t)J * 64))) return fail(rcode);
   if ((rcode = dalloc(&h->out6, 8))) return fail(rcode);

@@ -151,6 +151,10 @@ struct PostArgs {
 void launch_post(const PostArgs& a, hipStream_t st);
 void launch_post_layout(const PostArgs& a, hipStream_t st);                       // XT / XT2 (/ S2T / XS) of every row
 void launch_post_gram_rows(const PostArgs& a, int own0, int own1, hipStream_t st);   // C64, colsum (, colsum2) of the rows [own0, own1) only
+// bnmtf_create's passes over the I x J data, on the device (kernel_layout.hip): the masked (and, for the rows direction, transposed)
+// contraction operand big[r][ul], and every unit's missing inner indices in order (64-wide slots, padded with m)
+void launch_masked_operand(const float* R, const uint8_t* M, int I, int J, int by_rows, int unit0, int n, int m, float* out, int ld, hipStream_t st);
+void launch_missing_lists(const uint8_t* M, int I, int J, int by_rows, int unit0, int n, int m, const uint32_t* ptr, uint32_t* idx, hipStream_t st);
 // q hand-over tables of one writer / reader pair of directions, built on the device (kernel_handover.hip)
 struct HandoverArgs {
   // the writer's and the reader's slot layouts (FastArgs::off, pair_base, pair_E, unit_map), pairs, pairs per block (the sweep
