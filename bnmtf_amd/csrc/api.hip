@@ -211,6 +211,7 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
       Eu[ul] = nch * ehalf;                  // two chunks: each gets half of the unit's slot rows (a multiple of 4 in all)
     }
     });
+    laps.lap("    layout: lanes filled and balanced");
     auto res = [&](int ul, int ch, int r) -> const std::vector<uint32_t>& { return lanes[((size_t)ul * nch + ch) * 32 + r]; };
     std::vector<int> order(d.n);
     for (int i = 0; i < d.n; ++i) order[i] = i;
@@ -270,6 +271,7 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
       }
     });
     d.f_slots = rows_total;
+    laps.lap("    layout: slot table filled");
     CHK(dalloc(&d.f_unit_map, umap.size(), false));
     HIPCHK(hipMemcpy(d.f_unit_map, umap.data(), umap.size() * sizeof(int), hipMemcpyHostToDevice));
     CHK(dalloc(&d.f_pair_E, pE.size(), false));
@@ -322,6 +324,7 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
       }
     }
     CHK(dalloc(&d.stats, (size_t)d.stats_blocks * 4));
+    laps.lap("    layout: tables uploaded");
   }
 
   laps.lap("  build_dir: slot layout + its uploads");
