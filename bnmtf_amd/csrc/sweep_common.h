@@ -23,9 +23,14 @@ __device__ __forceinline__ float half_sum(float v) {          // all-reduce insi
 // inside the rows, then row_bcast:15 adds row 0's total into row 1 (and row 2's into row 3).  No LDS round trip.
 __device__ __forceinline__ float half_sum_upper(float v) {
   v = dpp_xor_row_sum(v);
-  // rows 1 and 3 add lane 15 of the row before them, rows 0 and 2 keep their value: ONE instruction (through the builtin the
-  // compiler makes a zero, a DPP move and an add of it; the hot loops run this two or three times per column and wave).
-  // s_nop 1: the two wait states a DPP read needs behind the vector instruction that wrote its source.
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));   // row_bcast:15, rows 1 and 3
+}
+// The same with the last step as ONE instruction: rows 1 and 3 add lane 15 of the row before them, rows 0 and 2 keep their value
+// (through the builtin the compiler makes a zero, a DPP move and an add of it).  s_nop 1: the two wait states a DPP read needs
+// behind the vector instruction that wrote its source.  For the Gibbs sweep's column loop (sweep_chip.inc), whose phases are
+// fenced anyway: in the VB sweep's loop the volatile statement upset the register allocation (750 spilled registers, 4 x slower).
+__device__ __forceinline__ float half_sum_upper_fused(float v) {
+  v = dpp_xor_row_sum(v);
   asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
   return v;
 }
