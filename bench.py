@@ -43,6 +43,7 @@ WORKLOADS = {
     "bnmtf_4096_k32": dict(kind="bnmtf", I=4096, J=4096, K=32, L=32),  # configs[3]
     "vb_8192_k64": dict(kind="vb", I=8192, J=8192, K=64),              # configs[4]
     "vb_4096_k32": dict(kind="vb", I=4096, J=4096, K=32),
+    "vb_8192_k32": dict(kind="vb", I=8192, J=8192, K=32),
 }
 PRI2 = dict(alpha=1.0, beta=1.0, lambdaU=0.1, lambdaV=0.1)
 PRI3 = dict(alpha=1.0, beta=1.0, lambdaF=0.1, lambdaS=0.1, lambdaG=0.1)
