@@ -262,6 +262,12 @@ def main():
     if a.warmup > 0:
         run(a.warmup, perf_w)
         trajectory += [float(x) for x in perf_w[:a.warmup, 0]]
+    # one untimed pass over the page-locked sample arrays: the device's first write to a fresh pinned page is slow (the first
+    # timed region ran at 600-1 700 instead of 2 400 it/s), and the arrays are re-used by every timed region
+    if with_samples:
+        perf_t = np.zeros((a.steps, 3))
+        run(a.steps, perf_t, samples=bufs)
+        trajectory += [float(x) for x in perf_t[:, 0]]
     # timed regions: HIP events bracket the roofline kernel only, on its own stream, in every fourth iteration (an event
     # record drains the queue for ~4 us: two per iteration were 2 % of the headline iteration)
     # (BNMTF: the cols direction's contraction is no pass over R~ any more -- (R~^T F) S from the S step's slabs -- so the
@@ -372,7 +378,7 @@ def main():
             "kernels": stats,
             "create_s": t_create,
             "mse_first_last": [float(perf_first[0, 0]), float(perf[-1, 0])],
-            "mse_trajectory": {"what": "masked MSE on the training mask after each iteration of this run, from iteration 1 (warm-up included), first %d" % min(len(trajectory), 200),
+            "mse_trajectory": {"what": "masked MSE on the training mask after each iteration of this run, from iteration 1 (warm-up and the untimed sample pass included), first %d" % min(len(trajectory), 200),
                                "values": trajectory[:200]},
             "cpu_baseline": cpu,
         }
