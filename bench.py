@@ -44,6 +44,15 @@ WORKLOADS = {
     "vb_8192_k64": dict(kind="vb", I=8192, J=8192, K=64),              # configs[4]
     "vb_4096_k32": dict(kind="vb", I=4096, J=4096, K=32),
     "vb_8192_k32": dict(kind="vb", I=8192, J=8192, K=32),
+    # the shapes the reference itself publishes numbers for: one small model / a model-selection job
+    "bnmf_toy_100x80_k10": dict(kind="bnmf", small=True, I=100, J=80, K=10, missing=0.0, steps=1000, published=29.3,
+                                source="plots/time_toy/nmf_gibbs_times.txt (1000 it in 34.16 s; experiments_toy/time/nmf_gibbs_time.py:23-51, M = ones)"),
+    "bnmf_gdsc_622x138_k25": dict(kind="bnmf", small=True, I=622, J=138, K=25, missing=0.19, steps=500, published=2.49,
+                                  source="plots/time_Sanger/nmf_gibbs_times.txt (500 it in 201.0 s; experiments_gdsc/time/nmf_gibbs_time.py:22-47, 81 % observed)"),
+    "bnmtf_toy_100x80_k5": dict(kind="bnmtf", small=True, I=100, J=80, K=5, L=5, missing=0.0, steps=1000, published=45.1,
+                                source="plots/time_toy/nmtf_gibbs_times.txt (2000 it in 44.37 s; experiments_toy/time/nmtf_gibbs_time.py:25-53)"),
+    "cv_gdsc": dict(kind="cv", small=True, I=622, J=138, K=25, missing=0.19, values_K=[15, 20, 25, 30], folds=10, iterations=1000, burn_in=900, thinning=2,
+                    source="experiments_gdsc/cross_validation/gibbs_nmf/linesearch_xval_gibbs.py:17-62 (10 folds x K in {15,20,25,30} x 1000 it, AIC, then 10 final models)"),
 }
 PRI2 = dict(alpha=1.0, beta=1.0, lambdaU=0.1, lambdaV=0.1)
 PRI3 = dict(alpha=1.0, beta=1.0, lambdaF=0.1, lambdaS=0.1, lambdaG=0.1)
@@ -194,16 +203,139 @@ def build_model(w, R, M, rank, world, local_rank, comm_id):
     return m
 
 
+def _small_problem(w, seed=0):
+    from bnmtf_amd.synthetic import generate_bnmf, generate_bnmtf
+    if w["kind"] == "bnmtf":
+        R, M, _, _, _ = generate_bnmtf(w["I"], w["J"], w["K"], w["L"], w["missing"], seed_data=seed, seed_mask=seed + 1)
+    else:
+        R, M, _, _ = generate_bnmf(w["I"], w["J"], w["K"], w["missing"], tau=1.0, seed_data=seed, seed_mask=seed + 1)
+    return R, M
+
+
+def _small_model(w, R, M, seed):
+    import bnmtf_amd
+    np.random.seed(seed)
+    if w["kind"] == "bnmtf":
+        m = bnmtf_amd.bnmtf_gibbs_optimised(R, M, w["K"], w["L"], PRI3, seed=seed, verbose=False)
+        m.initialise("random", "random")
+    else:
+        m = bnmtf_amd.bnmf_gibbs_optimised(R, M, w["K"], PRI2, seed=seed, verbose=False)
+        m.initialise("random")
+    m._push()
+    return m
+
+
+def main_small(a, w):
+    """The shapes the reference publishes numbers for: ONE small model through the class API (what its timing scripts do), a batch
+    of independent models in one launch (folds / ranks / restarts of a model search), and the cost of building a model."""
+    import bnmtf_amd
+    from bnmtf_amd import _lib
+    steps = a.steps if a.steps_given else w["steps"]
+    R, M = _small_problem(w)
+    # construction: class + initialise + handle (bnmtf_create), a fresh model each time
+    t_build = []
+    for s in range(6):
+        t0 = time.perf_counter(); m = _small_model(w, R, M, s); _lib.check(_lib.lib().bnmtf_sync(m._handle())); t_build.append(time.perf_counter() - t0)
+        if s < 5:
+            m.close()
+    m.run(max(a.warmup, 1))
+    # one model, the reference's call: run(iterations) with every sample handed to the host and the three metrics per iteration
+    dts = []
+    for _ in range(max(1, a.repeats)):
+        t0 = time.perf_counter(); m.run(steps); dts.append(time.perf_counter() - t0)
+    mse = list(m.all_performances["MSE"])
+    dt = float(np.median(dts))
+    dev_s = float(m.all_times[-1])           # the device's own clock over the last call (HIP events around the iterations)
+    t0 = time.perf_counter(); m.run(steps, store_samples=False); t_nos = time.perf_counter() - t0
+    desc = m.describe()
+    m.close()
+    # a batch of independent models (different masks / seeds, same shape) in ONE call: what a model search runs
+    batch = None
+    if hasattr(bnmtf_amd, "run_many"):
+        batch = {}
+        for nb in a.batch:
+            ms = []
+            for s in range(nb):
+                Rb, Mb = _small_problem(w, seed=100 + s) if nb <= 64 else (R, M)
+                ms.append(_small_model(w, Rb, Mb, 1000 + s))
+            bnmtf_amd.run_many(ms, max(a.warmup, 1), store_samples=False)
+            t0 = time.perf_counter(); bnmtf_amd.run_many(ms, steps, store_samples=False); tb = time.perf_counter() - t0
+            t0 = time.perf_counter(); bnmtf_amd.run_many(ms, steps, store_samples=True); tbs = time.perf_counter() - t0
+            fin = [float(x.all_performances["MSE"][-1]) for x in ms]
+            batch[str(nb)] = {"models": nb, "model_iterations_per_s": nb * steps / tb, "per_model_it_s": steps / tb, "with_samples_model_iterations_per_s": nb * steps / tbs,
+                              "final_mse_min_max": [min(fin), max(fin)]}
+            for x in ms:
+                x.close()
+    kind = w["kind"]
+    out = {"metric": ("Gibbs iterations/sec (BNMF, %dx%d, K=%d)" if kind == "bnmf" else "Gibbs iterations/sec (BNMTF, %dx%d, K=L=%d)") % (w["I"], w["J"], w["K"]),
+           "value": steps / dt, "unit": "Gibbs iterations/s", "n_gpus": 1, "steps": steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / steps,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": (steps / dt) / w["published"], "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "%s Gibbs, synthetic R %dx%d K=%d%s, %.0f %% missing, priors alpha=beta=1 lambda=0.1, init random; one model through the class API: run(%d) incl. the sample hand-off and the per-iteration metrics" % (
+               "BNMF" if kind == "bnmf" else "BNMTF", w["I"], w["J"], w["K"], " L=%d" % w["L"] if "L" in w else "", 100 * w["missing"], steps)},
+           "published": {"value": w["published"], "unit": "iterations/s", "hardware": "unstated CPU, Python 2.7 (BASELINE.md section 1)", "source": w["source"]},
+           "repeats": {"n": len(dts), "values": [steps / d for d in dts]},
+           "device_clock_it_s": steps / dev_s if dev_s > 0 else None, "no_samples_it_s": steps / t_nos,
+           "create_ms_per_model": {"median": 1e3 * float(np.median(t_build[1:])), "first": 1e3 * t_build[0], "what": "class constructor + initialise + bnmtf_create + state upload"},
+           "batch": batch, "mse_first_last": [mse[0], mse[-1]], "describe": desc, "roofline": None, "cpu_baseline": None}
+    print(json.dumps(out)); sys.stdout.flush()
+
+
+def main_cv(a, w):
+    """The reference's model-selection job (linesearch_xval_gibbs.py): 10 folds x K in {15, 20, 25, 30} x 1000 iterations through
+    LineSearchCrossValidation, then 10 final models -- 50 model fits -- on one GPU with s replica slots."""
+    import tempfile
+    import bnmtf_amd
+    from bnmtf_amd.cross_validation.line_search_cross_validation import LineSearchCrossValidation
+    from bnmtf_amd.cross_validation.replicas import ReplicaPool
+    import random
+    R, M = _small_problem(w)
+    its = a.steps if a.steps_given else w["iterations"]
+    burn, thin = (w["burn_in"], w["thinning"]) if its == w["iterations"] else (its // 2, 2)
+    res = {}
+    for s in a.slots:
+        random.seed(0); np.random.seed(0)
+        pool = ReplicaPool(devices=[0] * s, shared={"R": np.asarray(R, dtype=float)}, **({"batched": True} if a.cv_batched else {}))
+        with tempfile.NamedTemporaryFile("w", suffix=".txt") as f:
+            cv = LineSearchCrossValidation(classifier=bnmtf_amd.bnmf_gibbs_optimised, R=R, M=M, values_K=w["values_K"], folds=w["folds"], priors=PRI2,
+                                           init_UV="random", iterations=its, restarts=1, quality_metric="AIC", file_performance=f.name, pool=pool, seed=1)
+            pool.map(_noop, [{} for _ in range(s)])            # workers up (process start + library load are not the job)
+            t0 = time.perf_counter(); cv.run(burn_in=burn, thinning=thin); dt = time.perf_counter() - t0
+        pool.close()
+        nmodels = w["folds"] * len(w["values_K"]) + w["folds"]
+        res[str(s)] = {"slots": s, "seconds": dt, "models": nmodels, "model_iterations_per_s": nmodels * its / dt,
+                       "heldout_MSE": cv.average_performance["MSE"], "heldout_R2": cv.average_performance["R^2"]}
+    best = max(res.values(), key=lambda r: r["model_iterations_per_s"])
+    out = {"metric": "model-iterations/sec of the GDSC-shaped 10-fold line-search cross-validation (BNMF Gibbs 622x138, K in {15,20,25,30}, %d iterations)" % its,
+           "value": best["model_iterations_per_s"], "unit": "model-iterations/s", "n_gpus": 1, "steps": its, "warmup": 0, "ms_per_step": 1e3 * best["seconds"] / its,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (GDSC's shape and observed fraction)",
+           "config": {"workload": "LineSearchCrossValidation, %d folds x K in %s x %d iterations (burn-in %d, thinning %d) + %d final models; ReplicaPool slots on one GPU: %s%s" % (
+               w["folds"], w["values_K"], its, burn, thin, w["folds"], a.slots, ", batched launches" if a.cv_batched else ""), "source": w["source"]},
+           "by_slots": res, "roofline": None, "cpu_baseline": None}
+    print(json.dumps(out)); sys.stdout.flush()
+
+
+def _noop(job, shared):
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps iterations each; value = median")
     ap.add_argument("--workload", default="bnmf_8192_k64", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-samples", action="store_true", help="leave the samples on the device in the timed loop too (then `value` is NOT the reference's iteration)")
+    ap.add_argument("--batch", type=int, nargs="*", default=[16, 256], help="small workloads: models per batched call")
+    ap.add_argument("--slots", type=int, nargs="*", default=[1, 4], help="cv_gdsc: replica slots on the GPU")
+    ap.add_argument("--cv-batched", action="store_true", help="cv_gdsc: the pool fits its jobs in batched launches")
     a = ap.parse_args()
+    a.steps_given = a.steps is not None
+    if a.steps is None:
+        a.steps = 100
+    if WORKLOADS[a.workload].get("small"):
+        return (main_cv if WORKLOADS[a.workload]["kind"] == "cv" else main_small)(a, WORKLOADS[a.workload])
 
     from bnmtf_amd import comm
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
