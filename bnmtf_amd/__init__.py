@@ -10,5 +10,6 @@ from .bnmf_vb import bnmf_vb_optimised, bnmf_vb
 from .bnmtf_vb import bnmtf_vb_optimised, bnmtf_vb
 from .nmf_icm import nmf_icm
 from .nmtf_icm import nmtf_icm
+from .batch import run_many
 
-__all__ = ["bnmf_gibbs_optimised", "bnmf_gibbs", "bnmtf_gibbs_optimised", "bnmtf_gibbs", "bnmf_vb_optimised", "bnmf_vb", "bnmtf_vb_optimised", "bnmtf_vb", "nmf_icm", "nmtf_icm", "device_count", "BnmtfError", "lib", "LIB_PATH", "EXPORTS"]
+__all__ = ["bnmf_gibbs_optimised", "bnmf_gibbs", "bnmtf_gibbs_optimised", "bnmtf_gibbs", "bnmf_vb_optimised", "bnmf_vb", "bnmtf_vb_optimised", "bnmtf_vb", "nmf_icm", "nmtf_icm", "run_many", "device_count", "BnmtfError", "lib", "LIB_PATH", "EXPORTS"]

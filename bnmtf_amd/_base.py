@@ -188,6 +188,17 @@ class DeviceModel(object):
         """fast=False forces the generic sweep kernel (test hook; results are the same)."""
         _lib.check(_lib.lib().bnmtf_set_sweep_path(self._handle(), int(bool(fast))))
 
+    def set_small_path(self, on=True):
+        """on=False sends this model's run() down the multi-launch path even when it qualifies for the one-launch path for
+        small models (test / A-B hook; the chain is the same up to fp32 summation order)."""
+        _lib.check(_lib.lib().bnmtf_set_small_path(self._handle(), int(bool(on))))
+
+    def is_small(self):
+        """Does run() take the one-launch path (kernel_small.hip: the whole run in one launch, one block per model)?"""
+        out = C.c_int()
+        _lib.check(_lib.lib().bnmtf_is_small(self._handle(), C.byref(out)))
+        return bool(out.value)
+
     def kernel_stats(self, kernel):
         ms = C.c_double(); n = C.c_uint64()
         _lib.check(_lib.lib().bnmtf_kernel_stats(self._handle(), int(kernel), C.byref(ms), C.byref(n)))

@@ -1,0 +1,28 @@
+"""Independent models in one device call.
+
+    bnmtf_amd.run_many(models, iterations)      # every model ends as if its own run(iterations) had been called
+
+The reference fits the candidates of a model search -- folds x ranks x restarts -- one after the other
+(code/cross_validation/line_search_cross_validation.py:54-131, line_search_bnmf.py:53-76) or in a process pool
+(parallel_matrix_cross_validation.py:40-74).  Small BNMF Gibbs / ICM models run on the device as ONE block each
+(csrc/kernel_small.hip), so a list of them is one launch; models that do not qualify are run in turn."""
+import ctypes as C
+
+from . import _lib
+
+
+def run_many(models, iterations, update='draw', store_samples=True, expectation=None):
+    """run(iterations, update, store_samples, expectation) of every model in `models` (bnmf_gibbs_optimised instances, all on
+    one device), with the models of the one-launch path sharing a single launch.  Returns the list of the runs' results."""
+    models = list(models)
+    if not models:
+        return []
+    if not all(hasattr(m, "_run_prepare") for m in models):
+        raise TypeError("run_many takes bnmf_gibbs_optimised models")
+    bufs = [m._run_prepare(iterations, store_samples, expectation) for m in models]
+    n = len(models)
+    arr = lambda i: (C.c_void_p * n)(*[None if b[i] is None else b[i].ctypes.data for b in bufs])
+    hs = (C.c_void_p * n)(*[m._handle().value for m in models])
+    _lib.check(_lib.lib().bnmf_gibbs_run_many(hs, n, bufs[0][0], _lib.UPDATE_MODE if update == 'mode' else _lib.UPDATE_DRAW,
+                                              arr(1), arr(2), arr(3), arr(4), arr(5)))
+    return [m._run_finish(b, store_samples) for m, b in zip(models, bufs)]

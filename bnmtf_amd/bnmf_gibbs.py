@@ -82,15 +82,24 @@ class bnmf_gibbs_optimised(DeviceModel):
         expectation=(burn_in, thinning) also accumulates the posterior means of exactly that
         approx_expectation(burn_in, thinning) on the device (what the model-selection drivers
         need: with store_samples=False no sample ever crosses to the host)."""
+        bufs = self._run_prepare(iterations, store_samples, expectation)
+        it, U_out, V_out, taus, perf, times = bufs
+        _lib.check(_lib.lib().bnmf_gibbs_run(self._handle(), it, _lib.UPDATE_MODE if update == 'mode' else _lib.UPDATE_DRAW,
+                                             _lib.ptr(U_out), _lib.ptr(V_out), _lib.ptr(taus), _lib.ptr(perf), _lib.ptr(times)))
+        return self._run_finish(bufs, store_samples)
+
+    def _run_prepare(self, iterations, store_samples, expectation):
+        """State on the device, expectation switch, output arrays of one run() call (also used by bnmtf_amd.run_many)."""
         it = int(iterations)
         self._push()
         self._set_expectation(expectation, it)
         # page-locked sample arrays: the device-to-host copy of iteration t overlaps the sweeps of iteration t+1
         U_out = _lib.sample_buffer((it, self.I, self.K)) if store_samples else None
         V_out = _lib.sample_buffer((it, self.J, self.K)) if store_samples else None
-        taus = np.zeros(it); perf = np.zeros((it, 3)); times = np.zeros(it)
-        _lib.check(_lib.lib().bnmf_gibbs_run(self._handle(), it, _lib.UPDATE_MODE if update == 'mode' else _lib.UPDATE_DRAW,
-                                             _lib.ptr(U_out), _lib.ptr(V_out), _lib.ptr(taus), _lib.ptr(perf), _lib.ptr(times)))
+        return (it, U_out, V_out, np.zeros(it), np.zeros((it, 3)), np.zeros(it))
+
+    def _run_finish(self, bufs, store_samples):
+        it, U_out, V_out, taus, perf, times = bufs
         self._pull()
         # the samples are what the device drew: fp32 (the reference's arrays are fp64; every reduction below sums in fp64)
         self.all_U = U_out if store_samples else np.zeros((0, self.I, self.K))

@@ -52,15 +52,17 @@ class ReplicaError(Exception):
 
 
 class ReplicaPool(object):
-    def __init__(self, devices=None, shared=None):
+    def __init__(self, devices=None, shared=None, batched=False):
         """devices: list of device ordinals, one worker each (repeat an ordinal to run several models on one GPU at
         once); default: every visible GPU once.  shared: dict handed to every worker once (e.g. the data matrix R),
-        so that jobs only carry what differs between them."""
+        so that jobs only carry what differs between them.  batched: a slot fits ALL the model-fit jobs it is dealt in
+        one device call (bnmtf_amd.run_many: small models share a launch, one block each) instead of one after the other."""
         if devices is None:
             n = visible_devices()
             devices = list(range(max(n, 1)))
         self.devices = list(devices)
         self.shared = dict(shared or {})
+        self.batched = bool(batched)
         self._pool = None
 
     def _start(self):
@@ -76,7 +78,9 @@ class ReplicaPool(object):
         any job is raised here (after all jobs have run) with the worker's traceback -- or, with errors="return", comes
         back in the job's place as a ReplicaError (a caller that logs a failed setting and carries on)."""
         jobs = list(jobs)
-        if len(self.devices) <= 1:                      # single slot: in this process, like the reference's serial loops
+        if self.batched and fn is fit_model and jobs:
+            out = self._map_batched(jobs)
+        elif len(self.devices) <= 1:                    # single slot: in this process, like the reference's serial loops
             _worker_device[0] = self.devices[0] if self.devices else 0
             _worker_shared.clear(); _worker_shared.update(self.shared)
             out = [_call((fn, j)) for j in jobs]
@@ -87,6 +91,23 @@ class ReplicaPool(object):
         if errs and errors == "raise":
             raise RuntimeError("%d of %d replica jobs failed; first:\n%s" % (len(errs), len(jobs), errs[0]))
         return [ReplicaError(r[1]) if r[0] == "error" else r[1] for r in out]
+
+    def _map_batched(self, jobs):
+        """Every slot gets a contiguous share of the jobs and fits it as one batch."""
+        ns = max(len(self.devices), 1)
+        shares = [list(range(len(jobs)))[i::ns] for i in range(ns)]
+        if ns == 1:
+            _worker_device[0] = self.devices[0] if self.devices else 0
+            _worker_shared.clear(); _worker_shared.update(self.shared)
+            parts = [_call_batch([jobs[i] for i in shares[0]])]
+        else:
+            self._start()
+            parts = self._pool.map(_call_batch, [[jobs[i] for i in sh] for sh in shares], chunksize=1)
+        out = [None] * len(jobs)
+        for sh, part in zip(shares, parts):
+            for i, r in zip(sh, part):
+                out[i] = r
+        return out
 
     def close(self):
         if self._pool is not None:
@@ -100,6 +121,14 @@ class ReplicaPool(object):
         self.close()
 
 
+def _call_batch(jobs):
+    try:
+        return [("ok", r) for r in fit_models([dict(j, device=_worker_device[0]) for j in jobs], _worker_shared)]
+    except Exception as e:      # noqa: BLE001 -- one failure fails the share: every job of it reports it
+        msg = "%s: %s\n%s" % (type(e).__name__, e, traceback.format_exc())
+        return [("error", msg) for _ in jobs]
+
+
 def _accepts(fn, name):
     try:
         return name in inspect.signature(fn).parameters
@@ -107,15 +136,8 @@ def _accepts(fn, name):
         return False
 
 
-def fit_model(job, shared):
-    """One candidate model, start to finish, on the worker's GPU.  job:
-        classifier   the model class (bnmf_gibbs_optimised, nmf_icm, bnmtf_vb_optimised, ...)
-        args         positional arguments after (R, M): (K, priors) or (K, L, priors)
-        init         kwargs of initialise()
-        iterations, burn_in, thinning, minimum_TN (the last three may be None)
-        M            training mask;  test: mask to predict on, or None;  R: data matrix, or absent (then shared['R'])
-        seed         optional (numpy / random / sampler seed of this candidate)
-    Returns {'quality': {metric: value}, 'performance': predict(test) or None}."""
+def _build(job, shared):
+    """The model of one job: constructed and initialised (the job's seeds set first)."""
     import random
     R = job["R"] if job.get("R") is not None else shared["R"]
     cls = job["classifier"]
@@ -130,6 +152,10 @@ def fit_model(job, shared):
             kw["seed"] = job["seed"]
     model = cls(R, np.asarray(job["M"], dtype=float), *job["args"], **kw)
     model.initialise(**job["init"])
+    return model
+
+
+def _run_kw(job, model):
     burn_in, thinning = job.get("burn_in"), job.get("thinning")
     sampled = burn_in is not None and thinning is not None
     run_kw = {"iterations": job["iterations"]}
@@ -137,10 +163,46 @@ def fit_model(job, shared):
         run_kw["minimum_TN"] = job["minimum_TN"]
     if sampled and _accepts(model.run, "expectation"):          # posterior means on the device, no sample hand-off
         run_kw["expectation"] = (burn_in, thinning); run_kw["store_samples"] = False
-    model.run(**run_kw)
-    q_args = (burn_in, thinning) if sampled else ()
+    return run_kw, sampled
+
+
+def _score(job, model, sampled):
+    q_args = (job.get("burn_in"), job.get("thinning")) if sampled else ()
     quality = {m: model.quality(m, *q_args) for m in job.get("metrics", ["loglikelihood"])}
     perf = model.predict(np.asarray(job["test"], dtype=float), *q_args) if job.get("test") is not None else None
     if hasattr(model, "close"):
         model.close()
     return {"quality": quality, "performance": perf}
+
+
+def fit_model(job, shared):
+    """One candidate model, start to finish, on the worker's GPU.  job:
+        classifier   the model class (bnmf_gibbs_optimised, nmf_icm, bnmtf_vb_optimised, ...)
+        args         positional arguments after (R, M): (K, priors) or (K, L, priors)
+        init         kwargs of initialise()
+        iterations, burn_in, thinning, minimum_TN (the last three may be None)
+        M            training mask;  test: mask to predict on, or None;  R: data matrix, or absent (then shared['R'])
+        seed         optional (numpy / random / sampler seed of this candidate)
+    Returns {'quality': {metric: value}, 'performance': predict(test) or None}."""
+    model = _build(job, shared)
+    run_kw, sampled = _run_kw(job, model)
+    model.run(**run_kw)
+    return _score(job, model, sampled)
+
+
+def fit_models(jobs, shared):
+    """The same for a list of jobs at once: all models are built first, those that bnmtf_amd.run_many takes (BNMF Gibbs) and
+    that ask for the same run (iterations, expectation) go to the device as ONE call -- small models share a launch, one
+    block each --, then every model is scored.  Results in job order, each what fit_model(job) returns."""
+    from ..batch import run_many
+    models = [_build(j, shared) for j in jobs]
+    kws = [_run_kw(j, m) for j, m in zip(jobs, models)]
+    groups = {}
+    for i, (m, (kw, _)) in enumerate(zip(models, kws)):
+        if hasattr(m, "_run_prepare") and "minimum_TN" not in kw:
+            groups.setdefault((kw["iterations"], kw.get("expectation"), kw.get("store_samples", True)), []).append(i)
+        else:
+            m.run(**kw)
+    for (iterations, expectation, store), idx in groups.items():
+        run_many([models[i] for i in idx], iterations, store_samples=store, expectation=expectation)
+    return [_score(j, m, sampled) for j, m, (_, sampled) in zip(jobs, models, kws)]

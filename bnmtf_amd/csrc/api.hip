@@ -597,6 +597,11 @@ static int set_tau(bnmtf_model* h, double tau) {
 }
 
 static int bnmtf_alloc_extras(bnmtf_model* h, const double* lambdaS);
+static int build_standard(bnmtf_model* h, const double* lambda_S, const uint8_t* comm_id);
+static void describe_model(bnmtf_model* h);
+static int small_build(bnmtf_model* h, const float* R, const uint8_t* M);
+static void small_free(bnmtf_model* h);
+static int ensure_std(bnmtf_model* h);
 
 // ------------------------------------------------------------ sample hand-off
 // run() hands every sample to the host (all_U[it], all_V[it]; bnmf_gibbs_optimised.py:146-148).  The factor is packed
@@ -776,6 +781,8 @@ static void expectation_add(bnmtf_model* h, int it) {
 
 }  // namespace bnmtf
 
+#include "api_small.inc"
+
 using namespace bnmtf;
 
 // ======================================================================= C ABI
@@ -863,13 +870,59 @@ int bnmtf_create(const bnmtf_problem* p, bnmtf_handle* out) {
   laps.lap("counts and sums over the mask");
   const int Wr = p->K, Wc = p->L > 0 ? p->L : p->K;
   int rcode;
-  if ((rcode = dalloc(&h->Rfull, (size_t)I * J, false))) return fail(rcode);
+  // the geometry every entry point may ask for, whichever path runs the model
+  h->rows.nglob = I; h->rows.m = J; h->rows.W = Wr; h->rows.KP = Wr <= 32 ? 32 : 64;
+  h->cols.nglob = J; h->cols.m = I; h->cols.W = Wc; h->cols.KP = Wc <= 32 ? 32 : 64;
+  h->rows.obs_count = rc; h->cols.obs_count = cc;
+  {   // the full matrix and the training mask (predict / validation; the layout passes read them on the device); small scalars -- one allocation
+    const size_t bR = ((size_t)I * J * sizeof(float) + 255) & ~(size_t)255, bM = ((size_t)I * J + 255) & ~(size_t)255;
+    char* base = nullptr;
+    if ((rcode = dalloc(&base, bR + bM + 256, false))) return fail(rcode);
+    h->Rfull = reinterpret_cast<float*>(base); h->Mtrain = reinterpret_cast<uint8_t*>(base + bR);
+    h->out6 = reinterpret_cast<double*>(base + bR + bM); h->tau_d = h->out6 + 8; h->acc = h->out6 + 12; h->tau_f = reinterpret_cast<float*>(h->out6 + 16);
+    if (hipMemsetAsync(base + bR + bM, 0, 256, h->stream) != hipSuccess) { set_error("memset failed"); return fail(BNMTF_EHIP); }
+  }
   if (hipMemcpyAsync(h->Rfull, R, (size_t)I * J * sizeof(float), hipMemcpyHostToDevice, h->stream) != hipSuccess) { set_error("copy R failed"); return fail(BNMTF_EHIP); }
-  if ((rcode = dalloc(&h->Mtrain, (size_t)I * J, false))) return fail(rcode);
   if (hipMemcpyAsync(h->Mtrain, M, (size_t)I * J, hipMemcpyHostToDevice, h->stream) != hipSuccess) { set_error("copy M failed"); return fail(BNMTF_EHIP); }
-  rcode = build_dir(h->rows, I, J, Wr, p->rank, p->world, p->lambda_rows, h->Rfull, h->Mtrain, I, J, true, rc, h->stream);
+  // Small models (kernel_small.hip: the whole run in one launch, one block per model) build only their own arena here; the
+  // structures of the multi-launch path -- contraction operands, slot layouts, Gram partials, ... -- are built the first time an
+  // entry point needs them (ensure_std).  BNMTF_SMALL=0: never.
+  h->lam_rows.assign(p->lambda_rows, p->lambda_rows + (size_t)I * Wr);
+  h->lam_cols.assign(p->lambda_cols, p->lambda_cols + (size_t)J * Wc);
+  if (p->L == 0 && p->world == 1 && !getenv("BNMTF_FORCE_COMM")) {
+    if ((rcode = small_build(h, R, M))) return fail(rcode);
+  }
+  if (h->small) {
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { set_error("bnmtf_create: uploads failed"); return fail(BNMTF_EHIP); }    // (R, M are the caller's)
+    h->std_built = false;
+    laps.lap("small-model arena");
+  } else {
+    if ((rcode = build_standard(h, p->lambda_S, p->comm_id))) return fail(rcode);
+  }
+  h->create_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create0).count();
+  describe_model(h);
+  *out = h;
+  return BNMTF_OK;
+}
+}  // extern "C"
+
+namespace bnmtf {
+// The multi-launch path's part of a handle: both directions' contraction operands and slot layouts, factor buffers, the BNMTF
+// extras, the communicator, the q hand-over tables.  Called by bnmtf_create, or -- for a model that started on the small path --
+// by the first entry point that needs it.
+static int build_standard(bnmtf_model* h, const double* lambda_S, const uint8_t* comm_id) {
+  const auto t_create0 = std::chrono::steady_clock::now();
+  const int I = h->I, J = h->J;
+  const int Wr = h->K, Wc = h->L > 0 ? h->L : h->K;
+  struct { int K, L, rank, world; const uint8_t* comm_id; const double* lambda_S; uint64_t seed; } pv{h->K, h->L, h->rank, h->world, comm_id, lambda_S, h->seed};
+  auto* p = &pv;
+  auto fail = [&](int rc) { return rc; };
+  CreateLaps laps;
+  int rcode;
+  const std::vector<uint32_t> rc = h->rows.obs_count, cc = h->cols.obs_count;
+  rcode = build_dir(h->rows, I, J, Wr, p->rank, p->world, h->lam_rows.data(), h->Rfull, h->Mtrain, I, J, true, rc, h->stream);
   if (rcode) return fail(rcode);
-  rcode = build_dir(h->cols, J, I, Wc, p->rank, p->world, p->lambda_cols, h->Rfull, h->Mtrain, I, J, false, cc, h->stream);
+  rcode = build_dir(h->cols, J, I, Wc, p->rank, p->world, h->lam_cols.data(), h->Rfull, h->Mtrain, I, J, false, cc, h->stream);
   if (rcode) return fail(rcode);
   laps.lap("both directions built (total)");
   h->rows.obs_count = rc; h->cols.obs_count = cc;
@@ -879,10 +932,6 @@ int bnmtf_create(const bnmtf_problem* p, bnmtf_handle* out) {
   laps.lap("factor buffers");
   if ((rcode = dalloc(&h->Ad, (size_t)I * 64))) return fail(rcode);
   if ((rcode = dalloc(&h->Bd, (size_t)J * 64))) return fail(rcode);
-  if ((rcode = dalloc(&h->out6, 8))) return fail(rcode);
-  if ((rcode = dalloc(&h->tau_d, 1))) return fail(rcode);
-  if ((rcode = dalloc(&h->tau_f, 1))) return fail(rcode);
-  if ((rcode = dalloc(&h->acc, 4))) return fail(rcode);
   if (p->L > 0 && (rcode = dalloc(&h->S, (size_t)p->K * p->L))) return fail(rcode);
   if (p->L > 0 && (rcode = bnmtf_alloc_extras(h, p->lambda_S))) return fail(rcode);
 
@@ -917,8 +966,16 @@ int bnmtf_create(const bnmtf_problem* p, bnmtf_handle* out) {
     if (const char* r = getenv("BNMTF_HANDOVER_REFRESH")) h->ho_refresh = (uint64_t)std::max(1, atoi(r));
     if (getenv("BNMTF_CREATE_TIMING")) fprintf(stderr, "hand-over tables: %.1f ms (create so far %.1f ms)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_ho0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create0).count());
   }
-  h->create_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create0).count();
-  char buf[768];
+  h->std_built = true;
+  h->create_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create0).count();
+  return BNMTF_OK;
+}
+static void describe_model(bnmtf_model* h) {
+  const int I = h->I, J = h->J;
+  struct { int K, L, rank, world; } pv{h->K, h->L, h->rank, h->world};
+  auto* p = &pv;
+  const double n_obs = h->n_obs;
+  char buf[1024];
   snprintf(buf, sizeof(buf),
            "I=%d J=%d K=%d L=%d rank=%d/%d rows[n=%d n_pad=%d split=%d ipw=%d inner_pad=%d nmiss=%zu nslots=%zu sweep_nw=%d turns=%d twin=%d handover=%d emax=%d generic_units=%d] "
            "cols[n=%d n_pad=%d split=%d ipw=%d inner_pad=%d nmiss=%zu nslots=%zu sweep_nw=%d turns=%d emax=%d generic_units=%d] n_obs=%.0f create_ms=%.0f",
@@ -926,9 +983,14 @@ int bnmtf_create(const bnmtf_problem* p, bnmtf_handle* out) {
            h->rows.nmiss, h->rows.nslots, h->rows.f_nw, (int)h->rows.use_turns, (int)h->rows.use_twin, (int)h->ho_enabled, h->rows.f_emax, h->rows.f_gen_count, h->cols.n, h->cols.n_pad, h->cols.split,
            h->cols.ipw, h->cols.inner_pad, h->cols.nmiss, h->cols.nslots, h->cols.f_nw, (int)h->cols.use_turns, h->cols.f_emax, h->cols.f_gen_count, n_obs, h->create_ms);
   h->description = buf;
-  *out = h;
-  return BNMTF_OK;
+  if (h->small) {
+    snprintf(buf, sizeof(buf), " small[block=%d entry_threads=%d/%d slots=%d/%d lds=%zu std_built=%d]", h->small->nt, h->small->dev.rows.nthreads, h->small->dev.cols.nthreads,
+             h->small->dev.rows.em, h->small->dev.cols.em, h->small->lds_bytes, (int)h->std_built);
+    h->description += buf;
+  }
 }
+}  // namespace bnmtf
+extern "C" {
 
 int bnmtf_destroy(bnmtf_handle h) {
   if (!h) return BNMTF_OK;
@@ -940,9 +1002,11 @@ int bnmtf_destroy(bnmtf_handle h) {
   dfree(h->exp_rows); dfree(h->exp_cols); dfree(h->exp_S); dfree(h->exp_tau);
   dfree(h->muS); dfree(h->tauS); dfree(h->varS); dfree(h->mv_rows); dfree(h->mv_cols); dfree(h->tri_order); dfree(h->tri_sums);
   dfree(h->ss_Wc); dfree(h->ss_Gc); dfree(h->ss_cands); dfree(h->ss_slabs); dfree(h->ss_AB); dfree(h->ss_r); dfree(h->ss_bpart);
-  dfree(h->Rfull); dfree(h->Mtrain); dfree(h->Mscratch); dfree(h->Ad); dfree(h->Bd); dfree(h->out6);
+  small_free(h);
+  dfree(h->Rfull); h->Mtrain = nullptr; h->out6 = nullptr; h->tau_d = nullptr; h->tau_f = nullptr; h->acc = nullptr;   // (one allocation: bnmtf_create)
+  dfree(h->Mscratch); dfree(h->Ad); dfree(h->Bd);
   dfree(h->A2d); dfree(h->B2d); dfree(h->vb_rec); dfree(h->vbred);
-  dfree(h->tau_d); dfree(h->tau_f); dfree(h->acc); dfree(h->rec); dfree(h->gunit); dfree(h->S);
+  dfree(h->rec); dfree(h->gunit); dfree(h->S);
   for (auto& pe : h->pending_events) { (void)hipEventDestroy(pe.second.first); (void)hipEventDestroy(pe.second.second); }
   for (auto e : h->event_pool) (void)hipEventDestroy(e);
   if (h->copy_stream) {
@@ -1030,6 +1094,8 @@ int bnmtf_set_profiling(bnmtf_handle h, int enable) {
   return BNMTF_OK;
 }
 int bnmtf_set_sweep_path(bnmtf_handle h, int fast) { h->use_fast = fast != 0; h->ho_regions_current = false; return BNMTF_OK; }
+int bnmtf_set_small_path(bnmtf_handle h, int on) { h->small_enabled = on != 0; return BNMTF_OK; }
+int bnmtf_is_small(bnmtf_handle h, int* out) { *out = small_wanted(h) ? 1 : 0; return BNMTF_OK; }
 int bnmtf_kernel_stats(bnmtf_handle h, int kernel, double* total_ms, uint64_t* launches) {
   if (kernel < 0 || kernel >= BNMTF_KERNEL_COUNT) { set_error("bad kernel id"); return BNMTF_EINVAL; }
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -1046,8 +1112,13 @@ int bnmtf_describe(bnmtf_handle h, char* buf, size_t buflen) {
 int bnmf_set_state(bnmtf_handle h, const double* U, const double* V, double tau) {
   if (h->L != 0) { set_error("bnmf_set_state on a BNMTF handle"); return BNMTF_ESTATE; }
   HIPCHK(hipSetDevice(h->device));
-  CHK(upload_factor(h, h->rows, U));
-  CHK(upload_factor(h, h->cols, V));
+  h->std_cur = false; h->small_cur = false;
+  if (h->std_built) {
+    CHK(upload_factor(h, h->rows, U));
+    CHK(upload_factor(h, h->cols, V));
+    h->std_cur = true;
+  }
+  if (h->small) CHK(small_upload_state(h, U, V));
   CHK(set_tau(h, tau));
   h->have_state = true;
   h->ho_regions_current = false;          // (q hand-over: whatever the regions hold belongs to the state that was just replaced)
@@ -1057,8 +1128,11 @@ int bnmf_set_state(bnmtf_handle h, const double* U, const double* V, double tau)
 int bnmf_get_state(bnmtf_handle h, double* U, double* V, double* tau) {
   if (!h->have_state) { set_error("no state set"); return BNMTF_ESTATE; }
   HIPCHK(hipSetDevice(h->device));
-  if (U) CHK(download_matrix(h, h->rows.X, h->I, h->rows.W, h->rows.KP, U));
-  if (V) CHK(download_matrix(h, h->cols.X, h->J, h->cols.W, h->cols.KP, V));
+  if (h->small && h->small_cur) CHK(small_download_state(h, U, V));
+  else {
+    if (U) CHK(download_matrix(h, h->rows.X, h->I, h->rows.W, h->rows.KP, U));
+    if (V) CHK(download_matrix(h, h->cols.X, h->J, h->cols.W, h->cols.KP, V));
+  }
   if (tau) {
     HIPCHK(hipMemcpyAsync(tau, h->tau_d, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1073,6 +1147,7 @@ int bnmf_cond_params(bnmtf_handle h, int which, int k, double* numer_out, double
   Dir& o = which == 0 ? h->cols : h->rows;
   if (k < 0 || k >= d.W) { set_error("column %d out of range", k); return BNMTF_EINVAL; }
   HIPCHK(hipSetDevice(h->device));
+  CHK(ensure_std(h));
   enqueue_gemm(h, d, o, which == 0 ? BNMTF_KERNEL_GEMM_ROWS : BNMTF_KERNEL_GEMM_COLS);
   SweepArgs s = sweep_args(h, d, o, kSweepDraw, which == 0 ? kStreamRows : kStreamCols);
   s.cond_k = k;
@@ -1091,8 +1166,14 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
   if (n_iter < 0) { set_error("negative iteration count"); return BNMTF_EINVAL; }
   if (n_iter == 0) return BNMTF_OK;
   HIPCHK(hipSetDevice(h->device));
-  CHK(ensure_rec(h, (size_t)n_iter));
   if (update < 0 || update > BNMTF_UPDATE_ICM) { set_error("unknown update rule"); return BNMTF_EINVAL; }
+  if (small_wanted(h)) {                       // a small model: the whole call is one launch (kernel_small.hip)
+    const SmallOut o{U_out, V_out, tau_out, perf_out, times_out};
+    return small_run_many(&h, 1, n_iter, update, &o);
+  }
+  CHK(ensure_std(h));
+  h->std_cur = true; h->small_cur = false;
+  CHK(ensure_rec(h, (size_t)n_iter));
   const int mode = update == BNMTF_UPDATE_DRAW ? kSweepDraw : kSweepMode;
   h->cur_min_x = update == BNMTF_UPDATE_ICM ? (float)h->min_tn : 0.f;
   Dir& r = h->rows; Dir& c = h->cols;
@@ -1179,6 +1260,37 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
   return BNMTF_OK;
 }
 
+int bnmf_gibbs_run_many(const bnmtf_handle* hs, int n_models, int n_iter, int update, float* const* U_outs, float* const* V_outs,
+                        double* const* tau_outs, double* const* perf_outs, double* const* times_outs) {
+  if (n_models < 0 || n_iter < 0) { set_error("negative count"); return BNMTF_EINVAL; }
+  if (n_models == 0 || n_iter == 0) return BNMTF_OK;
+  if (update < 0 || update > BNMTF_UPDATE_ICM) { set_error("unknown update rule"); return BNMTF_EINVAL; }
+  // models of the one-launch path go down in one grid per device; the others run one after the other
+  std::vector<bnmtf_model*> batch; std::vector<SmallOut> outs;
+  auto out_of = [&](int b) { return SmallOut{U_outs ? U_outs[b] : nullptr, V_outs ? V_outs[b] : nullptr, tau_outs ? tau_outs[b] : nullptr,
+                                             perf_outs ? perf_outs[b] : nullptr, times_outs ? times_outs[b] : nullptr}; };
+  std::vector<char> taken(n_models, 0);
+  for (int b = 0; b < n_models; ++b) {
+    if (taken[b]) continue;
+    if (!small_wanted(hs[b]) || hs[b]->L != 0) {
+      const SmallOut o = out_of(b);
+      CHK(bnmf_gibbs_run(hs[b], n_iter, update, o.U, o.V, o.tau, o.perf, o.times));
+      taken[b] = 1;
+      continue;
+    }
+    batch.clear(); outs.clear();
+    for (int c = b; c < n_models; ++c)
+      if (!taken[c] && small_wanted(hs[c]) && hs[c]->device == hs[b]->device) {
+        bool dup = false;
+        for (bnmtf_model* x : batch) dup = dup || x == hs[c];
+        if (dup) { set_error("bnmf_gibbs_run_many: the same handle twice"); return BNMTF_EINVAL; }
+        batch.push_back(hs[c]); outs.push_back(out_of(c)); taken[c] = 1;
+      }
+    CHK(small_run_many(batch.data(), (int)batch.size(), n_iter, update, outs.data()));
+  }
+  return BNMTF_OK;
+}
+
 // ---------------------------------------------------------------------- metrics
 int bnmtf_metric_sums(bnmtf_handle h, const uint8_t* Mp, const double* A, const double* S, const double* B,
                       double sums_out[6]) {
@@ -1189,8 +1301,11 @@ int bnmtf_metric_sums(bnmtf_handle h, const uint8_t* Mp, const double* A, const 
   if (!A) {
     if (!h->have_state) { set_error("no state set"); return BNMTF_ESTATE; }
     a_own.resize((size_t)I * h->rows.W); b_own.resize((size_t)J * h->cols.W);
-    CHK(download_matrix(h, h->rows.X, I, h->rows.W, h->rows.KP, a_own.data()));
-    CHK(download_matrix(h, h->cols.X, J, h->cols.W, h->cols.KP, b_own.data()));
+    if (h->small && h->small_cur) CHK(small_download_state(h, a_own.data(), b_own.data()));
+    else {
+      CHK(download_matrix(h, h->rows.X, I, h->rows.W, h->rows.KP, a_own.data()));
+      CHK(download_matrix(h, h->cols.X, J, h->cols.W, h->cols.KP, b_own.data()));
+    }
     A = a_own.data(); B = b_own.data();
     if (h->L > 0) {
       as.resize((size_t)h->K * h->L);
@@ -1214,6 +1329,7 @@ int bnmtf_metric_sums(bnmtf_handle h, const uint8_t* Mp, const double* A, const 
     Kc = h->L > 0 ? h->L : h->K;
     if (h->L > 0) { set_error("bnmtf_metric_sums: S required for a BNMTF handle"); return BNMTF_EINVAL; }
   }
+  if (!h->Ad) { CHK(dalloc(&h->Ad, (size_t)I * 64, false)); CHK(dalloc(&h->Bd, (size_t)J * 64, false)); }
   HIPCHK(hipMemcpyAsync(h->Ad, A, sizeof(double) * (size_t)I * Kc, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->Bd, B, sizeof(double) * (size_t)J * Kc, hipMemcpyHostToDevice, h->stream));
   const uint8_t* mask = h->Mtrain;

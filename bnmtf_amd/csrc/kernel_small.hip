@@ -1,0 +1,632 @@
+// Small models: the whole run(n) of one BNMF Gibbs model in ONE launch, one 16-wave block (one CU) per model; a batch of
+// independent models -- the folds x ranks x restarts of a model search -- is one grid.
+//
+// The reference's loop (bnmf_gibbs_optimised.py:133-155; tauU/muU :167-171, tauV/muV :173-177) in the exact Gram +
+// sparse-complement form of the large path (kernel_sweep.hip header), laid out for ONE CU:
+//
+//  * both factors live in LDS for the whole launch, row major with an odd row stride (33): a gather of column k over
+//    arbitrary rows, a row read by the MFMA B fragment and a per-unit write are all (nearly) conflict-free.  The region of
+//    the factor being updated holds, during its half sweep, the running numerator base
+//        G_uk = tau P_uk - lambda_uk - tau sum_l x_ul C_lk
+//    instead (P = R~ . Xo the masked contraction, C = Xo^T Xo); entry (u, k) is replaced by the new x_uk when column k is
+//    done, so after the sweep the region holds the new factor and no relayout pass exists.
+//  * the contraction is the block's own: v_mfma_f32_16x16x4_f32 tiles, R~ streamed from L2 with the unit index on the
+//    lanes (1, 2 or 4 units per lane and load, picked so that the items fill the four SIMDs), the other factor's rows as
+//    the B fragment straight from LDS; the K x K term - X.C rides in the same accumulators (32 more inner steps); the
+//    epilogue scales by tau and subtracts lambda.
+//  * q_ij = U_i . V_j on the MISSING entries sits in registers of "entry threads" (up to 32 slots per thread, a unit's
+//    entries over consecutive threads); a column is: deferred update of column k-1 + gather of column k + two partial sums
+//    per entry thread -> LDS -> the unit's own thread (thread u <-> unit u) sums its segment, forms (numer, tau_p), draws.
+//    After the draw the unit thread folds delta into the numerator bases of the columns still to come.
+//  * draws: Philox-4x32-10 keyed exactly as in the large kernels (row, column, iteration, stream | candidate << 4), first
+//    accepted candidate of the fixed candidate sequence (oracle/rng.py).  Candidate 0 is evaluated by the unit thread; the
+//    units that rejected it are compacted into a block-wide list and get their next W candidates evaluated by W lanes
+//    each (W = 1024 / rejected, a power of two <= 64), again until the list is empty: no thread loops over a divergent
+//    rejection chain.
+//  * between the half sweeps q is handed over through a per-model array in L2 (the other direction holds the same entries
+//    in another order: a permutation table per direction); the rows sweep of every `refresh`-th iteration rebuilds q from
+//    the factors, as the large path does.
+//  * Gram matrices in fp64 on v_mfma_f64_16x16x4_f64 from the LDS copy; masked SSE / MSE / R^2 / Rp from the Gram
+//    identities (kernel_misc.hip finish_kernel: same formulas), tau from the host-staged Gamma variate.
+#include <algorithm>
+
+#include "../../include/bnmtf_hip.h"
+#include "kernels.h"
+#include "sweep_common.h"
+
+namespace bnmtf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2n __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2n __attribute__((ext_vector_type(2)));
+
+// Pointers that come out of the launch descriptor are generic to the compiler: it would emit FLAT loads and stores, which also
+// count on the LDS counter -- so that every LDS-only barrier of the column loop would wait for the global traffic in flight
+// (the first version of this kernel: 60 us per toy iteration).  G(p): the same pointer in the global address space.
+template <typename T> __device__ __forceinline__ __attribute__((address_space(1))) T* G(T* p) { return (__attribute__((address_space(1))) T*)p; }
+#ifdef BNMTF_SMALL_TIMING
+// debug build only (tools/variant.sh small_timing kernel_small.hip -DBNMTF_SMALL_TIMING): shader-clock sums per phase, printed by block 0
+#define STAMP(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); ph[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+constexpr int kS = kSmallStride;
+// Two block barriers.  bar_lds: LDS traffic only -- global loads issued ahead (the next column's old values) and global stores
+// (samples, state) stay in flight across it; a wave waiting for its own global stores in front of every barrier of the
+// column loop is what made the first version of this kernel as slow as the multi-launch path.  bar_all: also the wave's
+// global stores and loads -- where another thread of the block reads what this one wrote to global memory.
+__device__ __forceinline__ void bar_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void bar_all() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// misc area behind the factors and the two Gram copies (floats), for a block of NT threads: the fixed part first, then the
+// sweep's exchange arrays -- which the Gram's scratch re-uses between the sweeps
+template <int NT> struct Misc {
+  static constexpr int cnt = 0;                    // int [4] lengths of the three rotating lists of rejected units
+  static constexpr int red = 4;                    // double [NT / 64][4] + [4] block reductions
+  static constexpr int tau = red + 136;            // float tau
+  static constexpr int c64 = tau + 4;              // double [32][32] Gram of the rows factor (the end of the iteration takes <C_rows, C_cols> from it)
+  static constexpr int colsum = c64 + 2048;        // double [2][32] column sums of the two factors
+  static constexpr int part = colsum + 128;        // float2 [NT] partial (sum q v, sum v^2) of every entry thread
+  static constexpr int numer = part + 2 * NT;      // [NT] numer of a unit that rejected candidate 0
+  static constexpr int taup = numer + NT;          // [NT] its tau_p
+  static constexpr int xk = taup + NT;             // [NT] its old value
+  static constexpr int dl = xk + NT;               // [NT] delta of the column just drawn, per unit
+  static constexpr int xnw = dl + NT;              // [NT] draw made in a retry round, per unit
+  static constexpr int list = xnw + NT;            // uint16 [3][NT] rejected units
+  static constexpr int floats = list + 3 * NT / 2;
+  // Gram scratch (between the sweeps, from `part` on): NT / 256 waves x 3 tiles x 256 doubles, 8 slices x 32 doubles
+  static constexpr int gram_waves = NT / 256;
+  static_assert(gram_waves * 3 * 256 * 2 + 8 * 32 * 2 <= floats - part, "the Gram scratch re-uses the sweep's exchange area");
+  static_assert(red % 2 == 0 && c64 % 2 == 0 && part % 2 == 0, "doubles are 8-byte aligned");
+};
+
+__host__ __device__ inline int small_misc_offset(int I, int J) { return ((I + 1) * kS + (J + 1) * kS + 2 * 32 * kS + 3) & ~3; }
+size_t small_lds_bytes(int I, int J, int nt) {
+  return sizeof(float) * (size_t)(small_misc_offset(I, J) + (nt <= 256 ? Misc<256>::floats : (nt <= 512 ? Misc<512>::floats : Misc<1024>::floats)));
+}
+
+// sum of four doubles over the block, in a fixed order (wave: xor butterfly; block: wave 0 .. 15); every thread gets the sums
+template <int NT>
+__device__ __forceinline__ void block_sum4(double v[4], double* red, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v[t] += __shfl_xor(v[t], m, 64);
+  }
+  bar_lds();
+  if (lane == 0) { red[wave * 4 + 0] = v[0]; red[wave * 4 + 1] = v[1]; red[wave * 4 + 2] = v[2]; red[wave * 4 + 3] = v[3]; }
+  bar_lds();
+  if (tid < 4) {
+    double s = 0.0;
+#pragma unroll 4
+    for (int w = 0; w < NT / 64; ++w) s += red[w * 4 + tid];
+    red[64 + tid] = s;
+  }
+  bar_lds();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) v[t] = red[64 + t];
+}
+
+// C = X^T X (fp64) of the factor in `reg` ([n][33] in LDS): v_mfma_f64_16x16x4_f64 over 4 units per step.  The steps are
+// dealt to FOUR groups (step j to group j mod 4) whose partial tiles are added as (g0 + g1) + (g2 + g3) -- by four waves, two
+// waves or one wave depending on the block size, but always in that order: a model gives the same bits in a 256-thread block
+// of its own and in a 1024-thread block of a mixed batch.  Results, all in LDS: Cs ([32][33], fp32: what the other direction's
+// sweep reads), the column sums (fp64, 8 slices added in slice order), and either the fp64 Gram itself (c64_out: the rows
+// factor) or <C_other, C> (c64_dot: the cols factor, at the end of the iteration; returned by thread 0, zero elsewhere).
+// Columns >= K of the region are zero.
+template <int NT>
+__device__ __forceinline__ double small_gram(const float* reg, int n, int K, float* scratch, float* Cs, double* colsum, double* c64_out, const double* c64_dot, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  constexpr int GW = Misc<NT>::gram_waves;
+  double* scr = reinterpret_cast<double*>(scratch);         // [GW waves][3 tiles][256]
+  double* scs = scr + GW * 3 * 256;                         // [8 slices][32 columns]
+  const bool two = K > 16;
+  bar_lds();
+  if (wave < GW) {
+    auto group = [&](int g, f64x4& a00, f64x4& a01, f64x4& a11) {
+      a00 = f64x4{0, 0, 0, 0}; a01 = a00; a11 = a00;
+      for (int u0 = 4 * g; u0 < n; u0 += 16) {
+        const int u = u0 + lk;
+        const double x0 = u < n ? (double)reg[u * kS + li] : 0.0;
+        const double x1 = (u < n && two) ? (double)reg[u * kS + 16 + li] : 0.0;
+        a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, a00, 0, 0, 0);
+        if (two) {
+          a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x1, a01, 0, 0, 0);
+          a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, a11, 0, 0, 0);
+        }
+      }
+    };
+    f64x4 s00, s01, s11;
+    if constexpr (GW == 4) group(wave, s00, s01, s11);
+    else {
+      f64x4 t00, t01, t11;
+      group(GW == 2 ? 2 * wave : 0, s00, s01, s11);
+      group(GW == 2 ? 2 * wave + 1 : 1, t00, t01, t11);
+      s00 += t00; s01 += t01; s11 += t11;
+      if constexpr (GW == 1) {
+        f64x4 v00, v01, v11;
+        group(2, t00, t01, t11);
+        group(3, v00, v01, v11);
+        t00 += v00; t01 += v01; t11 += v11;
+        s00 += t00; s01 += t01; s11 += t11;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      scr[(wave * 3 + 0) * 256 + r * 64 + lane] = s00[r];
+      scr[(wave * 3 + 1) * 256 + r * 64 + lane] = s01[r];
+      scr[(wave * 3 + 2) * 256 + r * 64 + lane] = s11[r];
+    }
+  }
+  if (tid < 256) {   // column sums: 8 slices of the units, one column per lane
+    const int k = tid & 31, sl = tid >> 5;
+    double cs = 0.0;
+    for (int u = sl; u < n; u += 8) cs += (double)reg[u * kS + k];
+    scs[sl * 32 + k] = cs;
+  }
+  bar_lds();
+  for (int te = tid; te < 768; te += NT) {
+    const int tile = te >> 8, e = te & 255, r = e >> 6, ln = e & 63;
+    double s;
+    if constexpr (GW == 4) s = (scr[tile * 256 + e] + scr[(3 + tile) * 256 + e]) + (scr[(6 + tile) * 256 + e] + scr[(9 + tile) * 256 + e]);
+    else if constexpr (GW == 2) s = scr[tile * 256 + e] + scr[(3 + tile) * 256 + e];
+    else s = scr[tile * 256 + e];
+    const int a = (ln >> 4) + 4 * r + (tile == 2 ? 16 : 0), b = (ln & 15) + (tile >= 1 ? 16 : 0);    // C/D of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 reg
+    Cs[a * kS + b] = (float)s;
+    if (c64_out) c64_out[a * 32 + b] = s;
+    double pr = 0.0;
+    if (c64_dot) pr = c64_dot[a * 32 + b] * s;
+    if (tile == 1) {
+      Cs[b * kS + a] = (float)s;
+      if (c64_out) c64_out[b * 32 + a] = s;
+      if (c64_dot) pr += c64_dot[b * 32 + a] * s;
+    }
+    scr[tile * 256 + e] = pr;            // (this thread alone reads and writes entry (tile, e))
+  }
+  if (tid >= NT - 32) {
+    const int k = tid - (NT - 32);
+    double s = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) s += scs[sl * 32 + k];
+    colsum[k] = s;
+  }
+  bar_lds();
+  double dot = 0.0;
+  if (c64_dot && tid < 64) {
+#pragma unroll 4
+    for (int j = 0; j < 12; ++j) dot += scr[tid + 64 * j];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) dot += __shfl_xor(dot, m, 64);
+    if (tid != 0) dot = 0.0;
+  }
+  bar_lds();
+  return dot;
+}
+
+// The masked contraction with the K x K term and the epilogue: regOwn[u][k] = tau (sum_r big[r][u] Xo[r][k] - sum_l X[u][l] C[l][k]) - lambda[u][k].
+// An item = 16 UW units x 16 columns: lane (i = lane & 15, kk = lane >> 4) loads UW consecutive units of inner row r0 + kk
+// (A fragments of UW MFMAs: MFMA t covers the units u0 + UW i + t) and one B element Xo[r0 + kk][k0 + i] from LDS.  R~ comes
+// from L2 (a microsecond away): the loads of the next NB steps are in flight while the MFMAs of the current NB run; `big` has
+// round_up(m, 32) rows, the ones behind m zero.
+template <int UW, int NT>
+__device__ __forceinline__ void small_contract(const SmallDirDev& d, const float* regO, const float* CsO, float* regOwn, float tau, int K,
+                                               float* PT, int tid) {
+  constexpr int NB = UW == 4 ? 4 : 8;
+  auto load_units = [](const float* p, float (&av)[UW]) {
+    if constexpr (UW == 4) { const f32x4 t = *G(reinterpret_cast<const f32x4*>(p)); av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w; }
+    else if constexpr (UW == 2) { const f32x2n t = *G(reinterpret_cast<const f32x2n*>(p)); av[0] = t.x; av[1] = t.y; }
+    else av[0] = *G(p);
+  };
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int kt = (K + 15) >> 4, ub = (d.n + 16 * UW - 1) / (16 * UW), items = ub * kt;
+  // batches of NB inner steps (4 rows each): nb_big of R~ (its rows behind m are zero), then the K x K term's: A = X^T (rows
+  // behind K zero), B = -C
+  const int nb_big = ((d.m + 31) & ~31) / (4 * NB), nb = nb_big + (K + 4 * NB - 1) / (4 * NB);
+  for (int item = wave; item < items; item += NT / 64) {
+    const int u0 = (item / kt) * 16 * UW, k0 = (item % kt) * 16;
+    f32x4 acc[UW], pacc[UW];
+#pragma unroll
+    for (int t = 0; t < UW; ++t) acc[t] = pacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* ap = d.big + u0 + UW * li + (size_t)lk * d.ldb;
+    const float* xp = d.XT + u0 + UW * li + (size_t)lk * d.ldn;
+    auto load_batch = [&](int bi, float (&dst)[NB][UW]) {
+      const float* src = bi < nb_big ? ap + (size_t)(bi * 4 * NB) * d.ldb : xp + (size_t)((bi - nb_big) * 4 * NB) * d.ldn;
+      const int ld = bi < nb_big ? d.ldb : d.ldn;
+#pragma unroll
+      for (int s = 0; s < NB; ++s) load_units(src + (size_t)(4 * s) * ld, dst[s]);
+    };
+    float cur[NB][UW], nxt[NB][UW];
+    load_batch(0, cur);
+    for (int bi = 0; bi < nb; ++bi) {
+      if (bi + 1 < nb) load_batch(bi + 1, nxt);
+      if (bi == nb_big) {
+#pragma unroll
+        for (int t = 0; t < UW; ++t) pacc[t] = acc[t];
+      }
+      const bool big = bi < nb_big;
+      const int r0 = (big ? bi : bi - nb_big) * 4 * NB + lk;
+#pragma unroll
+      for (int s = 0; s < NB; ++s) {
+        const int r = r0 + 4 * s;
+        const float b = big ? regO[min(r, d.m) * kS + k0 + li] : -CsO[r * kS + k0 + li];      // rows >= m of the factor: its zero row
+#pragma unroll
+        for (int t = 0; t < UW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[s][t], b, acc[t], 0, 0, 0);
+      }
+#pragma unroll
+      for (int s = 0; s < NB; ++s)
+#pragma unroll
+        for (int t = 0; t < UW; ++t) cur[s][t] = nxt[s][t];
+    }
+    // C/D of the 16x16 f32 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg
+    const int k = k0 + li;
+#pragma unroll
+    for (int t = 0; t < UW; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int u = u0 + UW * (4 * lk + r) + t;
+        if (u < d.n && k < K) {
+          regOwn[u * kS + k] = fmaf(tau, acc[t][r], -*G(d.lambda + u * 32 + k));
+          if (PT) *G(PT + (size_t)k * d.ldn + u) = pacc[t][r];
+        }
+      }
+  }
+}
+
+template <int EM, int NT>
+__global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __restrict__ all) {
+  extern __shared__ float lds[];
+  const SmallLaunch& L = all[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int I = L.rows.n, J = L.cols.n, K = L.K;
+  float* regR = lds;
+  float* regC = regR + (I + 1) * kS;
+  float* CsR = regC + (J + 1) * kS;
+  float* CsC = CsR + 32 * kS;
+  float* misc = lds + small_misc_offset(I, J);
+  typedef Misc<NT> MS;
+  float2* part = reinterpret_cast<float2*>(misc + MS::part);
+  float* numer_s = misc + MS::numer; float* taup_s = misc + MS::taup; float* xk_s = misc + MS::xk;
+  float* dl = misc + MS::dl; float* xnw = misc + MS::xnw;
+  uint16_t* lists = reinterpret_cast<uint16_t*>(misc + MS::list);
+  int* cnt = reinterpret_cast<int*>(misc + MS::cnt);
+  double* red = reinterpret_cast<double*>(misc + MS::red);
+  float* tau_s = misc + MS::tau;
+  double* c64R = reinterpret_cast<double*>(misc + MS::c64);
+  double* csum = reinterpret_cast<double*>(misc + MS::colsum);
+  float* gscr = misc + MS::part;
+
+  // ---- the state into LDS: both factors (zero pads, zero row behind the last), the transposed copies the column loop reads
+  for (int t = tid; t < (I + 1) * kS; t += NT) { const int u = t / kS, k = t - u * kS; regR[t] = (u < I && k < K) ? L.rows.X[u * 32 + k] : 0.f; }
+  for (int t = tid; t < (J + 1) * kS; t += NT) { const int u = t / kS, k = t - u * kS; regC[t] = (u < J && k < K) ? L.cols.X[u * 32 + k] : 0.f; }
+  for (int t = tid; t < 2 * 32 * kS; t += NT) CsR[t] = 0.f;
+  for (int t = tid; t < I * K; t += NT) { const int u = t % I, k = t / I; L.rows.XT[(size_t)k * L.rows.ldn + u] = L.rows.X[u * 32 + k]; }
+  for (int t = tid; t < J * K; t += NT) { const int u = t % J, k = t / J; L.cols.XT[(size_t)k * L.cols.ldn + u] = L.cols.X[u * 32 + k]; }
+  if (tid < 4) cnt[tid] = 0;
+  if (tid == 0) { *tau_s = *L.tau_f; L.clock[0] = wall_clock64(); }
+  bar_all();
+  small_gram<NT>(regR, I, K, gscr, CsR, csum, c64R, nullptr, tid);
+  small_gram<NT>(regC, J, K, gscr, CsC, csum + 32, nullptr, nullptr, tid);
+
+  int rr = 0;                                // running retry-round number: list rr % 3 is the one being filled / read
+  const bool draw = L.update == BNMTF_UPDATE_DRAW;
+#ifdef BNMTF_SMALL_TIMING
+  unsigned long long ph[16] = {0}, tlast = __builtin_readcyclecounter();
+  int nretry = 0;
+#endif
+
+  for (int it = 0; it < L.n_iter; ++it) {
+    const unsigned long long it_abs = L.it0 + (unsigned long long)it;
+    const uint32_t it32 = (uint32_t)it_abs;
+    double st_px = 0.0, st_q = 0.0, st_q2 = 0.0, st_dot = 0.0;       // statistics of the cols sweep (this thread's share)
+
+#pragma unroll 1
+    for (int dir = 0; dir < 2; ++dir) {
+      // (an opaque copy of the thread index per half sweep: the address arithmetic of this phase is not hoisted out of the
+      // iteration loop, where it would sit in ~45 registers across every other phase)
+      int tq = tid;
+      asm volatile("" : "+v"(tq));
+      const int lane = tq & 63;
+      const SmallDirDev d = dir == 0 ? L.rows : L.cols;
+      const float* oq = dir == 0 ? L.cols.q : L.rows.q;
+      float* regOwn = dir == 0 ? regR : regC;
+      const float* regO = dir == 0 ? regC : regR;
+      const float* CsO = dir == 0 ? CsC : CsR;
+      const uint32_t stream = dir == 0 ? kStreamRows : kStreamCols;
+      const float tau = *tau_s;
+      const int n = d.n, m = d.m, em = d.em;
+      const bool entry = tq < d.nthreads, unit = tq < n;
+
+      // ---- the Philox words of the first nc0 candidates of every (unit, column) of this half sweep, by all threads at once
+      // (they depend on the counters only; inside the column loop a Philox call is ~800 cycles of a wave on the critical path)
+      constexpr int nc0 = 1;
+      u32x2n* tab = reinterpret_cast<u32x2n*>(d.tab);
+      if (draw)
+        for (int e = tq; e < K * nc0 * d.ldn; e += NT) {
+          const int u = e % d.ldn, kc = e / d.ldn;
+          if (u < n) {
+            const U4 r = philox4x32_10((uint32_t)u, (uint32_t)(kc / nc0), it32, stream + 16u * (uint32_t)(kc % nc0), L.key0, L.key1);
+            *G(tab + e) = u32x2n{r.x, r.y};
+          }
+        }
+      STAMP(0);
+      // ---- contraction: regOwn = G (nothing of the sweep's per-thread state is live yet: the operand pipeline has the registers)
+      {
+        const int kt = (K + 15) >> 4;
+        float* PT = dir == 1 ? L.PT : nullptr;
+        if (((n + 63) / 64) * kt >= NT / 64) small_contract<4, NT>(d, regO, CsO, regOwn, tau, K, PT, tq);
+        else if (((n + 31) / 32) * kt >= (3 * NT) / 256) small_contract<2, NT>(d, regO, CsO, regOwn, tau, K, PT, tq);
+        else small_contract<1, NT>(d, regO, CsO, regOwn, tau, K, PT, tq);
+      }
+      bar_all();                               // (PT is read by other threads than the ones that stored it)
+      STAMP(1);
+
+      // ---- this thread's slots, and q of its entries: handed over by the other direction's sweep, or -- every `refresh`-th
+      // iteration in the rows sweep -- rebuilt from the factors (the own one as it was: its transposed copy in L2)
+      uint32_t jj[EM / 2];
+      float q[EM], vp[EM];
+      int myunit = 0;
+      if (entry) myunit = *G(d.unit_of + tq);
+#pragma unroll
+      for (int h = 0; h < EM / 2; ++h) {
+        uint32_t j0 = (uint32_t)m, j1 = (uint32_t)m;
+        if (entry && 2 * h < em) { j0 = *G(d.idx + (2 * h) * kSmallThreads + tq); j1 = *G(d.idx + (2 * h + 1) * kSmallThreads + tq); }
+        jj[h] = j0 | (j1 << 16);
+        q[2 * h] = q[2 * h + 1] = 0.f; vp[2 * h] = vp[2 * h + 1] = 0.f;
+      }
+      const bool prepass = dir == 0 && (it_abs % L.refresh == 0 || (it == 0 && !L.q_valid));
+      if (prepass) {
+        if (entry)
+          for (int k = 0; k < K; ++k) {
+            const float xv = *G(d.XT + (size_t)k * d.ldn + myunit);
+#pragma unroll
+            for (int h = 0; h < EM / 2; ++h)
+              if (2 * h < em) {
+                q[2 * h] = fmaf(xv, regO[(jj[h] & 0xFFFFu) * kS + k], q[2 * h]);
+                q[2 * h + 1] = fmaf(xv, regO[(jj[h] >> 16) * kS + k], q[2 * h + 1]);
+              }
+          }
+      } else if (entry) {
+#pragma unroll
+        for (int e = 0; e < EM; ++e)
+          if (e < em) {
+            const uint32_t p = *G(d.perm + e * kSmallThreads + tq);
+            q[e] = p != kSmallNone ? *G(oq + p) : 0.f;
+          }
+      }
+
+      STAMP(2);
+      // ---- the K sequential columns
+      // (candidate role: thread (cc, cu) takes candidate cc < nc0 of unit cu's draw; with nc0 = 1 that is the unit's own thread)
+      const int T = d.ldn;
+      const int cc = tq / T, cu = tq - cc * T;
+      const bool cand_on = draw && cc < nc0 && cu < n;
+      int seg0 = 0, segn = 0;
+      float xk_n = 0.f, pv_n = 0.f;             // column k + 1's old value and Pv, on their way from L2 during column k
+      u32x2n cw_n = {0u, 0u};                   // ... and this thread's candidate words
+      if (unit) {
+        seg0 = *G(d.seg + 2 * tq); segn = *G(d.seg + 2 * tq + 1);
+        xk_n = *G(d.XT + tq);
+        if (dir == 1) pv_n = *G(L.PT + tq);
+      }
+      if (cand_on) cw_n = *G(tab + (size_t)cc * T + cu);
+#pragma unroll 1
+      for (int k = 0; k < K; ++k) {
+        if (entry) {
+          const float dlt = k > 0 ? dl[myunit] : 0.f;
+          float qv = 0.f, vv = 0.f;
+          const float* col = regO + k;
+#pragma unroll
+          for (int h = 0; h < EM / 2; ++h)
+            if (2 * h < em) {
+              q[2 * h] = fmaf(dlt, vp[2 * h], q[2 * h]);
+              q[2 * h + 1] = fmaf(dlt, vp[2 * h + 1], q[2 * h + 1]);
+              const float v0 = col[(jj[h] & 0xFFFFu) * kS], v1 = col[(jj[h] >> 16) * kS];
+              vp[2 * h] = v0; vp[2 * h + 1] = v1;
+              qv = fmaf(q[2 * h], v0, qv); vv = fmaf(v0, v0, vv);
+              qv = fmaf(q[2 * h + 1], v1, qv); vv = fmaf(v1, v1, vv);
+            }
+          part[tq] = float2{qv, vv};
+        }
+        // what does not wait for the partial sums: this column's prefetched operands into place, the next column's on their way,
+        // the candidate's word-only half (log, sqrt, cos)
+        const float xk = xk_n, pv = pv_n;
+        float gk = 0.f, ckk = 0.f;
+        TnCand cand = {0.f, 0.f, 0.f};
+        if (cand_on) cand = tn_cand_pre(cw_n.x, cw_n.y);
+        if (k + 1 < K) {
+          if (unit) {
+            xk_n = *G(d.XT + (size_t)(k + 1) * T + tq);
+            if (dir == 1) pv_n = *G(L.PT + (size_t)(k + 1) * T + tq);
+          }
+          if (cand_on) cw_n = *G(tab + ((size_t)(k + 1) * nc0 + cc) * T + cu);
+        }
+        if (unit) { gk = regOwn[tq * kS + k]; ckk = CsO[k * kS + k]; }
+        STAMP(3);
+        bar_lds();
+        STAMP(4);
+        bool done = true;
+        float xnew = 0.f;
+        if (unit) {
+          float qv = 0.f, vv = 0.f;
+          for (int g = seg0; g < seg0 + segn; ++g) { const float2 p = part[g]; qv += p.x; vv += p.y; }
+          const float corr = fmaf(-xk, vv, qv);
+          const float tau_p = tau * (ckk - vv);
+          const float numer = fmaf(tau, fmaf(xk, ckk, corr), gk);
+          if (draw) {
+            // candidate 0 (its Philox words made in bulk, its word-only half before the barrier): accepted by ~3 draws in 4
+            const TnFast tf = tn_fast_params(numer, tau_p);
+            float xc;
+            const bool acc = tn_cand_post(tf, cand, &xc);
+            if (!tf.live) xnew = 0.f;                          // (a dead conditional draws 0: oracle/rng.py)
+            else if (acc) xnew = tn_guard(xc);
+            else {
+              done = false;
+              numer_s[tq] = numer; taup_s[tq] = tau_p; xk_s[tq] = xk;
+              const int pos = atomicAdd(&cnt[rr % 3], 1);
+              lists[(rr % 3) * NT + pos] = (uint16_t)tq;
+            }
+            if (done) dl[tq] = xnew - xk;
+          } else {
+            const float mu = numer / tau_p;
+            xnew = fmaxf((tau_p > 0.f && mu > 0.f) ? mu : 0.f, L.min_x);
+            dl[tq] = xnew - xk;
+          }
+        }
+        bar_lds();
+        STAMP(5);
+        if (draw) {
+          // ---- retry rounds: the units that rejected candidate 0 get their next W candidates evaluated at once, by as many waves
+          // as that takes (a Philox call is ~740 cycles of a SIMD: speculative candidates are not free)
+          uint32_t c0 = (uint32_t)nc0;
+          for (;;) {
+            const int cur = rr % 3, nxt = (rr + 1) % 3;
+            const int nrej = cnt[cur];
+            if (nrej == 0) break;
+            int W = NT / nrej;
+            W = W >= 4 ? 4 : (W >= 2 ? 2 : 1);
+            if ((tq & ~63) < nrej * W) {
+              const int li = tq / W, c = tq & (W - 1);
+              const bool active = li < nrej;
+              const int u = active ? (int)lists[cur * NT + li] : 0;
+              const TnFast tf = tn_fast_params(numer_s[u], taup_s[u]);
+              const U4 r = philox4x32_10((uint32_t)u, (uint32_t)k, it32, stream + 16u * (c0 + (uint32_t)c), L.key0, L.key1);
+              float xc;
+              const bool acc = tn_eval_fast(tf, r.x, r.y, &xc) && active;
+              const unsigned long long mask = __ballot(acc);
+              const int gbase = lane & ~(W - 1);
+              const unsigned long long gm = (mask >> gbase) & ((1ull << W) - 1ull);
+              const int src = gm ? gbase + __ffsll((long long)gm) - 1 : lane;
+              const float xsel = __shfl(xc, src, 64);
+              if (active && c == 0) {
+                if (gm) { const float xn = tn_guard(xsel); dl[u] = xn - xk_s[u]; xnw[u] = xn; }
+                else if (c0 + (uint32_t)W >= 4096u) { dl[u] = -xk_s[u]; xnw[u] = 0.f; }
+                else { const int pos = atomicAdd(&cnt[nxt], 1); lists[nxt * NT + pos] = (uint16_t)u; }
+              }
+            }
+            if (tq == 0) cnt[(rr + 2) % 3] = 0;
+            c0 += (uint32_t)W;
+            ++rr;
+            bar_lds();
+#ifdef BNMTF_SMALL_TIMING
+            ++nretry;
+#endif
+          }
+          STAMP(8);
+        }
+        // ---- the unit's thread: the new value into the factor's region, delta into the columns still to come
+        if (unit) {
+          if (!done) xnew = xnw[tq];
+          const float delta = xnew - xk;
+          *G(d.XT + (size_t)k * T + tq) = xnew;
+          regOwn[tq * kS + k] = xnew;
+          if (dir == 1) st_px += (double)pv * (double)xnew;
+          const float t = tau * delta;
+          for (int k2 = k + 1; k2 < K; k2 += 8) {
+            float g8[8], c8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int kk = min(k2 + j, 31); g8[j] = regOwn[tq * kS + kk]; c8[j] = CsO[k * kS + kk]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (k2 + j < K) regOwn[tq * kS + k2 + j] = fmaf(-t, c8[j], g8[j]);
+          }
+        }
+        STAMP(9);
+      }
+      // ---- the last column's update of q; q goes where the other direction finds it
+      if (entry) {
+        const float dlt = dl[myunit];
+#pragma unroll
+        for (int e = 0; e < EM; ++e)
+          if (e < em) {
+            q[e] = fmaf(dlt, vp[e], q[e]);
+            *G(d.q + e * kSmallThreads + tq) = q[e];
+            if (dir == 1) { st_q += (double)q[e]; st_q2 += (double)q[e] * (double)q[e]; }
+          }
+      }
+      bar_all();                               // q and the transposed factor: read by other threads in the next half sweeps
+      STAMP(10);
+      // ---- Gram of the new factor; state, sample, posterior sums
+      if (dir == 0) small_gram<NT>(regOwn, n, K, gscr, CsR, csum, c64R, nullptr, tq);
+      else st_dot = small_gram<NT>(regOwn, n, K, gscr, CsC, csum + 32, nullptr, c64R, tq);
+      if (tq < 4) cnt[tq] = 0;                 // (no list is in flight here; rr keeps counting)
+      STAMP(11);
+      {
+        float* smp = dir == 0 ? L.U_s : L.V_s;
+        double* ex = dir == 0 ? L.expR : L.expC;
+        const bool add = ex && L.exp_burn >= 0 && it >= L.exp_burn && (it - L.exp_burn) % L.exp_thin == 0;
+        for (int t = tq; t < n * K; t += NT) {
+          const int u = t / K, k = t - u * K;
+          const float v = regOwn[u * kS + k];
+          *G(d.X + u * 32 + k) = v;
+          if (smp) *G(smp + ((size_t)it * n + u) * K + k) = v;
+          if (add) *G(ex + u * 32 + k) += (double)v;
+        }
+      }
+      bar_lds();
+      STAMP(12);
+    }
+
+    // ---- end of the iteration (kernel_misc.hip finish_kernel): SSE from the Gram identities, tau, the three metrics
+    {
+      int tf_ = tid;
+      asm volatile("" : "+v"(tf_));
+      double v[4] = {st_dot, st_px, st_q, st_q2};
+      block_sum4<NT>(v, red, tf_);
+      if (tf_ == 0) {
+        double sp1 = 0.0;
+        for (int k = 0; k < K; ++k) sp1 += csum[k] * csum[32 + k];
+        const double srp = v[1], sp = sp1 - v[2], spp = v[0] - v[3];
+        const double nobs = L.n_obs;
+        const double sse = L.sumR2 - 2.0 * srp + spp;
+        const double alpha_s = L.alpha + 0.5 * nobs, beta_s = L.beta + 0.5 * sse;
+        double tau;
+        if (L.update == BNMTF_UPDATE_ICM) tau = (alpha_s - 1.0) / beta_s;
+        else if (L.update != BNMTF_UPDATE_DRAW) tau = alpha_s / beta_s;
+        else tau = *G(L.gunit + it) / beta_s;
+        *G(L.tau_d) = tau; *G(L.tau_f) = (float)tau; *tau_s = (float)tau;
+        const double ss_tot = L.sumR2 - L.sumR * L.sumR / nobs;
+        const double cov = srp - L.sumR * sp / nobs;
+        const double vpred = spp - sp * sp / nobs;
+        auto* rec = G(L.rec + (size_t)it * 5);
+        rec[0] = tau;
+        rec[1] = sse / nobs;
+        rec[2] = ss_tot != 0.0 ? 1.0 - sse / ss_tot : __longlong_as_double(0x7ff0000000000000LL);
+        rec[3] = cov / (sqrt(ss_tot) * sqrt(vpred));
+        rec[4] = sse;
+        if (L.exp_tau && L.exp_burn >= 0 && it >= L.exp_burn && (it - L.exp_burn) % L.exp_thin == 0) *G(L.exp_tau) += tau;
+        *G(L.clock + it + 1) = wall_clock64();
+      }
+      bar_lds();
+      STAMP(13);
+    }
+  }
+#ifdef BNMTF_SMALL_TIMING
+  if (blockIdx.x == 0 && (tid == 0 || tid == NT - 64))
+    printf("small kernel thread %d, %d iterations, cycles per iteration: table %llu contract %llu qinit %llu | columns: entry+prefetch %llu bar %llu unit %llu cand %llu pick %llu retry %llu (%d rounds) fixup %llu | qstore %llu gram %llu copy %llu finish %llu\n",
+           tid, L.n_iter, ph[0] / L.n_iter, ph[1] / L.n_iter, ph[2] / L.n_iter, ph[3] / L.n_iter, ph[4] / L.n_iter, ph[5] / L.n_iter, ph[6] / L.n_iter, ph[7] / L.n_iter,
+           ph[8] / L.n_iter, nretry, ph[9] / L.n_iter, ph[10] / L.n_iter, ph[11] / L.n_iter, ph[12] / L.n_iter, ph[13] / L.n_iter);
+#endif
+}
+
+template <int EM, int NT>
+static void launch_small_inst(const SmallLaunch* dev_launches, int n_models, size_t lds_bytes, hipStream_t st) {
+  static std::atomic<uint64_t> ok{0};
+  if (allow_full_lds((const void*)small_gibbs_kernel<EM, NT>, ok)) hipLaunchKernelGGL((small_gibbs_kernel<EM, NT>), dim3(n_models), dim3(NT), lds_bytes, st, dev_launches);
+}
+template <int EM>
+static void launch_small_em(const SmallLaunch* dev_launches, int n_models, int nt, size_t lds_bytes, hipStream_t st) {
+  if (nt <= 256) launch_small_inst<EM, 256>(dev_launches, n_models, lds_bytes, st);
+  else if (nt <= 512) launch_small_inst<EM, 512>(dev_launches, n_models, lds_bytes, st);
+  else launch_small_inst<EM, 1024>(dev_launches, n_models, lds_bytes, st);
+}
+// em: slots per entry thread (8 / 16 / 32), nt: threads per block (256 / 512 / 1024) -- the largest any model of the batch needs
+void launch_small_gibbs(const SmallLaunch* dev_launches, int n_models, int em, int nt, size_t lds_bytes, hipStream_t st) {
+  if (n_models <= 0) return;
+  if (em <= 8) launch_small_em<8>(dev_launches, n_models, nt, lds_bytes, st);
+  else if (em <= 16) launch_small_em<16>(dev_launches, n_models, nt, lds_bytes, st);
+  else launch_small_em<32>(dev_launches, n_models, nt, lds_bytes, st);
+}
+
+}  // namespace bnmtf

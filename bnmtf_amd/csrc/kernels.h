@@ -340,6 +340,55 @@ struct TriFactorArgs { int which, side, rows, K, L; const float* X; const float*
 void launch_tri_factors(const TriFactorArgs& a, hipStream_t st);
 void launch_tri_vb_finish(const double* sums, double alpha, double beta, double* tau_d, float* tau_f, double* rec, hipStream_t st);
 
+// ---------------------------------------------------------------------------
+// small models (kernel_small.hip): the WHOLE run(n) of a BNMF Gibbs model in one launch, one 16-wave block per model --
+// both factors, the Gram matrices and every per-column exchange in the CU's LDS, q of the missing entries in registers,
+// R~ streamed from L2 by the block's own f32 MFMA contraction; grid = number of models (the folds / ranks / restarts of a
+// model search: code/cross_validation/line_search_cross_validation.py:54-131 run them one after the other).  Same
+// conditionals, same Philox keying and candidate sequence as the large path (bnmf_gibbs_optimised.py:133-155, :167-177).
+// ---------------------------------------------------------------------------
+constexpr int kSmallThreads = 1024;     // threads of the largest block (16 waves = one CU); row stride of the slot tables.  Smaller models run 256- or 512-thread blocks, several to a CU
+constexpr int kSmallStride = 33;        // floats per factor row in LDS (odd: a column gather and a row read are both conflict-free)
+constexpr int kSmallKP = 32;            // K <= 32
+constexpr int kSmallMaxSlots = 32;      // missing entries per entry thread (slot classes 8 / 16 / 32)
+constexpr uint32_t kSmallNone = 0xFFFFFFFFu;
+struct SmallDirDev {
+  int n, m;                    // units (rows of this direction's factor), inner extent
+  int ldb, ldn;                // leading dimensions: big [round_up(m, 4)][ldb], XT / PT [32][ldn]  (multiples of 64)
+  int nthreads, em;            // entry threads in use; slots per entry thread
+  const float* big;            // masked R, unit index contiguous (rows: big[j][i], cols: big[i][j])
+  const float* lambda;         // [n][32] prior rates, zero padded
+  const uint16_t* idx;         // [em][1024] inner index of slot e of entry thread t (m: empty -> the zero row)
+  const uint16_t* unit_of;     // [1024] unit of entry thread t
+  const uint16_t* seg;         // [n][2] first entry thread and number of entry threads of unit u
+  const uint32_t* perm;        // [em][1024] where the OTHER direction keeps this slot's q (e' * 1024 + t'), kSmallNone: empty
+  float* X;                    // state [n][32] row major
+  float* XT;                   // [32][ldn] the same transposed (column k's old values, coalesced over the units)
+  float* q;                    // [em][1024] q of the missing entries as this direction's sweep left them
+  uint2* tab;                  // [K nc0][ldn] Philox words of the first nc0 candidates of every (unit, column) of a half sweep (nc0 <= 8, nc0 ldn <= 1024)
+  double* C64;                 // [32][32] Gram of X
+  double* colsum;              // [32]
+};
+struct SmallLaunch {
+  SmallDirDev rows, cols;
+  float* PT;                   // [32][cols.ldn] Pv = R~^T U of the cols contraction (for sum_Omega R.Rp)
+  int K;
+  double n_obs, sumR, sumR2, alpha, beta;
+  double* tau_d; float* tau_f;
+  // this call
+  int n_iter, update; float min_x;
+  uint32_t key0, key1; unsigned long long it0;
+  int q_valid;                 // cols.q holds q of the current state (left there by the previous call)
+  uint32_t refresh;            // the rows sweep rebuilds q from the factors when iteration % refresh == 0
+  const double* gunit;         // [n_iter] Gamma(alpha_s, 1) variates (draws)
+  double* rec;                 // [n_iter][5] tau, MSE, R^2, Rp, SSE
+  unsigned long long* clock;   // [n_iter + 1] wall_clock64 at the start and after every iteration
+  float* U_s; float* V_s;      // samples [n_iter][n][K], or null
+  double* expR; double* expC; double* exp_tau; int exp_burn, exp_thin;   // posterior sums (bnmtf_set_expectation), or null / -1
+};
+size_t small_lds_bytes(int I, int J, int nt);  // LDS a block of nt threads needs for an I x J model
+void launch_small_gibbs(const SmallLaunch* dev_launches, int n_models, int em, int nt, size_t lds_bytes, hipStream_t st);
+
 // small helpers
 void launch_sum_stats(const double* stats, int nblocks, double* acc, hipStream_t st);   // acc[0..2] += column sums of stats
 void launch_sum_cols(const double* stats, int nrows, int ld, int ncols, double* out, hipStream_t st);        // out[c] += column sums, ncols <= 8

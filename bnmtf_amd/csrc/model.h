@@ -96,6 +96,21 @@ struct Dir {
 
 struct Comm;   // RCCL wrapper (comm.cpp)
 
+// A model small enough for the one-launch path (kernel_small.hip, api_small.inc): ONE device allocation holds its static tables
+// (both masked operands, slot / segment / permutation tables, prior rates) and its state (factors, q of the missing entries,
+// Gram matrices); `dev` is the launch descriptor with the per-call fields blank.
+struct SmallModel {
+  char* arena = nullptr; size_t arena_bytes = 0;
+  SmallLaunch dev;
+  int em = 8, nt = 1024;             // slot class (max over the two directions) and threads per block of the launch
+  size_t lds_bytes = 0;
+  bool q_valid = false;              // cols.q holds q of the current state (hand-over from call to call)
+  // per-call buffers, grown on demand: [gunit | rec | clock] and the samples
+  char* call_buf = nullptr; size_t call_cap = 0;
+  float* smp = nullptr; size_t smp_cap = 0;
+  SmallLaunch* dev_launch = nullptr;  // device copy of the descriptor (single-model calls)
+};
+
 }  // namespace bnmtf
 
 struct bnmtf_model {
@@ -119,6 +134,11 @@ struct bnmtf_model {
   double *A2d = nullptr, *B2d = nullptr, *vb_rec = nullptr; size_t vb_rec_cap = 0;
   double* vbred = nullptr;               // VB over several GPUs: the 20 sums exchanged per iteration
   bool use_fast = true, last_sweep_fast = false;   // fast sweep kernel when the shape allows it
+  // the one-launch path for small models (api_small.inc): its arena; whether the multi-launch path's structures exist yet (they
+  // are built on first need for a model that starts small); which of the two holds the current state
+  bnmtf::SmallModel* small = nullptr;
+  bool small_enabled = true, std_built = true, small_cur = false, std_cur = false;
+  std::vector<double> lam_rows, lam_cols;          // prior rates as given (build_standard may run after bnmtf_create has returned)
   // BNMTF extras
   float* S = nullptr;            // [K][L] on device (row major, unpadded)
   bnmtf::Dir reff, ceff;         // effective factors U_eff = F S (I x L), V_eff = G S^T (J x K): factor storage only

@@ -130,6 +130,15 @@ int bnmtf_beta_s(bnmtf_handle h, double* out);
 int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* V_out,
                    double* tau_out, double* perf_out, double* times_out);
 
+/* The same call for n_models independent models at once -- the folds x ranks x restarts a model search fits one after the
+ * other (code/cross_validation/line_search_cross_validation.py:54-131, line_search_bnmf.py:53-76,
+ * parallel_matrix_cross_validation.py:40-74).  Models on the one-launch path (small models: DESIGN.md section 4,
+ * kernel_small.hip -- one block per model, the whole run in one launch) that share a device go down in ONE grid; any other
+ * handle in the list is run by bnmf_gibbs_run in turn.  Every model draws exactly the chain its own bnmf_gibbs_run call
+ * would draw.  The output arrays are arrays of n_models pointers (or NULL), each as in bnmf_gibbs_run. */
+int bnmf_gibbs_run_many(const bnmtf_handle* hs, int n_models, int n_iter, int update, float* const* U_outs, float* const* V_outs,
+                        double* const* tau_outs, double* const* perf_outs, double* const* times_outs);
+
 /* ---- BNMTF Gibbs (bnmtf_gibbs_optimised.py) ---------------------------- */
 int bnmtf_set_state(bnmtf_handle h, const double* F, const double* S, const double* G, double tau);
 int bnmtf_get_state(bnmtf_handle h, double* F, double* S, double* G, double* tau);
@@ -231,6 +240,11 @@ int bnmtf_set_minimum_tn(bnmtf_handle h, double minimum_TN);
 /* sweep kernel selection: 1 (default) = register/LDS-resident fast path when the shape
  * fits, 0 = always the generic kernel (any mask, q in global memory).  Same results. */
 int bnmtf_set_sweep_path(bnmtf_handle h, int fast);
+/* the one-launch path for small BNMF models (K <= 32, I, J <= 1024, factors within one CU's LDS; run() = one launch):
+ * on = 0 sends this handle's runs down the multi-launch path instead (tests, A/B).  Default 1.  Same chain either way up to
+ * fp32 summation order.  bnmtf_is_small: would the next bnmf_gibbs_run of this handle take it? */
+int bnmtf_set_small_path(bnmtf_handle h, int on);
+int bnmtf_is_small(bnmtf_handle h, int* out);
 int bnmtf_kernel_stats(bnmtf_handle h, int kernel, double* total_ms, uint64_t* launches);
 /* geometry of the last create: padded shapes, split factor, slot counts (for DESIGN/bench) */
 int bnmtf_describe(bnmtf_handle h, char* buf, size_t buflen);

@@ -103,7 +103,14 @@ def test_postrun_api_matches_reference(golden, name):
     assert str(e.value) == "Unrecognised metric for model quality: FAIL."
 
 
-@pytest.mark.parametrize("fast", [True, False])
+def _set_path(b, path):
+    """small: the one-launch kernel (kernel_small.hip); chip: the multi-launch path with the on-chip sweep; generic: with the generic sweep"""
+    b.set_small_path(path == "small")
+    b.set_sweep_path(path != "generic")
+    assert b.is_small() == (path == "small")
+
+
+@pytest.mark.parametrize("fast", ["small", "chip", "generic"])
 @pytest.mark.parametrize("name", ["toy", "r37x29", "r40x33"])
 def test_mode_update_trajectory_matches_oracle(golden, name, fast):
     """Deterministic end-to-end parity: with every draw replaced by the mode
@@ -116,7 +123,7 @@ def test_mode_update_trajectory_matches_oracle(golden, name, fast):
     o.run(8, draw=False)
     b = bnmf_gibbs_optimised(c["R"], c["M"], int(c["K"]), _pri(c), verbose=False)
     b.U, b.V, b.tau = c["U"].copy(), c["V"].copy(), float(c["tau"])
-    b.set_sweep_path(fast)
+    _set_path(b, fast)
     b.run(8, update='mode')
     np.testing.assert_allclose(b.all_performances['MSE'], o.all_performances['MSE'], rtol=2e-4)
     np.testing.assert_allclose(b.all_tau, o.all_tau, rtol=2e-4)
@@ -127,7 +134,7 @@ def test_mode_update_trajectory_matches_oracle(golden, name, fast):
     assert np.allclose(b.U, b.all_U[-1]) and np.allclose(b.V, b.all_V[-1]) and abs(b.tau - b.all_tau[-1]) < 1e-12
 
 
-@pytest.mark.parametrize("fast", [True, False])
+@pytest.mark.parametrize("fast", ["small", "chip", "generic"])
 def test_gibbs_draws_follow_oracle_with_same_philox_stream(golden, fast):
     """Same seed, same counters: the device sampler reproduces the oracle's draws
     (first sweep: every element within fp32 noise unless an accept/reject decision
@@ -141,7 +148,7 @@ def test_gibbs_draws_follow_oracle_with_same_philox_stream(golden, fast):
     o.run(30)
     b = bnmf_gibbs_optimised(t["R"], t["M"], K, pri, verbose=False, seed=77)
     b.U, b.V, b.tau = g["U0_seed0"].copy(), g["V0_seed0"].copy(), float(g["tau0_seed0"])
-    b.set_sweep_path(fast)
+    _set_path(b, fast)
     b.run(30)
     d0 = np.abs(b.all_U[0] - o.all_U[0]) / (1e-3 + np.abs(o.all_U[0]))
     assert np.mean(d0 < 1e-3) > 0.99
@@ -239,6 +246,7 @@ def test_rccl_exchange_path_with_one_rank(golden, monkeypatch):
             monkeypatch.setenv("BNMTF_FORCE_COMM", "1")
         b = bnmf_gibbs_optimised(c["R"], c["M"], int(c["K"]), _pri(c), verbose=False, seed=5)
         b.U, b.V, b.tau = c["U"].copy(), c["V"].copy(), float(c["tau"])
+        b.set_small_path(False)            # (both runs on the multi-launch path: the exchange is part of that one)
         b.run(5)
         res.append((b.all_U.copy(), b.all_tau.copy(), list(b.all_performances['MSE'])))
     # the exchange path folds the per-block sums in a different order (fp64 rounding): tau agrees to ~1e-15 relative
