@@ -99,8 +99,14 @@ class ControlPlane(object):
                     conn.settimeout(5.0)
                     hello = _recv(conn)
                     (r,) = struct.unpack("<I", hello[len(_MAGIC):len(_MAGIC) + 4]) if hello.startswith(_MAGIC) and len(hello) >= len(_MAGIC) + 4 else (None,)
-                    if r is None or not (1 <= r < self.world) or r in got:
+                    if r is None or not (1 <= r < self.world):
                         conn.close(); continue
+                    if r in got:        # the rank gave up on its first attempt (its hello timed out while we were held up) and came back:
+                        try:            # the earlier socket is dead on its side -- the new one is the peer
+                            got[r].close()
+                        except OSError:
+                            pass
+                        del got[r]
                     conn.settimeout(timeout)
                     conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                     _send(conn, _MAGIC)

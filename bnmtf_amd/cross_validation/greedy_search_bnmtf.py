@@ -45,6 +45,13 @@ class GreedySearch:
                         self.all_performances[metric].append((K, L, quality[metric]))
             return [self.find_KL(search_metric, K, L)[0][2] for K, L in pairs]
 
+        if self.as_written and len(self.values_L) == 1 and len(self.values_K) > 1:
+            # the reference's NameError (greedy_search_bnmtf.py:165: `performance_new_L` is only bound inside the main loop, which a
+            # single value of L never enters) comes after the first SUCCESSFUL step along K, i.e. after models have been fitted:
+            # said here, before any is
+            import warnings
+            warnings.warn("GreedySearch(as_written=True) with a single value in values_L raises the reference's NameError at the first "
+                          "successful step along K (greedy_search_bnmtf.py:165); as_written=False walks the K edge by the symmetric rule")
         ik, il = 0, 0
         current_K, current_L = self.values_K[ik], self.values_L[il]
         performance_so_far = try_KLs([(current_K, current_L)])[0]

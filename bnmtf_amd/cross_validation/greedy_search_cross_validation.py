@@ -44,16 +44,16 @@ class GreedySearchCrossValidation(object):
         pool = self.pool or ReplicaPool(devices=[0], shared={"R": self.R})
         pool.shared.setdefault("R", self.R)
         try:
-            best_KL = []
+            best_KL, fold_lines = [], []
             for fi in range(self.folds):
                 search = GreedySearch(classifier=self.classifier, values_K=self.values_K, values_L=self.values_L, R=self.R, M=self.M,
                                       priors=self.priors, initS=self.init_S, initFG=self.init_FG, iterations=self.iterations, restarts=self.restarts,
                                       pool=pool, seed=None if self.seed is None else self.seed + 104729 * fi)
                 search.search(self.quality_metric, burn_in=burn_in, thinning=thinning, minimum_TN=minimum_TN)
-                self.fout.write("All model fits for fold %s, metric %s: %s.\n" % (fi + 1, self.quality_metric, search.all_values(metric=self.quality_metric)))
-                self.fout.flush()
                 best_KL.append(search.best_value(metric=self.quality_metric))
-                self.fout.write("Best K,L for fold %s: %s.\n" % (fi + 1, best_KL[-1]))
+                # (written below, fold by fold, each followed by its Performance line: the reference's order, greedy_search_cross_validation.py:68-100)
+                fold_lines.append("All model fits for fold %s, metric %s: %s.\n" % (fi + 1, self.quality_metric, search.all_values(metric=self.quality_metric))
+                                  + "Best K,L for fold %s: %s.\n" % (fi + 1, best_KL[-1]))
             final = pool.map(fit_model, [job for fi, (train, test) in enumerate(zip(folds_training, folds_test))
                                          for job in self._final_jobs(train, test, best_KL[fi][0], best_KL[fi][1], burn_in, thinning, minimum_TN, fi)])
         finally:
@@ -62,6 +62,7 @@ class GreedySearchCrossValidation(object):
         performances_test = {measure: [] for measure in measures}
         for fi in range(self.folds):
             performance = self._best(final[fi * self.restarts:(fi + 1) * self.restarts])
+            self.fout.write(fold_lines[fi])
             self.fout.write("Performance: %s.\n\n" % performance)
             self.fout.flush()
             for measure in measures:

@@ -228,7 +228,9 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
     d.use_wide = wide_can && wide_blocks >= 192;
     if (const char* e = getenv("BNMTF_WIDE")) d.use_wide = wide_can && atoi(e) != 0;      // 0: never, 1: whenever it can run
     d.use_turns = false;
+#ifdef BNMTF_EXPERIMENTS
     if (const char* e = getenv("BNMTF_TURNS")) d.use_turns = d.use_wide && sweep_turns_supported(d.KP, d.pw) && atoi(e) != 0;
+#endif
     d.f_npairs = d.use_wide ? wide_blocks * 16 : npairs_real;
     auto slot_of = [&](int pi) {
       if (!d.use_wide) return pi;
@@ -301,7 +303,9 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
       if (d.use_wide) d.f_nw = 16;
       // the twin shape (BNMTF_TWIN=1): the 16-wave layout run by 8-wave blocks, two to a CU (sweep_chip.inc, TW = 1)
       d.use_twin = false;
+#ifdef BNMTF_EXPERIMENTS
       if (const char* e = getenv("BNMTF_TWIN")) d.use_twin = d.use_wide && !d.use_turns && world == 1 && d.pw <= kTwinPanelStride && atoi(e) != 0;
+#endif
       if (d.use_twin) d.f_nw = 8;
       if (nch == 2) d.f_nw = 8;                       // the two-chunk variant is an 8-wave kernel
       for (int pi = 0; pi < d.f_npairs && !d.use_wide; ++pi)
@@ -455,10 +459,9 @@ struct HandoverScope {
     if (!h->ho_active || !h->ho_regions_current) h->rows.ho_filled = h->cols.ho_filled = false;
     h->ho_regions_current = false;            // (an error return out of the loop leaves them unknown)
   }
-  ~HandoverScope() {
-    h->ho_regions_current = h->ho_active && h->rows.ho_filled;
-    h->ho_active = false;
-  }
+  // the run loop has finished and its stream is drained: the regions hold q of the state the call leaves behind
+  void commit() { h->ho_regions_current = h->ho_active && h->rows.ho_filled; }
+  ~HandoverScope() { h->ho_active = false; }        // (an error return never got to commit(): the regions stay "unknown")
 };
 // ------------------------------------------------------------- step pieces
 static void enqueue_gemm(bnmtf_model* h, Dir& d, const Dir& other, int kid) {
@@ -486,6 +489,23 @@ static void enqueue_post(bnmtf_model* h, Dir& d, bool vb = false) {
 // just ahead of its first reader.  Every collective is issued on the ONE exchange stream, in the same order on all ranks.
 static int exchange_factor(bnmtf_model* h, Dir& d) {
   if (!h->comm) { enqueue_post(h, d); return BNMTF_OK; }
+  // BNMTF_EXCHANGE=serial: every collective on the compute stream, in program order, nothing overlapped -- the fall-back
+  // while the two-stream ordering below has not run on a node with several GPUs (round 3's advice; tests/test_rccl_two_process_gpu.py)
+  static const bool serial = [] { const char* e = getenv("BNMTF_EXCHANGE"); return e && !strcmp(e, "serial"); }();
+  if (serial) {
+    PostArgs g;
+    memset(&g, 0, sizeof(g));
+    g.X = d.X; g.rows = d.nglob; g.KP = d.KP; g.XT = d.XT; g.ldT = d.ldT; g.XT2 = d.XT2; g.ld2 = d.ldT;
+    g.Cpart = d.Cpart; g.spart = d.spart; g.C64 = d.C64; g.C32 = d.C32; g.colsum = d.colsum;
+    launch_post_gram_rows(g, d.n0, d.n0 + d.n, h->stream);
+    CHK(comm_allgather_factor(h->comm, d.X, d.KP, d.nglob, h->world, h->stream));
+    CHK(comm_allreduce_sum(h->comm, d.C64, 64 * 64 + 64, h->stream));
+    launch_gram_cast(d.C64, d.C32, d.KP * d.KP, h->stream);
+    g.snap = d.snap_dst; g.snapW = d.W; d.snap_dst = nullptr;
+    launch_post_layout(g, h->stream);
+    d.gram_pending = false;
+    return BNMTF_OK;
+  }
   if (!h->xchg_stream) HIPCHK(hipStreamCreateWithFlags(&h->xchg_stream, hipStreamNonBlocking));
   for (hipEvent_t* e : {&d.ev_sweep, &d.ev_gram, &d.ev_gathered, &d.ev_gram_all})
     if (!*e) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -543,8 +563,11 @@ static void enqueue_sweep(bnmtf_model* h, Dir& d, const Dir& other, SweepArgs& s
     s2.acc = nullptr;
     f.off16 = d.pair_ok ? d.f_off16 : nullptr;
     set_handover(h, d, other, f, !d.use_turns && d.nch == 1 && d.f_nw == d.ho_ppb && s.mode != kSweepVB);
+#ifdef BNMTF_EXPERIMENTS
     if (d.use_wide && d.use_turns) launch_sweep_turns(s2, f, h->stream);
-    else if (d.use_wide && !d.use_twin) launch_sweep_wide(s2, f, h->stream);
+    else
+#endif
+    if (d.use_wide && !d.use_twin) launch_sweep_wide(s2, f, h->stream);
     else launch_sweep_fast(s2, f, h->stream);
     h->last_sweep_fast = true;
     if (d.f_gen_count == 0) return;
@@ -703,7 +726,11 @@ struct SampleSink {
     next_copy = it + 1;
     HIPCHK(hipEventRecord(h->snap_ready[g], h->stream));
     HIPCHK(hipStreamWaitEvent(h->copy_stream, h->snap_ready[g], 0));
-    static const bool nocopy = getenv("BNMTF_SAMPLES_NOCOPY") != nullptr;     // measurement hook (wrong results): the hand-off without its copies
+#ifdef BNMTF_EXPERIMENT_SAMPLES_NOCOPY
+    constexpr bool nocopy = true;      // measurement build only (wrong results): the hand-off without its copies
+#else
+    constexpr bool nocopy = false;
+#endif
     for (int j = first; j <= it && !nocopy; ++j) {
       const float* slot = h->snap_dev + (size_t)(j % kDepth) * per_it;
       if (direct) {
@@ -1094,6 +1121,13 @@ int bnmtf_set_profiling(bnmtf_handle h, int enable) {
   return BNMTF_OK;
 }
 int bnmtf_set_sweep_path(bnmtf_handle h, int fast) { h->use_fast = fast != 0; h->ho_regions_current = false; return BNMTF_OK; }
+int bnmtf_has_experiments(void) {
+#ifdef BNMTF_EXPERIMENTS
+  return 1;
+#else
+  return 0;
+#endif
+}
 int bnmtf_set_small_path(bnmtf_handle h, int on) { h->small_enabled = on != 0; return BNMTF_OK; }
 int bnmtf_is_small(bnmtf_handle h, int* out) { *out = small_wanted(h) ? 1 : 0; return BNMTF_OK; }
 int bnmtf_kernel_stats(bnmtf_handle h, int kernel, double* total_ms, uint64_t* launches) {
@@ -1223,8 +1257,10 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
     if (snap_compact) sink.snapshot(it, c.X);
     if (h->comm) {
       // the three sums of the SSE identity: behind the Gram on the exchange stream (its event covers the fold above)
-      CHK(comm_allreduce_sum(h->comm, h->acc, 4, h->xchg_stream));
-      HIPCHK(hipEventRecord(c.ev_gram_all, h->xchg_stream));
+      if (h->xchg_stream) {
+        CHK(comm_allreduce_sum(h->comm, h->acc, 4, h->xchg_stream));
+        HIPCHK(hipEventRecord(c.ev_gram_all, h->xchg_stream));
+      } else CHK(comm_allreduce_sum(h->comm, h->acc, 4, h->stream));       // (BNMTF_EXCHANGE=serial)
     }
     CHK(sink.close_slot(it));
     CHK(await_gram(h, c)); CHK(await_gram(h, r));
@@ -1245,6 +1281,7 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
   HIPCHK(hipStreamSynchronize(h->stream));
   CHK(sink.finish());
   HIPCHK(hipGetLastError());
+  ho_scope.commit();
   drain_events(h);
   std::vector<double> rec((size_t)n_iter * 5);
   HIPCHK(hipMemcpy(rec.data(), h->rec, rec.size() * sizeof(double), hipMemcpyDeviceToHost));

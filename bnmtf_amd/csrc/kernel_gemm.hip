@@ -299,8 +299,12 @@ __global__ __launch_bounds__(256, (TW == 4 ? 1 : 2)) void gemm_bf16x3_kernel(Gem
 
 void launch_gemm(const GemmArgs& a, int KP, hipStream_t st) {
   dim3 grid(a.n_pad / 128, a.split), block(256);
-  const char* mode = getenv("BNMTF_GEMM");                        // "f32": the f32-MFMA kernel (kept as the cross-check of the bf16x3 products: tests/test_contraction_gpu.py); read per launch
+#ifdef BNMTF_EXPERIMENTS
+  const char* mode = getenv("BNMTF_GEMM");                        // "f32": the f32-MFMA kernel (the cross-check of the bf16x3 products: tests/test_contraction_gpu.py); read per launch
   const bool f32 = mode && !strcmp(mode, "f32");
+#else
+  constexpr bool f32 = false;
+#endif
   if (!f32) {
     // three raw-operand register sets (two 8 KiB steps in flight per wave); deeper rings measured no faster
     // TW = 4 column tiles (128 columns) per wave, one wave per SIMD.  TW = 2 with two waves per SIMD (grid n_pad/64) was
@@ -310,8 +314,10 @@ void launch_gemm(const GemmArgs& a, int KP, hipStream_t st) {
     else          hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, 4>), grid, block, 0, st, a);
     return;
   }
+#ifdef BNMTF_EXPERIMENTS
   if (KP == 32) hipLaunchKernelGGL((gemm_kernel<1, 16, 2>), grid, block, 0, st, a);
   else          hipLaunchKernelGGL((gemm_kernel<2, 16, 1>), grid, block, 0, st, a);
+#endif
 }
 
 }  // namespace bnmtf

@@ -210,9 +210,21 @@ __device__ __forceinline__ double small_gram(const float* reg, int n, int K, flo
 // (A fragments of UW MFMAs: MFMA t covers the units u0 + UW i + t) and one B element Xo[r0 + kk][k0 + i] from LDS.  R~ comes
 // from L2 (a microsecond away): the loads of the next NB steps are in flight while the MFMAs of the current NB run; `big` has
 // round_up(m, 32) rows, the ones behind m zero.
+struct ContractArgs {
+#ifdef BNMTF_SMALL_TIMING
+  unsigned long long* cph;
+#endif
+  const float* big; const float* XT; const float* lambda; float* PT;
+  int n, m, ldb, ldn, K; float tau;
+  uint32_t regO_b, CsO_b, regOwn_b;       // LDS byte addresses of the other factor, its Gram, and the own factor's region
+};
 template <int UW, int NT>
-__device__ __forceinline__ void small_contract(const SmallDirDev& d, const float* regO, const float* CsO, float* regOwn, float tau, int K,
-                                               float* PT, int tid) {
+__device__ __forceinline__ void small_contract(const ContractArgs& d, int tid) {
+  lds_cf* regO = (lds_cf*)(uintptr_t)d.regO_b;
+  lds_cf* CsO = (lds_cf*)(uintptr_t)d.CsO_b;
+  lds_fp regOwn = (lds_fp)(uintptr_t)d.regOwn_b;
+  const float tau = d.tau; const int K = d.K;
+  float* const PT = d.PT;
   constexpr int NB = UW == 4 ? 4 : 8;
   auto load_units = [](const float* p, float (&av)[UW]) {
     if constexpr (UW == 4) { const f32x4 t = *G(reinterpret_cast<const f32x4*>(p)); av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w; }
@@ -238,40 +250,88 @@ __device__ __forceinline__ void small_contract(const SmallDirDev& d, const float
 #pragma unroll
       for (int s = 0; s < NB; ++s) load_units(src + (size_t)(4 * s) * ld, dst[s]);
     };
-    float cur[NB][UW], nxt[NB][UW];
-    load_batch(0, cur);
-    for (int bi = 0; bi < nb; ++bi) {
-      if (bi + 1 < nb) load_batch(bi + 1, nxt);
+    // operand sets used in turn (no register copies: a copy would wait for the loads it is meant to overlap): two sets for the
+    // wide items -- the loads of batch bi + 1 in flight while the 16 MFMAs of batch bi run --, four for the one-unit-per-lane items,
+    // whose batch is 8 dependent MFMAs (320 cycles) against an L2 round trip of 500-900; the batch's B elements come out of LDS
+    // ahead of its MFMAs
+    auto run_batch = [&](int bi, const float (&cur)[NB][UW]) {
       if (bi == nb_big) {
 #pragma unroll
         for (int t = 0; t < UW; ++t) pacc[t] = acc[t];
       }
       const bool big = bi < nb_big;
       const int r0 = (big ? bi : bi - nb_big) * 4 * NB + lk;
+      float bv[NB];
+      if (big) {
 #pragma unroll
-      for (int s = 0; s < NB; ++s) {
-        const int r = r0 + 4 * s;
-        const float b = big ? regO[min(r, d.m) * kS + k0 + li] : -CsO[r * kS + k0 + li];      // rows >= m of the factor: its zero row
+        for (int s = 0; s < NB; ++s) bv[s] = regO[min(r0 + 4 * s, d.m) * kS + k0 + li];        // rows >= m of the factor: its zero row
+      } else {
 #pragma unroll
-        for (int t = 0; t < UW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[s][t], b, acc[t], 0, 0, 0);
+        for (int s = 0; s < NB; ++s) bv[s] = -CsO[(r0 + 4 * s) * kS + k0 + li];
       }
 #pragma unroll
       for (int s = 0; s < NB; ++s)
 #pragma unroll
-        for (int t = 0; t < UW; ++t) cur[s][t] = nxt[s][t];
+        for (int t = 0; t < UW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[s][t], bv[s], acc[t], 0, 0, 0);
+    };
+#ifdef BNMTF_SMALL_TIMING
+    unsigned long long ct0 = __builtin_readcyclecounter();
+#endif
+    if constexpr (UW == 1 && NT < 1024) {       // (a 16-wave block has 128 registers per lane: two sets there)
+      float o0[NB][UW], o1[NB][UW], o2[NB][UW], o3[NB][UW];
+      load_batch(0, o0);
+      if (nb > 1) load_batch(1, o1);
+      if (nb > 2) load_batch(2, o2);
+      for (int bi = 0; bi < nb; bi += 4) {
+        if (bi + 3 < nb) load_batch(bi + 3, o3);
+        run_batch(bi, o0);
+        if (bi + 1 >= nb) break;
+        if (bi + 4 < nb) load_batch(bi + 4, o0);
+        run_batch(bi + 1, o1);
+        if (bi + 2 >= nb) break;
+        if (bi + 5 < nb) load_batch(bi + 5, o1);
+        run_batch(bi + 2, o2);
+        if (bi + 3 >= nb) break;
+        if (bi + 6 < nb) load_batch(bi + 6, o2);
+        run_batch(bi + 3, o3);
+      }
+    } else {
+      float opa[NB][UW], opb[NB][UW];
+      load_batch(0, opa);
+      for (int bi = 0; bi < nb; bi += 2) {
+        if (bi + 1 < nb) load_batch(bi + 1, opb);
+        run_batch(bi, opa);
+        if (bi + 1 >= nb) break;
+        if (bi + 2 < nb) load_batch(bi + 2, opa);
+        run_batch(bi + 1, opb);
+      }
     }
+#ifdef BNMTF_SMALL_TIMING
+    { const unsigned long long t_ = __builtin_readcyclecounter(); d.cph[0] += t_ - ct0; ct0 = t_; d.cph[2] += 1; }
+#endif
     // C/D of the 16x16 f32 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg
     const int k = k0 + li;
+    float lam[UW][4];                      // the prior rates: all loads first (one after the other they were 16 L2 round trips per item)
+#pragma unroll
+    for (int t = 0; t < UW; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int u = min(u0 + UW * (4 * lk + r) + t, d.n - 1);          // (unconditional: the loads go out together)
+        lam[t][r] = *G(d.lambda + u * 32 + k);
+      }
 #pragma unroll
     for (int t = 0; t < UW; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int u = u0 + UW * (4 * lk + r) + t;
         if (u < d.n && k < K) {
-          regOwn[u * kS + k] = fmaf(tau, acc[t][r], -*G(d.lambda + u * 32 + k));
+          regOwn[u * kS + k] = fmaf(tau, acc[t][r], -lam[t][r]);
           if (PT) *G(PT + (size_t)k * d.ldn + u) = pacc[t][r];
         }
       }
+#ifdef BNMTF_SMALL_TIMING
+    { const unsigned long long t_ = __builtin_readcyclecounter(); d.cph[1] += t_ - ct0; }
+#endif
   }
 }
 
@@ -313,7 +373,7 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
   int rr = 0;                                // running retry-round number: list rr % 3 is the one being filled / read
   const bool draw = L.update == BNMTF_UPDATE_DRAW;
 #ifdef BNMTF_SMALL_TIMING
-  unsigned long long ph[16] = {0}, tlast = __builtin_readcyclecounter();
+  unsigned long long ph[16] = {0}, cph[6] = {0}, tlast = __builtin_readcyclecounter();
   int nretry = 0;
 #endif
 
@@ -355,10 +415,16 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
       // ---- contraction: regOwn = G (nothing of the sweep's per-thread state is live yet: the operand pipeline has the registers)
       {
         const int kt = (K + 15) >> 4;
-        float* PT = dir == 1 ? L.PT : nullptr;
-        if (((n + 63) / 64) * kt >= NT / 64) small_contract<4, NT>(d, regO, CsO, regOwn, tau, K, PT, tq);
-        else if (((n + 31) / 32) * kt >= (3 * NT) / 256) small_contract<2, NT>(d, regO, CsO, regOwn, tau, K, PT, tq);
-        else small_contract<1, NT>(d, regO, CsO, regOwn, tau, K, PT, tq);
+        ContractArgs ca;
+#ifdef BNMTF_SMALL_TIMING
+        ca.cph = cph + 3 * dir;
+#endif
+        ca.big = d.big; ca.XT = d.XT; ca.lambda = d.lambda; ca.PT = dir == 1 ? L.PT : nullptr;
+        ca.n = n; ca.m = m; ca.ldb = d.ldb; ca.ldn = d.ldn; ca.K = K; ca.tau = tau;
+        ca.regO_b = (uint32_t)(uintptr_t)(lds_fp)regO; ca.CsO_b = (uint32_t)(uintptr_t)(lds_fp)CsO; ca.regOwn_b = (uint32_t)(uintptr_t)(lds_fp)regOwn;
+        if (((n + 63) / 64) * kt >= NT / 64) small_contract<4, NT>(ca, tq);
+        else if (((n + 31) / 32) * kt >= NT / 128) small_contract<2, NT>(ca, tq);
+        else small_contract<1, NT>(ca, tq);
       }
       bar_all();                               // (PT is read by other threads than the ones that stored it)
       STAMP(1);
@@ -371,7 +437,7 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
       if (entry) myunit = *G(d.unit_of + tq);
 #pragma unroll
       for (int h = 0; h < EM / 2; ++h) {
-        uint32_t j0 = (uint32_t)m, j1 = (uint32_t)m;
+        uint32_t j0 = (uint32_t)(m * kS), j1 = (uint32_t)(m * kS);      // (33 j: the first word of factor row j; 33 m: the zero row)
         if (entry && 2 * h < em) { j0 = *G(d.idx + (2 * h) * kSmallThreads + tq); j1 = *G(d.idx + (2 * h + 1) * kSmallThreads + tq); }
         jj[h] = j0 | (j1 << 16);
         q[2 * h] = q[2 * h + 1] = 0.f; vp[2 * h] = vp[2 * h + 1] = 0.f;
@@ -384,8 +450,8 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
 #pragma unroll
             for (int h = 0; h < EM / 2; ++h)
               if (2 * h < em) {
-                q[2 * h] = fmaf(xv, regO[(jj[h] & 0xFFFFu) * kS + k], q[2 * h]);
-                q[2 * h + 1] = fmaf(xv, regO[(jj[h] >> 16) * kS + k], q[2 * h + 1]);
+                q[2 * h] = fmaf(xv, regO[(jj[h] & 0xFFFFu) + k], q[2 * h]);
+                q[2 * h + 1] = fmaf(xv, regO[(jj[h] >> 16) + k], q[2 * h + 1]);
               }
           }
       } else if (entry) {
@@ -423,7 +489,8 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
             if (2 * h < em) {
               q[2 * h] = fmaf(dlt, vp[2 * h], q[2 * h]);
               q[2 * h + 1] = fmaf(dlt, vp[2 * h + 1], q[2 * h + 1]);
-              const float v0 = col[(jj[h] & 0xFFFFu) * kS], v1 = col[(jj[h] >> 16) * kS];
+              asm volatile("" : "+v"(jj[h]));            // opaque: the 32 word addresses are made per gather, not kept in 32 more registers
+              const float v0 = col[jj[h] & 0xFFFFu], v1 = col[jj[h] >> 16];
               vp[2 * h] = v0; vp[2 * h + 1] = v1;
               qv = fmaf(q[2 * h], v0, qv); vv = fmaf(v0, v0, vv);
               qv = fmaf(q[2 * h + 1], v1, qv); vv = fmaf(v1, v1, vv);
@@ -607,6 +674,9 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
     printf("small kernel thread %d, %d iterations, cycles per iteration: table %llu contract %llu qinit %llu | columns: entry+prefetch %llu bar %llu unit %llu cand %llu pick %llu retry %llu (%d rounds) fixup %llu | qstore %llu gram %llu copy %llu finish %llu\n",
            tid, L.n_iter, ph[0] / L.n_iter, ph[1] / L.n_iter, ph[2] / L.n_iter, ph[3] / L.n_iter, ph[4] / L.n_iter, ph[5] / L.n_iter, ph[6] / L.n_iter, ph[7] / L.n_iter,
            ph[8] / L.n_iter, nretry, ph[9] / L.n_iter, ph[10] / L.n_iter, ph[11] / L.n_iter, ph[12] / L.n_iter, ph[13] / L.n_iter);
+  if (blockIdx.x == 0 && (tid & 63) == 0)
+    printf("   wave %2d contraction per iteration: rows loop %llu epilogue %llu (%llu items) | cols loop %llu epilogue %llu (%llu items)\n", tid >> 6,
+           cph[0] / L.n_iter, cph[1] / L.n_iter, cph[2] / L.n_iter, cph[3] / L.n_iter, cph[4] / L.n_iter, cph[5] / L.n_iter);
 #endif
 }
 

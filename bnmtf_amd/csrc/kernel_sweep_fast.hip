@@ -29,6 +29,7 @@ bool sweep_two_chunks_plan(int KP, int m, int* mh, int* pw, int* pw1) {
   return true;
 }
 
+#ifdef BNMTF_EXPERIMENTS
 // the twin shape (FastArgs::twin): 8 waves, split sampler, two blocks per CU when q is handed over
 static void launch_chip_twin(const SweepArgs& a, const FastArgs& f, hipStream_t st) {
   const int nx = a.KP / 32;
@@ -36,9 +37,13 @@ static void launch_chip_twin(const SweepArgs& a, const FastArgs& f, hipStream_t 
   else                      { if (nx == 1) launch_chip_inst<1, kSweepMode, 8, 0, 1, 1, 1>(a, f, st); else launch_chip_inst<2, kSweepMode, 8, 0, 1, 1, 1>(a, f, st); }
 }
 
+#endif
+
 void launch_sweep_fast(const SweepArgs& a, const FastArgs& f, hipStream_t st) {
-  if (f.twin) launch_chip_twin(a, f, st);
-  else if (f.nch == 2) launch_chip_two_chunks(a, f, st);                 // an inner extent of two LDS panels (9 185 .. 18 368)
+#ifdef BNMTF_EXPERIMENTS
+  if (f.twin) { launch_chip_twin(a, f, st); return; }
+#endif
+  if (f.nch == 2) launch_chip_two_chunks(a, f, st);                 // an inner extent of two LDS panels (9 185 .. 18 368)
   else if (f.nw == 2 || f.nw == 4) launch_sweep_small(a, f, st);    // kernel_sweep_small.hip
   else if (chip_split_enabled()) launch_chip<8, 0, 1>(a, f, st);
   else launch_chip<8, 0, 0>(a, f, st);

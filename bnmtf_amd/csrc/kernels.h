@@ -358,7 +358,7 @@ struct SmallDirDev {
   int nthreads, em;            // entry threads in use; slots per entry thread
   const float* big;            // masked R, unit index contiguous (rows: big[j][i], cols: big[i][j])
   const float* lambda;         // [n][32] prior rates, zero padded
-  const uint16_t* idx;         // [em][1024] inner index of slot e of entry thread t (m: empty -> the zero row)
+  const uint16_t* idx;         // [em][1024] 33 j for the inner index j of slot e of entry thread t (33 m: empty -> the zero row)
   const uint16_t* unit_of;     // [1024] unit of entry thread t
   const uint16_t* seg;         // [n][2] first entry thread and number of entry threads of unit u
   const uint32_t* perm;        // [em][1024] where the OTHER direction keeps this slot's q (e' * 1024 + t'), kSmallNone: empty

@@ -32,6 +32,9 @@
 extern "C" {
 #endif
 
+/* the library is built with -fvisibility=hidden: these are its only dynamic symbols */
+#define BNMTF_API __attribute__((visibility("default")))
+
 #define BNMTF_OK 0
 #define BNMTF_EINVAL (-1)   /* bad argument / unsupported shape */
 #define BNMTF_EHIP (-2)     /* HIP runtime error */
@@ -67,59 +70,59 @@ typedef struct bnmtf_problem {
 } bnmtf_problem;
 
 /* ---- library ---------------------------------------------------------- */
-int bnmtf_version(void);
-const char* bnmtf_last_error(void);
-int bnmtf_device_count(int* count);
+BNMTF_API int bnmtf_version(void);
+BNMTF_API const char* bnmtf_last_error(void);
+BNMTF_API int bnmtf_device_count(int* count);
 /* the contiguous block of `n` units (rows for the U/F sweep, columns for V/G) owned by `rank`:
  * first = n*rank/world, count = n*(rank+1)/world - first.  Pure function, no GPU needed. */
-int bnmtf_shard_range(int64_t n, int rank, int world, int64_t* first, int64_t* count);
+BNMTF_API int bnmtf_shard_range(int64_t n, int rank, int world, int64_t* first, int64_t* count);
 /* rank 0 makes the id, the host code ships it to the other ranks */
-int bnmtf_comm_unique_id(uint8_t out[128]);
+BNMTF_API int bnmtf_comm_unique_id(uint8_t out[128]);
 
 /* ---- life cycle: bnmf_gibbs_optimised.__init__ (bnmf_gibbs_optimised.py:54-78),
  *      bnmtf_gibbs_optimised.__init__ (bnmtf_gibbs_optimised.py:56-84).  Shape /
  *      empty-row assertions stay in the Python class (exact messages); create
  *      re-checks them and fails with BNMTF_EINVAL. ---------------------- */
-int bnmtf_create(const bnmtf_problem* p, bnmtf_handle* out);
-int bnmtf_destroy(bnmtf_handle h);
-int bnmtf_sync(bnmtf_handle h);
+BNMTF_API int bnmtf_create(const bnmtf_problem* p, bnmtf_handle* out);
+BNMTF_API int bnmtf_destroy(bnmtf_handle h);
+BNMTF_API int bnmtf_sync(bnmtf_handle h);
 
 /* size_Omega and the per-row / per-column observed counts (bit-exact integers;
  * size_Omega = M.sum(), bnmf_gibbs_optimised.py:65; counts :83-84).
  * row/col may be NULL. */
-int bnmtf_omega_counts(bnmtf_handle h, uint64_t* total, uint32_t* row, uint32_t* col);
+BNMTF_API int bnmtf_omega_counts(bnmtf_handle h, uint64_t* total, uint32_t* row, uint32_t* col);
 
 /* Page-locked host memory for the sample arrays run() fills (all_U, all_V, ...; bnmf_gibbs_optimised.py:125-127,
  * 146-148).  *_gibbs_run accepts ANY host pointer for its sample outputs; buffers from here (or registered by the
  * caller with hipHostRegister) are written by asynchronous device-to-host copies that overlap the following
  * iterations, pageable ones go through an internal pinned ring and a host memcpy. */
-int bnmtf_host_alloc(size_t bytes, void** out);
-int bnmtf_host_free(void* p);
+BNMTF_API int bnmtf_host_alloc(size_t bytes, void** out);
+BNMTF_API int bnmtf_host_free(void* p);
 
 /* approx_expectation(burn_in, thinning) (bnmf_gibbs_optimised.py:182-187, bnmtf_gibbs_optimised.py:216-223) on the
  * device: with burn_in >= 0 every *_gibbs_run call sums (fp64) the samples of its iterations burn_in, burn_in +
  * thinning, ... and bnmtf_get_expectation returns their means -- no iterations x I x K array crosses to the host (the
  * model-selection drivers of code/cross_validation/ only need these means).  burn_in < 0 switches it off (default).
  * A: I x K, S: K x L (BNMTF, else ignored), B: J x K (or J x L); any may be NULL. */
-int bnmtf_set_expectation(bnmtf_handle h, int burn_in, int thinning);
-int bnmtf_get_expectation(bnmtf_handle h, double* A, double* S, double* B, double* tau, uint64_t* count);
+BNMTF_API int bnmtf_set_expectation(bnmtf_handle h, int burn_in, int thinning);
+BNMTF_API int bnmtf_get_expectation(bnmtf_handle h, double* A, double* S, double* B, double* tau, uint64_t* count);
 
 /* Gibbs iteration counter = RNG counter word 2 (continues across run calls). */
-int bnmtf_set_iteration(bnmtf_handle h, uint64_t it);
-int bnmtf_get_iteration(bnmtf_handle h, uint64_t* it);
+BNMTF_API int bnmtf_set_iteration(bnmtf_handle h, uint64_t it);
+BNMTF_API int bnmtf_get_iteration(bnmtf_handle h, uint64_t* it);
 
 /* ---- BNMF Gibbs state: attributes U, V, tau (bnmf_gibbs_optimised.py:102-117) */
-int bnmf_set_state(bnmtf_handle h, const double* U, const double* V, double tau);
-int bnmf_get_state(bnmtf_handle h, double* U, double* V, double* tau);
+BNMTF_API int bnmf_set_state(bnmtf_handle h, const double* U, const double* V, double tau);
+BNMTF_API int bnmf_get_state(bnmtf_handle h, double* U, double* V, double* tau);
 
 /* tauU(k)/muU(tauUk,k) (which=0, :167-171) and tauV(k)/muV (which=1, :173-177) for
  * the current state, through the same kernels the sampler uses.  numer_out is
  * (-lambda[:,k] + tau * sum(...)), so that mu = numer / tau_k as the reference
  * divides by the caller-supplied tauUk; tau_out is tauU(k). Length I (or J). */
-int bnmf_cond_params(bnmtf_handle h, int which, int k, double* numer_out, double* tau_out);
+BNMTF_API int bnmf_cond_params(bnmtf_handle h, int which, int k, double* numer_out, double* tau_out);
 
 /* beta_s() (:164-165) for the current state: beta + 0.5 * masked SSE */
-int bnmtf_beta_s(bnmtf_handle h, double* out);
+BNMTF_API int bnmtf_beta_s(bnmtf_handle h, double* out);
 
 /* run(iterations) (:121-157): n_iter full sweeps (U columns, V columns, tau draw,
  * metrics on the training mask).  Outputs, each may be NULL:
@@ -127,7 +130,7 @@ int bnmtf_beta_s(bnmtf_handle h, double* out);
  *   tau_out [n_iter]                             (all_tau)
  *   perf_out [n_iter][3]  MSE, R^2, Rp           (all_performances)
  *   times_out [n_iter]    cumulative seconds     (all_times)           */
-int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* V_out,
+BNMTF_API int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* V_out,
                    double* tau_out, double* perf_out, double* times_out);
 
 /* The same call for n_models independent models at once -- the folds x ranks x restarts a model search fits one after the
@@ -136,58 +139,58 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
  * kernel_small.hip -- one block per model, the whole run in one launch) that share a device go down in ONE grid; any other
  * handle in the list is run by bnmf_gibbs_run in turn.  Every model draws exactly the chain its own bnmf_gibbs_run call
  * would draw.  The output arrays are arrays of n_models pointers (or NULL), each as in bnmf_gibbs_run. */
-int bnmf_gibbs_run_many(const bnmtf_handle* hs, int n_models, int n_iter, int update, float* const* U_outs, float* const* V_outs,
+BNMTF_API int bnmf_gibbs_run_many(const bnmtf_handle* hs, int n_models, int n_iter, int update, float* const* U_outs, float* const* V_outs,
                         double* const* tau_outs, double* const* perf_outs, double* const* times_outs);
 
 /* ---- BNMTF Gibbs (bnmtf_gibbs_optimised.py) ---------------------------- */
-int bnmtf_set_state(bnmtf_handle h, const double* F, const double* S, const double* G, double tau);
-int bnmtf_get_state(bnmtf_handle h, double* F, double* S, double* G, double* tau);
+BNMTF_API int bnmtf_set_state(bnmtf_handle h, const double* F, const double* S, const double* G, double tau);
+BNMTF_API int bnmtf_get_state(bnmtf_handle h, double* F, double* S, double* G, double* tau);
 /* which = 0: tauF(k)/muF (:195-199), length I; 1: tauS(k,l)/muS (:201-205), length 1;
  * 2: tauG(l)/muG (:207-211), length J (k ignored). */
-int bnmtf_cond_params(bnmtf_handle h, int which, int k, int l, double* numer_out, double* tau_out);
+BNMTF_API int bnmtf_cond_params(bnmtf_handle h, int which, int k, int l, double* numer_out, double* tau_out);
 /* run(iterations) (:138-180): F columns, S row-major, G columns, tau. */
-int bnmtf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* F_out, float* S_out, float* G_out,
+BNMTF_API int bnmtf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* F_out, float* S_out, float* G_out,
                     double* tau_out, double* perf_out, double* times_out);
 
 /* ---- BNMF VB (bnmf_vb_optimised.py) ------------------------------------ */
 /* all eight q-parameter matrices + exptau; any pointer may be NULL (left as is) */
-int bnmf_vb_set_state(bnmtf_handle h, const double* muU, const double* tauU, const double* expU, const double* varU,
+BNMTF_API int bnmf_vb_set_state(bnmtf_handle h, const double* muU, const double* tauU, const double* expU, const double* varU,
                       const double* muV, const double* tauV, const double* expV, const double* varV, double exptau);
-int bnmf_vb_get_state(bnmtf_handle h, double* muU, double* tauU, double* expU, double* varU,
+BNMTF_API int bnmf_vb_get_state(bnmtf_handle h, double* muU, double* tauU, double* expU, double* varU,
                       double* muV, double* tauV, double* expV, double* varV);
 /* update_U(k)+update_exp_U(k) (which=0, :189-191,199-204) or update_V/update_exp_V
  * (which=1, :193-195,206-211) for one column; moments=0 skips the update_exp part. */
-int bnmf_vb_update(bnmtf_handle h, int which, int k, int moments);
+BNMTF_API int bnmf_vb_update(bnmtf_handle h, int which, int k, int moments);
 /* exp_square_diff() (:185-187) */
-int bnmf_vb_exp_square_diff(bnmtf_handle h, double* out);
+BNMTF_API int bnmf_vb_exp_square_diff(bnmtf_handle h, double* out);
 /* run(iterations) (:121-153).  exptau_out[n_iter] (all_exp_tau), perf_out[n_iter][3], times_out[n_iter],
  * elbo_terms_out[n_iter][10] = the O(I*J) / O((I+J)K) pieces of elbo() (:163-177) that live on the device:
  *   {exp_square_diff, beta_s,
  *    sum tauU/2 (varU+(expU-muU)^2), sum log(0.5 erfc(-muU sqrt(tauU/2))), sum log tauU, sum lambdaU expU,
  *    the same four for V};  the host finishes the scalar algebra (digamma, gammaln). */
-int bnmf_vb_run(bnmtf_handle h, int n_iter, double* exptau_out, double* perf_out,
+BNMTF_API int bnmf_vb_run(bnmtf_handle h, int n_iter, double* exptau_out, double* perf_out,
                 double* elbo_terms_out, double* times_out);
 
 /* ---- BNMTF VB (bnmtf_vb_optimised.py); K, L <= 32, one GPU ---------------- */
 /* the twelve q-parameter matrices (F: I x K, S: K x L, G: J x L) + exptau; any pointer may be NULL (left as is) */
-int bnmtf_vb_set_state(bnmtf_handle h, const double* muF, const double* tauF, const double* expF, const double* varF,
+BNMTF_API int bnmtf_vb_set_state(bnmtf_handle h, const double* muF, const double* tauF, const double* expF, const double* varF,
                        const double* muS, const double* tauS, const double* expS, const double* varS,
                        const double* muG, const double* tauG, const double* expG, const double* varG, double exptau);
-int bnmtf_vb_get_state(bnmtf_handle h, double* muF, double* tauF, double* expF, double* varF,
+BNMTF_API int bnmtf_vb_get_state(bnmtf_handle h, double* muF, double* tauF, double* expF, double* varF,
                        double* muS, double* tauS, double* expS, double* varS,
                        double* muG, double* tauG, double* expG, double* varG);
 /* update_F(k) (which = 0, :241-250), update_S(k,l) (which = 1, :252-262), update_G(l) (which = 2, :264-273) for the
  * current state; moments != 0 also runs the matching update_exp_* (:276-285). */
-int bnmtf_vb_update(bnmtf_handle h, int which, int k, int l, int moments);
+BNMTF_API int bnmtf_vb_update(bnmtf_handle h, int which, int k, int l, int moments);
 /* exp_square_diff() (:235-239); sums_out (may be NULL): n, sum R, sum R^2, sum P, sum P^2, sum R P over the training
  * mask with P = E[F] E[S] E[G]^T */
-int bnmtf_vb_exp_square_diff(bnmtf_handle h, double* esd_out, double sums_out[6]);
+BNMTF_API int bnmtf_vb_exp_square_diff(bnmtf_handle h, double* esd_out, double sums_out[6]);
 /* run(iterations) (:160-205).  orders [n_iter][K L + K + L]: per iteration the update order of the S entries (k L + l),
  * the F columns and the G columns (the reference shuffles them with random.shuffle, :171-186; the host class draws the
  * same shuffles).  exptau_out [n_iter]; perf_out [n_iter][3]; times_out [n_iter]; elbo_terms_out [n_iter][10] =
  * {exp_square_diff, beta_s, then for F and for G: sum tau/2 (var+(exp-mu)^2), sum log(0.5 erfc(-mu sqrt(tau/2))),
  * sum log tau, sum lambda exp} -- the K L terms of S and the scalar algebra are the host's. */
-int bnmtf_vb_run(bnmtf_handle h, int n_iter, const int32_t* orders, double* exptau_out, double* perf_out,
+BNMTF_API int bnmtf_vb_run(bnmtf_handle h, int n_iter, const int32_t* orders, double* exptau_out, double* perf_out,
                  double* elbo_terms_out, double* times_out);
 
 /* ---- metrics: predict()/predict_while_running()/quality('MSE')/log_likelihood
@@ -195,33 +198,33 @@ int bnmtf_vb_run(bnmtf_handle h, int n_iter, const int32_t* orders, double* expt
  *      training mask): n, sum R, sum R^2, sum P, sum P^2, sum R*P with
  *      P = A.B^T (S == NULL, A: I x K, B: J x K) or A.S.B^T (S: K x L, B: J x L).
  *      A == NULL uses the handle's current state. */
-int bnmtf_metric_sums(bnmtf_handle h, const uint8_t* Mp, const double* A, const double* S,
+BNMTF_API int bnmtf_metric_sums(bnmtf_handle h, const uint8_t* Mp, const double* A, const double* S,
                       const double* B, double sums_out[6]);
 
 /* ---- distributions (stand-alone hooks; code/models/distributions/) ----- */
 /* TN_vector_draw (truncated_normal_vector.py:37-50): out[e] ~ TN(mu[e],tau[e]) on
  * [0,inf); RNG counter (elem0+e, col, it, STREAM_HOOK). */
-int bnmtf_tn_sample(const double* mu, const double* tau, size_t n, uint64_t seed, uint64_t it,
+BNMTF_API int bnmtf_tn_sample(const double* mu, const double* tau, size_t n, uint64_t seed, uint64_t it,
                     uint32_t col, uint32_t elem0, int device, double* out);
 /* TN_vector_expectation / TN_vector_variance (:53-73) */
-int bnmtf_tn_moments(const double* mu, const double* tau, size_t n, int device,
+BNMTF_API int bnmtf_tn_moments(const double* mu, const double* tau, size_t n, int device,
                      double* exp_out, double* var_out);
 /* gamma_draw (gamma.py:11-14), shape alpha, rate beta */
-int bnmtf_gamma_sample(double alpha, double beta, uint64_t seed, uint64_t it, int device, double* out);
+BNMTF_API int bnmtf_gamma_sample(double alpha, double beta, uint64_t seed, uint64_t it, int device, double* out);
 
 /* ---- masked K-means for initialise(init_FG='kmeans') (code/models/kmeans/kmeans.py): the two O(points x coordinates x K)
  *      passes of an iteration; X [n_points][n_coords] fp64 (as the reference computes), M 0/1 bytes; the handle is a plain pointer of its own kind. */
-int bnmtf_kmeans_create(const double* X, const uint8_t* M, int n_points, int n_coords, int K, int device, void** out);
-int bnmtf_kmeans_destroy(void* h);
+BNMTF_API int bnmtf_kmeans_create(const double* X, const uint8_t* M, int n_points, int n_coords, int K, int device, void** out);
+BNMTF_API int bnmtf_kmeans_destroy(void* h);
 /* assignment() (kmeans.py:87-119): closest centroid by MSE over the shared observed coordinates (none: infinitely far;
  * ties: lowest index); dist_out = that MSE (+inf without overlap) */
-int bnmtf_kmeans_assign(void* h, const double* centroids, const uint8_t* mask_centroids, int32_t* assign_out, double* dist_out);
+BNMTF_API int bnmtf_kmeans_assign(void* h, const double* centroids, const uint8_t* mask_centroids, int32_t* assign_out, double* dist_out);
 /* the sums update() needs (kmeans.py:126-182): cnt_out / tot_out [K][n_coords] = number / sum of the values of the
  * cluster's members that observe the coordinate (assign < 0: the point belongs to no cluster) */
-int bnmtf_kmeans_sums(void* h, const int32_t* assign, double* cnt_out, double* tot_out);
+BNMTF_API int bnmtf_kmeans_sums(void* h, const int32_t* assign, double* cnt_out, double* tot_out);
 /* X[index][:] = values: `self.centroids[c] = self.X[index]` (kmeans.py:141) makes the refilled centroid a view of the data
  * point, so the means written into the centroid afterwards (:158-163) change the point; the host class mirrors that */
-int bnmtf_kmeans_set_row(void* h, int index, const double* values);
+BNMTF_API int bnmtf_kmeans_set_row(void* h, int index, const double* values);
 
 /* ---- measurement aids (bench.py) --------------------------------------- */
 #define BNMTF_KERNEL_GEMM_ROWS 0   /* P  = R~ . V      (U/F step numerators)        */
@@ -233,21 +236,25 @@ int bnmtf_kmeans_set_row(void* h, int index, const double* values);
 /* enable = 1: run() brackets each launch of the listed kernels with hipEvents on the handle's
  * stream; enable = 2 + k (+ 32 (n - 1)): only kernel k (BNMTF_KERNEL_*), in every n-th iteration (an event record
  * costs the queue a few microseconds: a timed run samples); 0: off.  Totals are read back with bnmtf_kernel_stats. */
-int bnmtf_set_profiling(bnmtf_handle h, int enable);
+BNMTF_API int bnmtf_set_profiling(bnmtf_handle h, int enable);
 /* ICM: the lower clamp run(iterations, minimum_TN) applies to every updated entry (nmf_icm.py:129,135;
  * nmtf_icm.py:147,153,159).  Used by *_gibbs_run with update = BNMTF_UPDATE_ICM.  Default 0. */
-int bnmtf_set_minimum_tn(bnmtf_handle h, double minimum_TN);
+BNMTF_API int bnmtf_set_minimum_tn(bnmtf_handle h, double minimum_TN);
 /* sweep kernel selection: 1 (default) = register/LDS-resident fast path when the shape
  * fits, 0 = always the generic kernel (any mask, q in global memory).  Same results. */
-int bnmtf_set_sweep_path(bnmtf_handle h, int fast);
+BNMTF_API int bnmtf_set_sweep_path(bnmtf_handle h, int fast);
 /* the one-launch path for small BNMF models (K <= 32, I, J <= 1024, factors within one CU's LDS; run() = one launch):
  * on = 0 sends this handle's runs down the multi-launch path instead (tests, A/B).  Default 1.  Same chain either way up to
  * fp32 summation order.  bnmtf_is_small: would the next bnmf_gibbs_run of this handle take it? */
-int bnmtf_set_small_path(bnmtf_handle h, int on);
-int bnmtf_is_small(bnmtf_handle h, int* out);
-int bnmtf_kernel_stats(bnmtf_handle h, int kernel, double* total_ms, uint64_t* launches);
+/* 1 when the library was built with `make EXPERIMENTS=1`: the measured-and-not-adopted kernels (two unit groups taking turns,
+ * BNMTF_TURNS=1; two 8-wave blocks per CU, BNMTF_TWIN=1; the f32-MFMA contraction, BNMTF_GEMM=f32 -- DESIGN.md section 7) are
+ * compiled in and their switches honoured.  The shipped build has none of them. */
+BNMTF_API int bnmtf_has_experiments(void);
+BNMTF_API int bnmtf_set_small_path(bnmtf_handle h, int on);
+BNMTF_API int bnmtf_is_small(bnmtf_handle h, int* out);
+BNMTF_API int bnmtf_kernel_stats(bnmtf_handle h, int kernel, double* total_ms, uint64_t* launches);
 /* geometry of the last create: padded shapes, split factor, slot counts (for DESIGN/bench) */
-int bnmtf_describe(bnmtf_handle h, char* buf, size_t buflen);
+BNMTF_API int bnmtf_describe(bnmtf_handle h, char* buf, size_t buflen);
 
 #ifdef __cplusplus
 }

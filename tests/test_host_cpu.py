@@ -16,13 +16,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "bnmtf_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(bnmt?f_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^BNMTF_API\s+(?:int|const char\*)\s+(bnmt?f_\w+)\s*\(", hdr, flags=re.M))
     assert declared, "no declarations parsed"
     lib = bnmtf_amd.lib()
     for name in declared:
         assert hasattr(lib, name), "libbnmtf_hip.so does not export %s" % name
     assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
     assert lib.bnmtf_version() >= 100
+    # ... and nothing else: -fvisibility=hidden and a linker version script (csrc/exports.map) leave the header's entry points as
+    # the library's only dynamic symbols
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", bnmtf_amd.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    syms = {l.split()[-1] for l in out.splitlines() if l.strip()}
+    assert syms == declared, sorted(syms ^ declared)[:20]
+    assert lib.bnmtf_has_experiments() == 0, "the shipped build has no experiment kernels (make EXPERIMENTS=1 is a tools/ build)"
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -8,6 +8,8 @@ Headline shape (8192 x 8192, K = 64): size-independent properties only."""
 import numpy as np
 import pytest
 
+from bnmtf_amd import _lib
+
 from bnmtf_amd import bnmf_gibbs_optimised
 from bnmtf_amd.synthetic import generate_bnmf
 from oracle import bnmtf_oracle as O
@@ -32,6 +34,8 @@ def _ragged_mask(rs, I, J, lo, hi):
 def test_wide_kernel_equals_generic_kernel_and_oracle(monkeypatch, I, J, K, lo, hi, turns):
     """turns = "1": the same layout run by kernel_sweep_turns.hip (BNMTF_TURNS=1: 8-wave blocks, two groups of units taking
     turns; an experiment kept in the tree -- its own order of the floating-point sums, the same draws)."""
+    if turns == "1" and not _lib.lib().bnmtf_has_experiments():
+        pytest.skip("the turns kernel is an experiment: make EXPERIMENTS=1")
     monkeypatch.setenv("BNMTF_WIDE", "1")
     monkeypatch.setenv("BNMTF_TURNS", turns)
     rs = np.random.RandomState(I + J)
@@ -76,6 +80,8 @@ def test_q_handed_over_between_the_half_sweeps_equals_the_pre_pass(monkeypatch, 
     the missing entries goes from the end of one half sweep to the start of the next through block-sorted packets
     instead of being rebuilt by the pre-pass.  Same chain as with the pre-pass (BNMTF_HANDOVER=0) up to fp32 rounding; never
     refreshed, twelve mode updates still follow the fp64 oracle."""
+    if wide == "twin" and not _lib.lib().bnmtf_has_experiments():
+        pytest.skip("the twin shape is an experiment: make EXPERIMENTS=1")
     monkeypatch.setenv("BNMTF_WIDE", "1" if wide == "twin" else wide)
     if wide == "twin":                   # the 16-wave layout run by 8-wave blocks, two to a CU (BNMTF_TWIN=1: an experiment kept in the tree)
         monkeypatch.setenv("BNMTF_TWIN", "1")

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bnmtf_amd
 from bnmtf_amd.synthetic import generate_bnmf
 PRI = dict(alpha=1.0, beta=1.0, lambdaU=0.1, lambdaV=0.1)
-for (I, J, K, miss) in [(100, 80, 10, 0.0), (100, 80, 10, 0.1), (622, 138, 25, 0.19)]:
+for (I, J, K, miss) in [(622, 138, 25, 0.19)]:
     R, M, _, _ = generate_bnmf(I, J, K, miss, seed_data=3, seed_mask=4)
     np.random.seed(1)
     b = bnmtf_amd.bnmf_gibbs_optimised(R, M, K, PRI, seed=5, verbose=False)
