@@ -85,6 +85,7 @@ class bnmf_vb_optimised(DeviceModel):
         self.all_times = list(times)
         self.all_performances = {'MSE': list(perf[:, 0]), 'R^2': list(perf[:, 1]), 'Rp': list(perf[:, 2])}
         self.all_elbo = [self._elbo_from_terms(terms[i]) for i in range(it)]
+        self.all_elbo_terms = terms        # per iteration: exp_square_diff, beta_s, then (quad, log erfc, log tau, lambda E) sums of U and of V
         if it > 0:
             self.alpha_s = self.alpha + self.size_Omega / 2.0
             self.beta_s = terms[-1, 1]

@@ -901,7 +901,16 @@ int bnmtf_create(const bnmtf_problem* p, bnmtf_handle* out) {
   h->rows.nglob = I; h->rows.m = J; h->rows.W = Wr; h->rows.KP = Wr <= 32 ? 32 : 64;
   h->cols.nglob = J; h->cols.m = I; h->cols.W = Wc; h->cols.KP = Wc <= 32 ? 32 : 64;
   h->rows.obs_count = rc; h->cols.obs_count = cc;
-  {   // the full matrix and the training mask (predict / validation; the layout passes read them on the device); small scalars -- one allocation
+  // Small models (kernel_small.hip: the whole run in one launch, one block per model) build only their own arena here -- ONE
+  // allocation that also holds the full matrix, the mask and the scalars; the structures of the multi-launch path -- contraction
+  // operands, slot layouts, Gram partials, ... -- are built the first time an entry point needs them (ensure_std).
+  // BNMTF_SMALL=0: never.
+  h->lam_rows.assign(p->lambda_rows, p->lambda_rows + (size_t)I * Wr);
+  h->lam_cols.assign(p->lambda_cols, p->lambda_cols + (size_t)J * Wc);
+  if (p->L == 0 && p->world == 1 && !getenv("BNMTF_FORCE_COMM")) {
+    if ((rcode = small_build(h, R, M))) return fail(rcode);
+  }
+  if (!h->one_arena) {   // the full matrix and the training mask (predict / validation; the layout passes read them on the device); small scalars -- one allocation
     const size_t bR = ((size_t)I * J * sizeof(float) + 255) & ~(size_t)255, bM = ((size_t)I * J + 255) & ~(size_t)255;
     char* base = nullptr;
     if ((rcode = dalloc(&base, bR + bM + 256, false))) return fail(rcode);
@@ -911,14 +920,6 @@ int bnmtf_create(const bnmtf_problem* p, bnmtf_handle* out) {
   }
   if (hipMemcpyAsync(h->Rfull, R, (size_t)I * J * sizeof(float), hipMemcpyHostToDevice, h->stream) != hipSuccess) { set_error("copy R failed"); return fail(BNMTF_EHIP); }
   if (hipMemcpyAsync(h->Mtrain, M, (size_t)I * J, hipMemcpyHostToDevice, h->stream) != hipSuccess) { set_error("copy M failed"); return fail(BNMTF_EHIP); }
-  // Small models (kernel_small.hip: the whole run in one launch, one block per model) build only their own arena here; the
-  // structures of the multi-launch path -- contraction operands, slot layouts, Gram partials, ... -- are built the first time an
-  // entry point needs them (ensure_std).  BNMTF_SMALL=0: never.
-  h->lam_rows.assign(p->lambda_rows, p->lambda_rows + (size_t)I * Wr);
-  h->lam_cols.assign(p->lambda_cols, p->lambda_cols + (size_t)J * Wc);
-  if (p->L == 0 && p->world == 1 && !getenv("BNMTF_FORCE_COMM")) {
-    if ((rcode = small_build(h, R, M))) return fail(rcode);
-  }
   if (h->small) {
     if (hipStreamSynchronize(h->stream) != hipSuccess) { set_error("bnmtf_create: uploads failed"); return fail(BNMTF_EHIP); }    // (R, M are the caller's)
     h->std_built = false;
@@ -957,8 +958,8 @@ static int build_standard(bnmtf_model* h, const double* lambda_S, const uint8_t*
   if ((rcode = alloc_factor(h->cols, h->rows.inner_pad))) return fail(rcode);
 
   laps.lap("factor buffers");
-  if ((rcode = dalloc(&h->Ad, (size_t)I * 64))) return fail(rcode);
-  if ((rcode = dalloc(&h->Bd, (size_t)J * 64))) return fail(rcode);
+  if (!h->Ad && (rcode = dalloc(&h->Ad, (size_t)I * 64))) return fail(rcode);
+  if (!h->Bd && (rcode = dalloc(&h->Bd, (size_t)J * 64))) return fail(rcode);
   if (p->L > 0 && (rcode = dalloc(&h->S, (size_t)p->K * p->L))) return fail(rcode);
   if (p->L > 0 && (rcode = bnmtf_alloc_extras(h, p->lambda_S))) return fail(rcode);
 
@@ -1024,12 +1025,12 @@ int bnmtf_destroy(bnmtf_handle h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->comm) comm_destroy(h->comm);
+  small_free(h);            // (first: a small model's arena also holds Rfull, the posterior sums, Ad / Bd -- their pointers are cleared)
   free_dir(h->rows); free_dir(h->cols); free_dir(h->reff); free_dir(h->ceff);
   dfree(h->slabsS); dfree(h->CfS); dfree(h->deltaS); dfree(h->s_partial); dfree(h->s_w); dfree(h->s_omp); dfree(h->lambdaS); dfree(h->s_numer); dfree(h->s_taup);
   dfree(h->exp_rows); dfree(h->exp_cols); dfree(h->exp_S); dfree(h->exp_tau);
   dfree(h->muS); dfree(h->tauS); dfree(h->varS); dfree(h->mv_rows); dfree(h->mv_cols); dfree(h->tri_order); dfree(h->tri_sums);
   dfree(h->ss_Wc); dfree(h->ss_Gc); dfree(h->ss_cands); dfree(h->ss_slabs); dfree(h->ss_AB); dfree(h->ss_r); dfree(h->ss_bpart);
-  small_free(h);
   dfree(h->Rfull); h->Mtrain = nullptr; h->out6 = nullptr; h->tau_d = nullptr; h->tau_f = nullptr; h->acc = nullptr;   // (one allocation: bnmtf_create)
   dfree(h->Mscratch); dfree(h->Ad); dfree(h->Bd);
   dfree(h->A2d); dfree(h->B2d); dfree(h->vb_rec); dfree(h->vbred);

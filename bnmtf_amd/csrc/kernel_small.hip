@@ -432,7 +432,9 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
       // ---- this thread's slots, and q of its entries: handed over by the other direction's sweep, or -- every `refresh`-th
       // iteration in the rows sweep -- rebuilt from the factors (the own one as it was: its transposed copy in L2)
       uint32_t jj[EM / 2];
-      float q[EM], vp[EM];
+      // (EM = 64: the gathered values of the previous column are not kept -- 64 more registers -- but gathered again for the update)
+      constexpr bool KEEPV = EM <= 32;
+      float q[EM], vp[KEEPV ? EM : 2];
       int myunit = 0;
       if (entry) myunit = *G(d.unit_of + tq);
 #pragma unroll
@@ -440,7 +442,8 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
         uint32_t j0 = (uint32_t)(m * kS), j1 = (uint32_t)(m * kS);      // (33 j: the first word of factor row j; 33 m: the zero row)
         if (entry && 2 * h < em) { j0 = *G(d.idx + (2 * h) * kSmallThreads + tq); j1 = *G(d.idx + (2 * h + 1) * kSmallThreads + tq); }
         jj[h] = j0 | (j1 << 16);
-        q[2 * h] = q[2 * h + 1] = 0.f; vp[2 * h] = vp[2 * h + 1] = 0.f;
+        q[2 * h] = q[2 * h + 1] = 0.f;
+        if constexpr (KEEPV) vp[2 * h] = vp[2 * h + 1] = 0.f;
       }
       const bool prepass = dir == 0 && (it_abs % L.refresh == 0 || (it == 0 && !L.q_valid));
       if (prepass) {
@@ -487,11 +490,16 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
 #pragma unroll
           for (int h = 0; h < EM / 2; ++h)
             if (2 * h < em) {
-              q[2 * h] = fmaf(dlt, vp[2 * h], q[2 * h]);
-              q[2 * h + 1] = fmaf(dlt, vp[2 * h + 1], q[2 * h + 1]);
               asm volatile("" : "+v"(jj[h]));            // opaque: the 32 word addresses are made per gather, not kept in 32 more registers
               const float v0 = col[jj[h] & 0xFFFFu], v1 = col[jj[h] >> 16];
-              vp[2 * h] = v0; vp[2 * h + 1] = v1;
+              if constexpr (KEEPV) {
+                q[2 * h] = fmaf(dlt, vp[2 * h], q[2 * h]);
+                q[2 * h + 1] = fmaf(dlt, vp[2 * h + 1], q[2 * h + 1]);
+                vp[2 * h] = v0; vp[2 * h + 1] = v1;
+              } else if (k > 0) {
+                q[2 * h] = fmaf(dlt, col[(int)(jj[h] & 0xFFFFu) - 1], q[2 * h]);
+                q[2 * h + 1] = fmaf(dlt, col[(int)(jj[h] >> 16) - 1], q[2 * h + 1]);
+              }
               qv = fmaf(q[2 * h], v0, qv); vv = fmaf(v0, v0, vv);
               qv = fmaf(q[2 * h + 1], v1, qv); vv = fmaf(v1, v1, vv);
             }
@@ -607,7 +615,10 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
 #pragma unroll
         for (int e = 0; e < EM; ++e)
           if (e < em) {
-            q[e] = fmaf(dlt, vp[e], q[e]);
+            float vlast;
+            if constexpr (KEEPV) vlast = vp[e];
+            else vlast = regO[((jj[e >> 1] >> (16 * (e & 1))) & 0xFFFFu) + (K - 1)];
+            q[e] = fmaf(dlt, vlast, q[e]);
             *G(d.q + e * kSmallThreads + tq) = q[e];
             if (dir == 1) { st_q += (double)q[e]; st_q2 += (double)q[e] * (double)q[e]; }
           }
@@ -696,7 +707,12 @@ void launch_small_gibbs(const SmallLaunch* dev_launches, int n_models, int em, i
   if (n_models <= 0) return;
   if (em <= 8) launch_small_em<8>(dev_launches, n_models, nt, lds_bytes, st);
   else if (em <= 16) launch_small_em<16>(dev_launches, n_models, nt, lds_bytes, st);
-  else launch_small_em<32>(dev_launches, n_models, nt, lds_bytes, st);
+  else if (em <= 32) launch_small_em<32>(dev_launches, n_models, nt, lds_bytes, st);
+  // (the classes above 32 slots only exist where the 32-slot one needs more than 1024 threads; they gather the previous column's
+  // values again instead of keeping them: 40 and 48 slots still fit a 16-wave block's 128 registers per lane, 64 spill)
+  else if (em <= 40) launch_small_inst<40, 1024>(dev_launches, n_models, lds_bytes, st);
+  else if (em <= 48) launch_small_inst<48, 1024>(dev_launches, n_models, lds_bytes, st);
+  else launch_small_inst<64, 1024>(dev_launches, n_models, lds_bytes, st);
 }
 
 }  // namespace bnmtf

@@ -350,7 +350,7 @@ void launch_tri_vb_finish(const double* sums, double alpha, double beta, double*
 constexpr int kSmallThreads = 1024;     // threads of the largest block (16 waves = one CU); row stride of the slot tables.  Smaller models run 256- or 512-thread blocks, several to a CU
 constexpr int kSmallStride = 33;        // floats per factor row in LDS (odd: a column gather and a row read are both conflict-free)
 constexpr int kSmallKP = 32;            // K <= 32
-constexpr int kSmallMaxSlots = 32;      // missing entries per entry thread (slot classes 8 / 16 / 32)
+constexpr int kSmallMaxSlots = 64;      // missing entries per entry thread (slot classes 8 / 16 / 32 / 64)
 constexpr uint32_t kSmallNone = 0xFFFFFFFFu;
 struct SmallDirDev {
   int n, m;                    // units (rows of this direction's factor), inner extent

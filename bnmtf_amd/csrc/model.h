@@ -108,7 +108,6 @@ struct SmallModel {
   // per-call buffers, grown on demand: [gunit | rec | clock] and the samples
   char* call_buf = nullptr; size_t call_cap = 0;
   float* smp = nullptr; size_t smp_cap = 0;
-  SmallLaunch* dev_launch = nullptr;  // device copy of the descriptor (single-model calls)
 };
 
 }  // namespace bnmtf
@@ -138,6 +137,7 @@ struct bnmtf_model {
   // are built on first need for a model that starts small); which of the two holds the current state
   bnmtf::SmallModel* small = nullptr;
   bool small_enabled = true, std_built = true, small_cur = false, std_cur = false;
+  bool one_arena = false;      // Rfull, Mtrain, the scalars, the posterior sums and Ad / Bd live in the small model's arena (one allocation per model)
   std::vector<double> lam_rows, lam_cols;          // prior rates as given (build_standard may run after bnmtf_create has returned)
   // BNMTF extras
   float* S = nullptr;            // [K][L] on device (row major, unpadded)

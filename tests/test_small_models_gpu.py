@@ -238,3 +238,27 @@ def test_batched_replica_pool_gives_the_sequential_results():
             assert a["quality"][k] == pytest.approx(b["quality"][k], rel=1e-12)       # (the metric kernel sums with fp64 atomics)
         for k in a["performance"]:
             assert a["performance"][k] == pytest.approx(b["performance"][k], rel=1e-12)
+
+
+@pytest.mark.parametrize("miss", [0.27, 0.34, 0.45])
+def test_the_slot_classes_above_32_follow_the_oracle(miss):
+    """Masks with more missing entries than 1024 threads hold at 32 slots each (a training fold of a 19 %-missing 622 x 138 matrix has
+    27 %): the 40-, 48- and 64-slot classes, which gather the previous column's values again instead of keeping them in registers."""
+    import re
+    R, M, _, _ = generate_bnmf(622, 138, 6, miss, seed_data=4, seed_mask=5)
+    rs = np.random.RandomState(2)
+    U0 = rs.rand(622, 6) + 0.3; V0 = rs.rand(138, 6) + 0.3
+    b = bnmf_gibbs_optimised(R, M, 6, PRI, verbose=False, seed=3)
+    assert b.is_small()
+    b.U, b.V, b.tau = U0.copy(), V0.copy(), 1.0
+    slots = [int(x) for x in re.search(r"slots=(\d+)/(\d+)", b.describe()).groups()]
+    assert max(slots) == {0.27: 40, 0.34: 48, 0.45: 64}[miss], b.describe()
+    o = O.BNMFGibbsOracle(R.astype(np.float64), M, 6, PRI)
+    o.U, o.V, o.tau = U0.copy(), V0.copy(), 1.0
+    o.run(4, draw=False); b.run(4, update='mode')
+    np.testing.assert_allclose(b.all_performances['MSE'], o.all_performances['MSE'], rtol=2e-4)
+    np.testing.assert_allclose(b.all_tau, o.all_tau, rtol=2e-4)
+    assert np.abs(b.all_U[-1] - o.all_U[-1]).max() < 2e-3 * max(1.0, np.abs(o.all_U[-1]).max())
+    b.run(10)
+    p = b.predict_while_running()
+    assert abs(p["MSE"] - b.all_performances['MSE'][-1]) < 5e-5 * p["MSE"]
