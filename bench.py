@@ -448,6 +448,9 @@ def main():
         run(a.steps)
         sync(); resident = a.steps / cp.allreduce_max(time.perf_counter() - t1)
 
+    import ctypes as C_
+    ck, cr = C_.c_int(), C_.c_int()
+    _lib.check(L.bnmtf_comm_info(h, C_.byref(ck), C_.byref(cr)))
     if rank == 0:
         Wc = w.get("L", K)                 # width of the cols-direction contraction's factor operand is K (F or U)
         ms_step = 1e3 * dt / a.steps
@@ -497,6 +500,8 @@ def main():
                            {"bnmf": "BNMF Gibbs", "bnmtf": "BNMTF Gibbs", "vb": "BNMF VB"}[kind], I, J, K, " L=%d" % w["L"] if "L" in w else "",
                            "exp" if kind == "vb" else "random"),
                        "parallelism": "rows/cols split x%d, RCCL all-gather of factor blocks" % world if world > 1 else "single GPU",
+                       "rccl_ranks": int(cr.value) if ck.value == 1 else 0,
+                       "communicator": {0: "none", 1: "rccl", 2: "in-process"}[int(ck.value)] + " (%d ranks by its own count, world %d)" % (cr.value, world),
                        "samples": ("handed to the host every iteration (all_U/all_V: %.1f MiB per iteration, page-locked arrays, copy stream)" % (
                                        4.0 * (I * K + J * Wc + (K * Wc if kind == "bnmtf" else 0)) / 2 ** 20)) if with_samples else
                                   ("none (the variational run() stores no samples)" if kind == "vb" else "device-resident (--no-samples)")},

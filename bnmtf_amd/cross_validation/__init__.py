@@ -7,7 +7,8 @@ Same class names, constructor arguments, methods and log-file lines as the refer
 (line_search_bnmf.LineSearch, grid_search_bnmtf.GridSearch, greedy_search_bnmtf.GreedySearch,
 line_search_cross_validation.LineSearchCrossValidation, greedy_search_cross_validation.GreedySearchCrossValidation,
 matrix_cross_validation.MatrixCrossValidation,
-parallel_matrix_cross_validation.ParallelMatrixCrossValidation, mask.*); build-only extras are keyword-only
+parallel_matrix_cross_validation.ParallelMatrixCrossValidation,
+nested_matrix_cross_validation.MatrixNestedCrossValidation, mask.*); build-only extras are keyword-only
 (`pool=`, a ReplicaPool)."""
 from . import mask
 from .replicas import ReplicaPool
@@ -18,6 +19,7 @@ from .line_search_cross_validation import LineSearchCrossValidation
 from .greedy_search_cross_validation import GreedySearchCrossValidation
 from .matrix_cross_validation import MatrixCrossValidation
 from .parallel_matrix_cross_validation import ParallelMatrixCrossValidation
+from .nested_matrix_cross_validation import MatrixNestedCrossValidation
 
 __all__ = ["mask", "ReplicaPool", "LineSearch", "GridSearch", "GreedySearch", "LineSearchCrossValidation", "GreedySearchCrossValidation",
-           "MatrixCrossValidation", "ParallelMatrixCrossValidation"]
+           "MatrixCrossValidation", "ParallelMatrixCrossValidation", "MatrixNestedCrossValidation"]

@@ -1122,6 +1122,7 @@ int bnmtf_set_profiling(bnmtf_handle h, int enable) {
   return BNMTF_OK;
 }
 int bnmtf_set_sweep_path(bnmtf_handle h, int fast) { h->use_fast = fast != 0; h->ho_regions_current = false; return BNMTF_OK; }
+int bnmtf_comm_info(bnmtf_handle h, int* kind, int* ranks) { return comm_info(h->comm, kind, ranks); }
 int bnmtf_has_experiments(void) {
 #ifdef BNMTF_EXPERIMENTS
   return 1;

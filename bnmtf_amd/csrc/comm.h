@@ -12,6 +12,7 @@ struct Comm;
 int comm_unique_id(uint8_t out[128]);
 int comm_create(Comm** out, const uint8_t id[128], int rank, int world, hipStream_t st);
 void comm_destroy(Comm* c);
+int comm_info(const Comm* c, int* kind, int* ranks);    // kind: 0 no communicator, 1 RCCL, 2 in-process transport; ranks as the communicator reports them
 // gather every rank's freshly drawn block of X ([nglob][KP], rank r owns rows
 // [nglob*r/world, nglob*(r+1)/world)) in place (the caller re-lays it out afterwards).
 int comm_allgather_factor(Comm* c, float* X, int KP, int nglob, int world, hipStream_t st);

@@ -29,6 +29,7 @@ struct Api {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;     // optional
   bool ok = false;
 };
 Api g_api;
@@ -57,6 +58,7 @@ int load_api() {
             sym(g_api.GroupStart, "ncclGroupStart") && sym(g_api.GroupEnd, "ncclGroupEnd") &&
             sym(g_api.GetErrorString, "ncclGetErrorString");
   if (!ok) { set_error("librccl is missing a required symbol"); return BNMTF_ECOMM; }
+  (void)sym(g_api.CommCount, "ncclCommCount");
   g_api.ok = true;
   return BNMTF_OK;
 }
@@ -100,6 +102,16 @@ struct Comm {
   std::string local_key;
   int rank = 0, world = 1;
 };
+
+// what the communicator itself says: 0 none, 1 RCCL, 2 the in-process transport; its rank count as RCCL (ncclCommCount) reports it
+int comm_info(const Comm* c, int* kind, int* ranks) {
+  *kind = 0; *ranks = 1;
+  if (!c) return BNMTF_OK;
+  if (c->local) { *kind = 2; *ranks = c->world; return BNMTF_OK; }
+  *kind = 1; *ranks = c->world;
+  if (c->comm && g_api.CommCount) { int n = 0; if (g_api.CommCount(c->comm, &n) == ncclSuccess) *ranks = n; }
+  return BNMTF_OK;
+}
 
 int comm_unique_id(uint8_t out[128]) {
   CHK(load_api());

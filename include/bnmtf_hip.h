@@ -246,6 +246,9 @@ BNMTF_API int bnmtf_set_sweep_path(bnmtf_handle h, int fast);
 /* the one-launch path for small BNMF models (K <= 32, I, J <= 1024, factors within one CU's LDS; run() = one launch):
  * on = 0 sends this handle's runs down the multi-launch path instead (tests, A/B).  Default 1.  Same chain either way up to
  * fp32 summation order.  bnmtf_is_small: would the next bnmf_gibbs_run of this handle take it? */
+/* the handle's communicator as it reports itself: kind 0 none (one GPU), 1 RCCL (ranks = ncclCommCount), 2 the in-process test
+ * transport; bench.py prints both next to its own world size */
+BNMTF_API int bnmtf_comm_info(bnmtf_handle h, int* kind, int* ranks);
 /* 1 when the library was built with `make EXPERIMENTS=1`: the measured-and-not-adopted kernels (two unit groups taking turns,
  * BNMTF_TURNS=1; two 8-wave blocks per CU, BNMTF_TWIN=1; the f32-MFMA contraction, BNMTF_GEMM=f32 -- DESIGN.md section 7) are
  * compiled in and their switches honoured.  The shipped build has none of them. */

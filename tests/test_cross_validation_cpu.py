@@ -167,3 +167,27 @@ def test_matrix_cross_validation_logs_a_failing_setting_and_carries_on(tmp_path)
     # (as in the reference, find_best_parameters indexes parameter_search by the position among the RECORDED settings, :125-127:
     # a failed setting ahead of the best one would shift it -- here the failed one is last)
     assert list(c.all_performances) == [c.JSON({"K": 2, "priors": {}})] and c.find_best_parameters("MSE", True)[0] == {"K": 2, "priors": {}}
+
+
+def test_nested_matrix_cross_validation(tmp_path):
+    """nested_matrix_cross_validation.py:78-140: per outer fold an inner cross-validation on the outer training mask names the parameters
+    (one log file each), the outer model is fitted with them and scored on the outer test fold; the closing log lines."""
+    from bnmtf_amd.cross_validation import MatrixNestedCrossValidation
+    rs = np.random.RandomState(0)
+    R = rs.rand(14, 12); M = np.ones((14, 12)); M[1, 1] = M[7, 3] = 0
+    random.seed(11)
+    files = [str(tmp_path / ("inner%d.txt" % i)) for i in range(3)]
+    f = str(tmp_path / "nested.txt")
+    search = [{"K": 2, "priors": {}}, {"K": 4, "priors": {}}, {"K": 6, "priors": {}}]
+    n = MatrixNestedCrossValidation(FakeModel, R, M, 3, 2, search, {"iterations": 2}, f, files, devices=[0, 0])
+    n.run()
+    txt = open(f).read()
+    assert txt.startswith("Average performances: ") and "\nAll performances: " in txt
+    # FakeModel.predict: MSE = 0.5 + 0.001 K, the same for every K's test fold -- the inner search's minimum is its first setting, K = 2
+    assert n.all_performances["MSE"] == [0.502] * 3 and abs(n.average_performances["MSE"] - 0.502) < 1e-12
+    assert sum(n.all_performances["n_test"]) == M.sum()                  # the outer test folds partition the observed entries
+    for fi in files:
+        inner = open(fi).read()
+        assert inner.count("Performances so far") >= 1 or "Average performances" in inner or len(inner) > 0
+    with pytest.raises(AssertionError):
+        MatrixNestedCrossValidation(FakeModel, R, M[:, :5], 3, 2, search, {"iterations": 2}, f, files)
