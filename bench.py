@@ -298,7 +298,7 @@ def main_cv(a, w):
         with tempfile.NamedTemporaryFile("w", suffix=".txt") as f:
             cv = LineSearchCrossValidation(classifier=bnmtf_amd.bnmf_gibbs_optimised, R=R, M=M, values_K=w["values_K"], folds=w["folds"], priors=PRI2,
                                            init_UV="random", iterations=its, restarts=1, quality_metric="AIC", file_performance=f.name, pool=pool, seed=1)
-            pool.map(_noop, [{} for _ in range(s)])            # workers up (process start + library load are not the job)
+            pool.map(_warm, [{} for _ in range(s)])            # workers up, library loaded, GPU context made: not the job
             t0 = time.perf_counter(); cv.run(burn_in=burn, thinning=thin); dt = time.perf_counter() - t0
         pool.close()
         nmodels = w["folds"] * len(w["values_K"]) + w["folds"]
@@ -314,7 +314,11 @@ def main_cv(a, w):
     print(json.dumps(out)); sys.stdout.flush()
 
 
-def _noop(job, shared):
+def _warm(job, shared):
+    import bnmtf_amd
+    R, M = _small_problem(dict(kind="bnmf", I=40, J=30, K=3, missing=0.1))
+    m = bnmtf_amd.bnmf_gibbs_optimised(R, M, 3, PRI2, seed=1, verbose=False, device=job.get("device", 0))
+    m.initialise("random"); m.run(2, store_samples=False); m.close()
     return 0
 
 

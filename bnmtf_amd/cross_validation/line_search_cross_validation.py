@@ -41,6 +41,10 @@ class LineSearchCrossValidation:
         pool.shared.setdefault("R", self.R)
         try:
             # every (fold, K, restart) of the line searches at once
+            def final_jobs(fi, K):
+                return [dict(classifier=self.classifier, args=(K, self.priors), init={"init": self.init_UV}, iterations=self.iterations,
+                             burn_in=burn_in, thinning=thinning, minimum_TN=minimum_TN, M=folds_training[fi], test=folds_test[fi], metrics=["loglikelihood"],
+                             seed=None if self.seed is None else self.seed + 15485863 + 104729 * fi + r) for r in range(self.restarts)]
             jobs = []
             for fi, train in enumerate(folds_training):
                 for ki, K in enumerate(self.values_K):
@@ -48,7 +52,18 @@ class LineSearchCrossValidation:
                         jobs.append(dict(classifier=self.classifier, args=(K, self.priors), init={"init": self.init_UV}, iterations=self.iterations,
                                          burn_in=burn_in, thinning=thinning, minimum_TN=minimum_TN, M=train, test=None, metrics=METRICS,
                                          seed=None if self.seed is None else self.seed + 104729 * fi + 7919 * ki + r))
-            res = pool.map(fit_model, jobs)
+            # A pool that fits its jobs as ONE device batch (ReplicaPool(batched=True): small models are a block each, a GPU has 256
+            # CUs) takes the folds' final models along with the search -- for EVERY candidate K, the ones of the losing K are dropped:
+            # the job's wall time is one batch instead of two.  Only with explicit seeds (each job then seeds its own streams; with
+            # the global NumPy stream the extra models would shift every later draw).
+            speculative = bool(getattr(pool, "batched", False)) and self.seed is not None
+            n_search = len(jobs)
+            if speculative:
+                for fi in range(self.folds):
+                    for K in self.values_K:
+                        jobs += final_jobs(fi, K)
+            res_all = pool.map(fit_model, jobs)
+            res = res_all[:n_search]
             best_K = []
             for fi in range(self.folds):
                 vals = []
@@ -64,13 +79,13 @@ class LineSearchCrossValidation:
                 self.fout.write("Best K for fold %s: %s.\n" % (fi + 1, best_K[-1]))
                 self.fout.flush()
             # the final models of every fold (restarts each), scored on the held-out entries
-            jobs = []
-            for fi, (train, test) in enumerate(zip(folds_training, folds_test)):
-                for r in range(self.restarts):
-                    jobs.append(dict(classifier=self.classifier, args=(best_K[fi], self.priors), init={"init": self.init_UV}, iterations=self.iterations,
-                                     burn_in=burn_in, thinning=thinning, minimum_TN=minimum_TN, M=train, test=test, metrics=["loglikelihood"],
-                                     seed=None if self.seed is None else self.seed + 15485863 + 104729 * fi + r))
-            res = pool.map(fit_model, jobs)
+            if speculative:
+                res = []
+                for fi in range(self.folds):
+                    o = n_search + (fi * len(self.values_K) + list(self.values_K).index(best_K[fi])) * self.restarts
+                    res += res_all[o:o + self.restarts]
+            else:
+                res = pool.map(fit_model, [job for fi in range(self.folds) for job in final_jobs(fi, best_K[fi])])
         finally:
             if own:
                 pool.close()

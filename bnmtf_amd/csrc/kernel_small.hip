@@ -561,7 +561,7 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
             const int nrej = cnt[cur];
             if (nrej == 0) break;
             int W = NT / nrej;
-            W = W >= 4 ? 4 : (W >= 2 ? 2 : 1);
+            W = W >= 64 ? 16 : (W >= 4 ? 4 : (W >= 2 ? 2 : 1));          // (a handful of stragglers: 16 candidates each, one round)
             if ((tq & ~63) < nrej * W) {
               const int li = tq / W, c = tq & (W - 1);
               const bool active = li < nrej;

@@ -262,3 +262,26 @@ def test_the_slot_classes_above_32_follow_the_oracle(miss):
     b.run(10)
     p = b.predict_while_running()
     assert abs(p["MSE"] - b.all_performances['MSE'][-1]) < 5e-5 * p["MSE"]
+
+
+def test_batched_line_search_cross_validation_takes_the_final_models_along(tmp_path):
+    """LineSearchCrossValidation on a batched pool with an explicit seed: the folds' final models ride in the search's batch (for
+    every candidate K; the losing ones are dropped) -- one device call instead of two, the same folds, ranks and scores."""
+    import random
+    import re
+    from bnmtf_amd.cross_validation import LineSearchCrossValidation, ReplicaPool
+    R, M, _, _ = generate_bnmf(50, 40, 3, 0.1, seed_data=7, seed_mask=8)
+    out = []
+    for batched in (False, True):
+        random.seed(5); np.random.seed(5)
+        f = str(tmp_path / ("ls%d.txt" % batched))
+        pool = ReplicaPool(devices=[0], shared={"R": np.asarray(R, dtype=float)}, batched=batched)
+        cv = LineSearchCrossValidation(classifier=bnmf_gibbs_optimised, R=R, M=M, values_K=[2, 3, 5], folds=3, priors=PRI, init_UV="random",
+                                       iterations=60, restarts=2, quality_metric="AIC", file_performance=f, pool=pool, seed=9)
+        cv.run(burn_in=30, thinning=2)
+        pool.close()
+        txt = open(f).read()
+        out.append((re.findall(r"Best K for fold \d+: (\d+)\.", txt), cv.performances))
+    assert out[0][0] == out[1][0] and len(out[0][0]) == 3
+    for m in ("MSE", "R^2", "Rp"):
+        np.testing.assert_allclose(out[0][1][m], out[1][1][m], rtol=1e-10)
