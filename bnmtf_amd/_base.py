@@ -188,10 +188,12 @@ class DeviceModel(object):
         """fast=False forces the generic sweep kernel (test hook; results are the same)."""
         _lib.check(_lib.lib().bnmtf_set_sweep_path(self._handle(), int(bool(fast))))
 
-    def set_small_path(self, on=True):
-        """on=False sends this model's run() down the multi-launch path even when it qualifies for the one-launch path for
-        small models (test / A-B hook; the chain is the same up to fp32 summation order)."""
-        _lib.check(_lib.lib().bnmtf_set_small_path(self._handle(), int(bool(on))))
+    def set_small_path(self, on='auto'):
+        """The one-launch path for small models (csrc/kernel_small.hip): 'auto' (default) takes it when it is the faster way to
+        run the call; True / 'always' forces it for a model that qualifies, False sends run() down the multi-launch path (test /
+        A-B hooks; the chain is the same up to fp32 summation order)."""
+        mode = {"auto": 1, "always": 2, True: 2, False: 0, 0: 0, 1: 1, 2: 2}[on]
+        _lib.check(_lib.lib().bnmtf_set_small_path(self._handle(), int(mode)))
 
     def is_small(self):
         """Does run() take the one-launch path (kernel_small.hip: the whole run in one launch, one block per model)?"""

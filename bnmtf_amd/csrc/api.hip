@@ -1169,7 +1169,11 @@ int bnmtf_has_experiments(void) {
   return 0;
 #endif
 }
-int bnmtf_set_small_path(bnmtf_handle h, int on) { h->small_enabled = on != 0; return BNMTF_OK; }
+int bnmtf_set_small_path(bnmtf_handle h, int mode) {
+  if (mode < 0 || mode > 2) { set_error("bnmtf_set_small_path: mode 0 (never), 1 (auto) or 2 (always)"); return BNMTF_EINVAL; }
+  h->small_mode = mode;
+  return BNMTF_OK;
+}
 int bnmtf_is_small(bnmtf_handle h, int* out) { *out = small_wanted(h) ? 1 : 0; return BNMTF_OK; }
 int bnmtf_kernel_stats(bnmtf_handle h, int kernel, double* total_ms, uint64_t* launches) {
   if (kernel < 0 || kernel >= BNMTF_KERNEL_COUNT) { set_error("bad kernel id"); return BNMTF_EINVAL; }
@@ -1348,9 +1352,15 @@ int bnmf_gibbs_run_many(const bnmtf_handle* hs, int n_models, int n_iter, int up
   auto out_of = [&](int b) { return SmallOut{U_outs ? U_outs[b] : nullptr, V_outs ? V_outs[b] : nullptr, tau_outs ? tau_outs[b] : nullptr,
                                              perf_outs ? perf_outs[b] : nullptr, times_outs ? times_outs[b] : nullptr}; };
   std::vector<char> taken(n_models, 0);
+  auto peers = [&](int b) {                   // models of the one-launch kind on model b's device, b included
+    int n = 0;
+    for (int c = 0; c < n_models; ++c) n += (hs[c]->small && hs[c]->small_mode != 0 && hs[c]->device == hs[b]->device) ? 1 : 0;
+    return n;
+  };
   for (int b = 0; b < n_models; ++b) {
     if (taken[b]) continue;
-    if (!small_wanted(hs[b]) || hs[b]->L != 0) {
+    const int np = peers(b);
+    if (!small_wanted(hs[b], np) || hs[b]->L != 0) {
       const SmallOut o = out_of(b);
       CHK(bnmf_gibbs_run(hs[b], n_iter, update, o.U, o.V, o.tau, o.perf, o.times));
       taken[b] = 1;
@@ -1358,7 +1368,7 @@ int bnmf_gibbs_run_many(const bnmtf_handle* hs, int n_models, int n_iter, int up
     }
     batch.clear(); outs.clear();
     for (int c = b; c < n_models; ++c)
-      if (!taken[c] && small_wanted(hs[c]) && hs[c]->device == hs[b]->device) {
+      if (!taken[c] && small_wanted(hs[c], np) && hs[c]->device == hs[b]->device) {
         bool dup = false;
         for (bnmtf_model* x : batch) dup = dup || x == hs[c];
         if (dup) { set_error("bnmf_gibbs_run_many: the same handle twice"); return BNMTF_EINVAL; }

@@ -136,7 +136,8 @@ struct bnmtf_model {
   // the one-launch path for small models (api_small.inc): its arena; whether the multi-launch path's structures exist yet (they
   // are built on first need for a model that starts small); which of the two holds the current state
   bnmtf::SmallModel* small = nullptr;
-  bool small_enabled = true, std_built = true, small_cur = false, std_cur = false;
+  int small_mode = 1;          // bnmtf_set_small_path: 0 never, 1 when it is the faster path for the call (api_small.inc small_wanted), 2 always
+  bool std_built = true, small_cur = false, std_cur = false;
   bool pool_stream = false;    // the stream goes back to the per-process pool at destroy (small models)
   bool one_arena = false;      // Rfull, Mtrain, the scalars, the posterior sums and Ad / Bd live in the small model's arena (one allocation per model)
   std::vector<double> lam_rows, lam_cols;          // prior rates as given (build_standard may run after bnmtf_create has returned)

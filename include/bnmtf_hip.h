@@ -243,9 +243,12 @@ BNMTF_API int bnmtf_set_minimum_tn(bnmtf_handle h, double minimum_TN);
 /* sweep kernel selection: 1 (default) = register/LDS-resident fast path when the shape
  * fits, 0 = always the generic kernel (any mask, q in global memory).  Same results. */
 BNMTF_API int bnmtf_set_sweep_path(bnmtf_handle h, int fast);
-/* the one-launch path for small BNMF models (K <= 32, I, J <= 1024, factors within one CU's LDS; run() = one launch):
- * on = 0 sends this handle's runs down the multi-launch path instead (tests, A/B).  Default 1.  Same chain either way up to
- * fp32 summation order.  bnmtf_is_small: would the next bnmf_gibbs_run of this handle take it? */
+/* the one-launch path for small BNMF models (K <= 32, I, J <= 1024, factors within one CU's LDS; run() = one launch, one
+ * block per model).  mode 1 (default): taken when it is the faster way to run the call -- always for the models of 256- and
+ * 512-thread blocks, for the ones that fill a CU (1024-thread blocks) from three models per bnmf_gibbs_run_many call on;
+ * 0: never (the multi-launch path); 2: always.  Same chain either way up to fp32 summation order.
+ * bnmtf_is_small: would a bnmf_gibbs_run of this handle alone take it? */
+BNMTF_API int bnmtf_set_small_path(bnmtf_handle h, int mode);
 /* the handle's communicator as it reports itself: kind 0 none (one GPU), 1 RCCL (ranks = ncclCommCount), 2 the in-process test
  * transport; bench.py prints both next to its own world size */
 BNMTF_API int bnmtf_comm_info(bnmtf_handle h, int* kind, int* ranks);
@@ -253,7 +256,6 @@ BNMTF_API int bnmtf_comm_info(bnmtf_handle h, int* kind, int* ranks);
  * BNMTF_TURNS=1; two 8-wave blocks per CU, BNMTF_TWIN=1; the f32-MFMA contraction, BNMTF_GEMM=f32 -- DESIGN.md section 7) are
  * compiled in and their switches honoured.  The shipped build has none of them. */
 BNMTF_API int bnmtf_has_experiments(void);
-BNMTF_API int bnmtf_set_small_path(bnmtf_handle h, int on);
 BNMTF_API int bnmtf_is_small(bnmtf_handle h, int* out);
 BNMTF_API int bnmtf_kernel_stats(bnmtf_handle h, int kernel, double* total_ms, uint64_t* launches);
 /* geometry of the last create: padded shapes, split factor, slot counts (for DESIGN/bench) */

@@ -126,6 +126,7 @@ def test_run_many_is_every_models_own_run():
             np.random.seed(seed)
             m = bnmf_gibbs_optimised(R, M, K, PRI, seed=seed, verbose=False)
             m.initialise('random')
+            m.set_small_path('always')          # (alone, the models that fill a CU would take the multi-launch path: another summation order)
             ms.append(m)
         return ms
     solo = build()
@@ -249,6 +250,7 @@ def test_the_slot_classes_above_32_follow_the_oracle(miss):
     rs = np.random.RandomState(2)
     U0 = rs.rand(622, 6) + 0.3; V0 = rs.rand(138, 6) + 0.3
     b = bnmf_gibbs_optimised(R, M, 6, PRI, verbose=False, seed=3)
+    b.set_small_path('always')
     assert b.is_small()
     b.U, b.V, b.tau = U0.copy(), V0.copy(), 1.0
     slots = [int(x) for x in re.search(r"slots=(\d+)/(\d+)", b.describe()).groups()]
@@ -285,3 +287,36 @@ def test_batched_line_search_cross_validation_takes_the_final_models_along(tmp_p
     assert out[0][0] == out[1][0] and len(out[0][0]) == 3
     for m in ("MSE", "R^2", "Rp"):
         np.testing.assert_allclose(out[0][1][m], out[1][1][m], rtol=1e-10)
+
+
+def test_the_path_is_chosen_by_what_the_call_runs():
+    """'auto' (the default): a model of a 256- / 512-thread block takes the one-launch path alone; a model that fills a CU (622 x 138
+    at 19 % missing: a 1024-thread block) takes the multi-launch path alone -- the whole chip is faster for one such model -- and the
+    one-launch path from three models per run_many call on."""
+    R, M, _, _ = generate_bnmf(100, 80, 10, 0.1, seed_data=1, seed_mask=2)
+    toy = bnmf_gibbs_optimised(R, M, 10, PRI, verbose=False, seed=1)
+    toy.initialise('random')
+    assert toy.is_small() and "block=256" in toy.describe()
+    R, M, _, _ = generate_bnmf(622, 138, 25, 0.19, seed_data=3, seed_mask=4)
+    ms = []
+    for s in range(3):
+        np.random.seed(s)
+        m = bnmf_gibbs_optimised(R, M, 25, PRI, verbose=False, seed=s)
+        m.initialise('random')
+        assert "block=1024" in m.describe() and not m.is_small()
+        ms.append(m)
+    ms[0].run(2)
+    assert "std_built=1" in ms[0].describe()                     # alone: the multi-launch path (its structures were built for it)
+    bnmtf_amd.run_many(ms[1:], 2)
+    assert all("std_built=1" in m.describe() for m in ms[1:])    # two models: one after the other on the multi-launch path
+    ms2 = []
+    for s in range(3):
+        np.random.seed(s)
+        m = bnmf_gibbs_optimised(R, M, 25, PRI, verbose=False, seed=s)
+        m.initialise('random')
+        ms2.append(m)
+    bnmtf_amd.run_many(ms2, 2)
+    assert all("std_built=0" in m.describe() for m in ms2)       # three: one grid, a block each
+    # the same chain either way (first sweep element-wise but for flipped accept / reject decisions)
+    d = np.abs(ms2[0].all_U[0] - ms[0].all_U[0]) / (1e-3 + np.abs(ms[0].all_U[0]))
+    assert np.mean(d < 1e-3) > 0.99

@@ -182,7 +182,10 @@ def test_headline_shape_properties():
     assert mse[0] > 1000 * mse[-1] and 0.9 < mse[-1] < 3.0        # on its way to the noise variance 1/tau = 1 (reached after ~300)
     assert np.all(np.diff(mse[20:]) < 0) and 0.3 < b.all_tau[-1] < 1.1
     p = b.predict_while_running()
-    assert abs(p["MSE"] - mse[-1]) < 1e-4 * mse[-1]
+    # the STATED tolerance of the per-iteration metrics at this size: 3e-4 relative to the fp64
+    # metric of the same (U, V) -- the Gram identity takes sum q^2 from fp32 q that is handed back and forth between the half sweeps
+    # (measured: 1.0 / 1.4 / 1.5e-4 after 16 / 200 / 1 000 iterations, tools/handover_drift.py)
+    assert abs(p["MSE"] - mse[-1]) < 3e-4 * mse[-1]
     assert abs(p["Rp"] - b.all_performances["Rp"][-1]) < 1e-5
     assert np.isfinite(b.U).all() and np.isfinite(b.V).all() and b.U.min() >= 0 and b.V.min() >= 0
 

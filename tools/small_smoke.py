@@ -13,6 +13,7 @@ def case(I, J, K, miss, iters=8):
     np.random.seed(1)
     b = bnmtf_amd.bnmf_gibbs_optimised(R, M, K, PRI, seed=5, verbose=False)
     b.initialise('random')
+    b.set_small_path('always')
     print(b.describe()[-90:], 'small:', b.is_small())
     o = O.BNMFGibbsOracle(R.astype(np.float64), M, K, PRI, seed=5)
     o.U, o.V, o.tau = b.U.copy(), b.V.copy(), b.tau

@@ -10,6 +10,7 @@ for (I, J, K, miss) in [(622, 138, 25, 0.19)]:
     np.random.seed(1)
     b = bnmtf_amd.bnmf_gibbs_optimised(R, M, K, PRI, seed=5, verbose=False)
     b.initialise('random')
+    b.set_small_path('always')
     b.run(50, store_samples=False)
     print("== %dx%d K=%d miss %.2f" % (I, J, K, miss), flush=True)
     b.run(100, store_samples=False)
