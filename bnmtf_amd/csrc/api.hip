@@ -502,11 +502,29 @@ struct HandoverScope {
   ~HandoverScope() { h->ho_active = false; }        // (an error return never got to commit(): the regions stay "unknown")
 };
 // ------------------------------------------------------------- step pieces
-static void enqueue_gemm(bnmtf_model* h, Dir& d, const Dir& other, int kid) {
-  ScopedKernelTimer t(h, kid);
+static void enqueue_gemm(bnmtf_model* h, Dir& d, const Dir& other, int kid, int part = 0);
+// part: 0 the whole contraction; 1 only the inner slices that lie inside the rank's OWN block of the other factor (rows
+// [other.n0, other.n0 + other.n): final the moment the rank's sweep ends, before any exchange); 2 the remaining slices
+static void enqueue_gemm(bnmtf_model* h, Dir& d, const Dir& other, int kid, int part) {
   GemmArgs g;
   g.big = d.big; g.ld = d.n_pad; g.X = other.X; g.slabs = d.slabs;
   g.n_pad = d.n_pad; g.split = d.split; g.inner_per_wave = d.ipw; g.tw = d.gemm_tw;
+  const int rows_per_slice = 4 * d.ipw;
+  const int s0 = (other.n0 + rows_per_slice - 1) / rows_per_slice, s1 = std::min(d.split, (other.n0 + other.n) / rows_per_slice);
+  const bool have_local = h->comm && s1 > s0;
+  if (part == 1) {
+    if (!have_local) return;
+    ScopedKernelTimer t(h, kid);
+    g.split0 = s0; g.nsplit = s1 - s0;
+    launch_gemm(g, d.KP, h->stream);
+    return;
+  }
+  ScopedKernelTimer t(h, kid);
+  if (part == 2 && have_local) {
+    if (s0 > 0) { g.split0 = 0; g.nsplit = s0; launch_gemm(g, d.KP, h->stream); }
+    if (s1 < d.split) { g.split0 = s1; g.nsplit = d.split - s1; launch_gemm(g, d.KP, h->stream); }
+    return;
+  }
   launch_gemm(g, d.KP, h->stream);
 }
 // relayout (XT, XT2) + Gram of a factor that was just written
@@ -525,7 +543,11 @@ static void enqueue_post(bnmtf_model* h, Dir& d, bool vb = false) {
 // every rank used to form the whole Gram from the gathered factor), which runs beside the relayout of the gathered factor
 // and the next contraction.  The compute stream waits for the gathered factor here and for the summed Gram in await_gram(),
 // just ahead of its first reader.  Every collective is issued on the ONE exchange stream, in the same order on all ranks.
-static int exchange_factor(bnmtf_model* h, Dir& d) {
+// next / next_kid: the direction whose contraction reads d's factor next.  Its inner slices over this rank's OWN rows of the
+// factor are launched here, ahead of the wait for the other ranks' blocks (they are final, whatever the others send); the
+// remaining slices behind the relayout of the gathered factor.  Every slice writes its own slab and the sweep adds the slabs
+// in slab order, so the chain is the same bits as with one launch.
+static int exchange_factor(bnmtf_model* h, Dir& d, Dir* next = nullptr, int next_kid = 0) {
   if (!h->comm) { enqueue_post(h, d); return BNMTF_OK; }
   // BNMTF_EXCHANGE=serial: every collective on the compute stream, in program order, nothing overlapped -- the fall-back
   // while the two-stream ordering below has not run on a node with several GPUs (round 3's advice; tests/test_rccl_two_process_gpu.py)
@@ -554,6 +576,7 @@ static int exchange_factor(bnmtf_model* h, Dir& d) {
   HIPCHK(hipEventRecord(d.ev_sweep, h->stream));
   launch_post_gram_rows(g, d.n0, d.n0 + d.n, h->stream);             // own rows only: they are final, whatever the others send
   HIPCHK(hipEventRecord(d.ev_gram, h->stream));
+  if (next) enqueue_gemm(h, *next, d, next_kid, 1);
   HIPCHK(hipStreamWaitEvent(h->xchg_stream, d.ev_sweep, 0));
   CHK(comm_allgather_factor(h->comm, d.X, d.KP, d.nglob, h->world, h->xchg_stream));
   HIPCHK(hipEventRecord(d.ev_gathered, h->xchg_stream));
@@ -565,6 +588,7 @@ static int exchange_factor(bnmtf_model* h, Dir& d) {
   HIPCHK(hipStreamWaitEvent(h->stream, d.ev_gathered, 0));
   g.snap = d.snap_dst; g.snapW = d.W; d.snap_dst = nullptr;
   launch_post_layout(g, h->stream);
+  if (next) { enqueue_gemm(h, *next, d, next_kid, 2); next->gemm_ahead = true; }
   return BNMTF_OK;
 }
 // the summed Gram of d (C32, C64, colsum) is about to be read on the compute stream
@@ -1274,7 +1298,8 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
   for (int it = 0; it < n_iter; ++it) {
     CHK(sink.open_slot(it));
     // ---- U columns: P = R~ . V, then the K sequential row-wise updates
-    enqueue_gemm(h, r, c, BNMTF_KERNEL_GEMM_ROWS);
+    if (!r.gemm_ahead) enqueue_gemm(h, r, c, BNMTF_KERNEL_GEMM_ROWS);      // (several GPUs: launched inside the previous iteration's exchange of V)
+    r.gemm_ahead = false;
     CHK(await_gram(h, c));                       // V^T V of the previous iteration's exchange
     {
       ScopedKernelTimer t(h, BNMTF_KERNEL_SWEEP_ROWS);
@@ -1283,10 +1308,11 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
     }
     static const bool snap_compact = getenv("BNMTF_SNAP_COMPACT") != nullptr;      // A/B switch: the packing kernel of round 2
     if (!snap_compact) r.snap_dst = sink.slot_for(it, r.X);         // the sample of U goes out with the relayout (no packing kernel of its own)
-    CHK(exchange_factor(h, r));                  // one GPU: relayout + Gram; several: see exchange_factor
+    CHK(exchange_factor(h, r, &c, BNMTF_KERNEL_GEMM_COLS));        // one GPU: relayout + Gram; several: see exchange_factor
     if (snap_compact) sink.snapshot(it, r.X);
     // ---- V columns: Pv = R~^T . U
-    enqueue_gemm(h, c, r, BNMTF_KERNEL_GEMM_COLS);
+    if (!c.gemm_ahead) enqueue_gemm(h, c, r, BNMTF_KERNEL_GEMM_COLS);
+    c.gemm_ahead = false;
     if (acc_used && it > 0) HIPCHK(hipMemsetAsync(h->acc, 0, 4 * sizeof(double), h->stream));
     CHK(await_gram(h, r));
     {
@@ -1298,7 +1324,7 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
     const bool fast_stats = h->last_sweep_fast;
     if (h->comm && fast_stats) launch_sum_stats(c.stats, c.stats_blocks, h->acc, h->stream);   // fold the slab before the exchange
     if (!snap_compact) c.snap_dst = sink.slot_for(it, c.X);
-    CHK(exchange_factor(h, c));
+    CHK(exchange_factor(h, c, it + 1 < n_iter ? &r : nullptr, BNMTF_KERNEL_GEMM_ROWS));
     if (snap_compact) sink.snapshot(it, c.X);
     if (h->comm) {
       // the three sums of the SSE identity: behind the Gram on the exchange stream (its event covers the fold above)

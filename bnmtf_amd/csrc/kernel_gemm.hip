@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256, WPS) void gemm_kernel(GemmArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, c = lane & 31;
   const int col0 = blockIdx.x * 128;
-  const int s = blockIdx.y;
+  const int s = blockIdx.y + a.split0;
   const int ipw = a.inner_per_wave;
   const size_t r0 = (size_t)(s * 4 + wave) * ipw + h;
 
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, (TW == 4 ? 1 : 2)) void gemm_bf16x3_kernel(Gem
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, c = lane & 31;
   const int col0 = blockIdx.x * (32 * TW);
-  const int s = blockIdx.y;
+  const int s = blockIdx.y + a.split0;
   const int ipw = a.inner_per_wave;
   const size_t r0 = (size_t)(s * 4 + wave) * ipw + 8 * h;
 
@@ -298,7 +298,11 @@ __global__ __launch_bounds__(256, (TW == 4 ? 1 : 2)) void gemm_bf16x3_kernel(Gem
 }
 
 void launch_gemm(const GemmArgs& a, int KP, hipStream_t st) {
-  dim3 grid(a.n_pad / 128, a.split), block(256);
+  // (a launch covers the inner slices [split0, split0 + nsplit): all of them, or -- several GPUs -- first the ones over the rank's
+  // own rows of the factor, the rest once the other ranks' blocks have arrived; every slice writes its own slab either way)
+  const int ns = a.nsplit > 0 ? a.nsplit : a.split;
+  if (ns <= 0) return;
+  dim3 grid(a.n_pad / 128, ns), block(256);
 #ifdef BNMTF_EXPERIMENTS
   const char* mode = getenv("BNMTF_GEMM");                        // "f32": the f32-MFMA kernel (the cross-check of the bf16x3 products: tests/test_contraction_gpu.py); read per launch
   const bool f32 = mode && !strcmp(mode, "f32");
@@ -310,7 +314,7 @@ void launch_gemm(const GemmArgs& a, int KP, hipStream_t st) {
     // TW = 4 column tiles (128 columns) per wave, one wave per SIMD.  TW = 2 with two waves per SIMD (grid n_pad/64) was
     // measured slower: 68-70 us against 60-62 us (the factor operand is split twice as often per MFMA).
     if (KP == 32) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 3, 4>), grid, block, 0, st, a);
-    else if (a.tw == 2) hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, 2>), dim3(a.n_pad / 64, a.split), block, 0, st, a);
+    else if (a.tw == 2) hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, 2>), dim3(a.n_pad / 64, ns), block, 0, st, a);
     else          hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, 4>), grid, block, 0, st, a);
     return;
   }

@@ -21,6 +21,7 @@ struct GemmArgs {
   float* slabs;                      // [split][n_pad][KP]
   int n_pad, split, inner_per_wave;  // inner range of wave w in split s: [(s*4+w)*ipw, +ipw)
   int tw;                            // 32-column tiles per wave: 4 (128 columns) or 2 (64 columns, short output sides)
+  int split0 = 0, nsplit = 0;        // this launch's inner slices [split0, split0 + nsplit) (nsplit = 0: all `split` of them)
 };
 void launch_gemm(const GemmArgs& a, int KP, hipStream_t st);
 

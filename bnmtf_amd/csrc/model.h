@@ -82,6 +82,7 @@ struct Dir {
   hipEvent_t ev_sweep = nullptr, ev_gram = nullptr, ev_gathered = nullptr, ev_gram_all = nullptr;   // exchange_factor (several GPUs)
   float* snap_dst = nullptr;            // set for ONE relayout: where its rows also go, packed [rows][W] (run()'s sample hand-off)
   bool gram_pending = false;            // the summed Gram is still on its way on the exchange stream
+  bool gemm_ahead = false;              // this direction's next contraction was launched inside the other factor's exchange (several GPUs)
   // VB only
   float *mu = nullptr, *tauq = nullptr, *var = nullptr, *S2 = nullptr, *S2T = nullptr;
   float *XS = nullptr, *vb_asq = nullptr, *vb_vsq = nullptr;   // fast VB sweep: (E, S2) pair panels; per (unit, column) sums for the ELBO pieces
