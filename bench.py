@@ -251,7 +251,7 @@ def main_small(a, w):
     m.close()
     # a batch of independent models (different masks / seeds, same shape) in ONE call: what a model search runs
     batch = None
-    if hasattr(bnmtf_amd, "run_many"):
+    if w["kind"] == "bnmf":                  # (run_many takes BNMF Gibbs models; the tri-factorisation has no one-launch kernel)
         batch = {}
         for nb in a.batch:
             ms = []
