@@ -49,7 +49,7 @@ _SIGS = {
     "bnmf_cond_params": ([_P, C.c_int, C.c_int, _P, _P], C.c_int),
     "bnmtf_beta_s": ([_P, C.POINTER(C.c_double)], C.c_int),
     "bnmf_gibbs_run": ([_P, C.c_int, C.c_int, _P, _P, _P, _P, _P], C.c_int),
-    "bnmf_gibbs_run_many": ([_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P], C.c_int),
+    "bnmf_gibbs_run_many": ([_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
     "bnmtf_comm_info": ([_P, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
     "bnmtf_has_experiments": ([], C.c_int),
     "bnmtf_set_small_path": ([_P, C.c_int], C.c_int),

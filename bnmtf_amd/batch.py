@@ -8,6 +8,8 @@ The reference fits the candidates of a model search -- folds x ranks x restarts 
 (csrc/kernel_small.hip), so a list of them is one launch; models that do not qualify are run in turn."""
 import ctypes as C
 
+import numpy as np
+
 from . import _lib
 
 
@@ -21,8 +23,11 @@ def run_many(models, iterations, update='draw', store_samples=True, expectation=
         raise TypeError("run_many takes bnmf_gibbs_optimised models")
     bufs = [m._run_prepare(iterations, store_samples, expectation) for m in models]
     n = len(models)
-    arr = lambda i: (C.c_void_p * n)(*[None if b[i] is None else b[i].ctypes.data for b in bufs])
+    states = [(np.zeros((m.I, m.K)), np.zeros((m.J, m.K)), np.zeros(1)) for m in models]      # what every model ends with
+    arr = lambda xs: (C.c_void_p * n)(*[None if x is None else x.ctypes.data for x in xs])
     hs = (C.c_void_p * n)(*[m._handle().value for m in models])
     _lib.check(_lib.lib().bnmf_gibbs_run_many(hs, n, bufs[0][0], _lib.UPDATE_MODE if update == 'mode' else _lib.UPDATE_DRAW,
-                                              arr(1), arr(2), arr(3), arr(4), arr(5)))
-    return [m._run_finish(b, store_samples) for m, b in zip(models, bufs)]
+                                              arr([b[1] for b in bufs]), arr([b[2] for b in bufs]), arr([b[3] for b in bufs]),
+                                              arr([b[4] for b in bufs]), arr([b[5] for b in bufs]),
+                                              arr([s[0] for s in states]), arr([s[1] for s in states]), arr([s[2] for s in states])))
+    return [m._run_finish(b, store_samples, state=s) for m, b, s in zip(models, bufs, states)]

@@ -98,9 +98,13 @@ class bnmf_gibbs_optimised(DeviceModel):
         V_out = _lib.sample_buffer((it, self.J, self.K)) if store_samples else None
         return (it, U_out, V_out, np.zeros(it), np.zeros((it, 3)), np.zeros(it))
 
-    def _run_finish(self, bufs, store_samples):
+    def _run_finish(self, bufs, store_samples, state=None):
         it, U_out, V_out, taus, perf, times = bufs
-        self._pull()
+        if state is None:
+            self._pull()
+        else:                       # (run_many fetched the final states of the whole batch with one synchronisation)
+            self.U, self.V, self.tau = state[0], state[1], float(state[2][0])
+            self._device_state = (self._h, self.U.copy(), self.V.copy(), self.tau)
         # the samples are what the device drew: fp32 (the reference's arrays are fp64; every reduction below sums in fp64)
         self.all_U = U_out if store_samples else np.zeros((0, self.I, self.K))
         self.all_V = V_out if store_samples else np.zeros((0, self.J, self.K))

@@ -551,8 +551,8 @@ static int exchange_factor(bnmtf_model* h, Dir& d, Dir* next = nullptr, int next
   if (!h->comm) { enqueue_post(h, d); return BNMTF_OK; }
   // BNMTF_EXCHANGE=serial: every collective on the compute stream, in program order, nothing overlapped -- the fall-back
   // while the two-stream ordering below has not run on a node with several GPUs (round 3's advice; tests/test_rccl_two_process_gpu.py)
-  static const bool serial = [] { const char* e = getenv("BNMTF_EXCHANGE"); return e && !strcmp(e, "serial"); }();
-  if (serial) {
+  const char* xe = getenv("BNMTF_EXCHANGE");            // (read per call: the sharded tests run both orderings in one process)
+  if (xe && !strcmp(xe, "serial")) {
     PostArgs g;
     memset(&g, 0, sizeof(g));
     g.X = d.X; g.rows = d.nglob; g.KP = d.KP; g.XT = d.XT; g.ldT = d.ldT; g.XT2 = d.XT2; g.ld2 = d.ldT;
@@ -1271,7 +1271,7 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
   HIPCHK(hipSetDevice(h->device));
   if (update < 0 || update > BNMTF_UPDATE_ICM) { set_error("unknown update rule"); return BNMTF_EINVAL; }
   if (small_wanted(h)) {                       // a small model: the whole call is one launch (kernel_small.hip)
-    const SmallOut o{U_out, V_out, tau_out, perf_out, times_out};
+    SmallOut o{U_out, V_out, tau_out, perf_out, times_out};
     return small_run_many(&h, 1, n_iter, update, &o);
   }
   CHK(ensure_std(h));
@@ -1369,14 +1369,16 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
 }
 
 int bnmf_gibbs_run_many(const bnmtf_handle* hs, int n_models, int n_iter, int update, float* const* U_outs, float* const* V_outs,
-                        double* const* tau_outs, double* const* perf_outs, double* const* times_outs) {
+                        double* const* tau_outs, double* const* perf_outs, double* const* times_outs,
+                        double* const* U_final, double* const* V_final, double* const* tau_final) {
   if (n_models < 0 || n_iter < 0) { set_error("negative count"); return BNMTF_EINVAL; }
   if (n_models == 0 || n_iter == 0) return BNMTF_OK;
   if (update < 0 || update > BNMTF_UPDATE_ICM) { set_error("unknown update rule"); return BNMTF_EINVAL; }
   // models of the one-launch path go down in one grid per device; the others run one after the other
   std::vector<bnmtf_model*> batch; std::vector<SmallOut> outs;
   auto out_of = [&](int b) { return SmallOut{U_outs ? U_outs[b] : nullptr, V_outs ? V_outs[b] : nullptr, tau_outs ? tau_outs[b] : nullptr,
-                                             perf_outs ? perf_outs[b] : nullptr, times_outs ? times_outs[b] : nullptr}; };
+                                             perf_outs ? perf_outs[b] : nullptr, times_outs ? times_outs[b] : nullptr,
+                                             U_final ? U_final[b] : nullptr, V_final ? V_final[b] : nullptr, tau_final ? tau_final[b] : nullptr}; };
   std::vector<char> taken(n_models, 0);
   auto peers = [&](int b) {                   // models of the one-launch kind on model b's device, b included
     int n = 0;
@@ -1389,6 +1391,7 @@ int bnmf_gibbs_run_many(const bnmtf_handle* hs, int n_models, int n_iter, int up
     if (!small_wanted(hs[b], np) || hs[b]->L != 0) {
       const SmallOut o = out_of(b);
       CHK(bnmf_gibbs_run(hs[b], n_iter, update, o.U, o.V, o.tau, o.perf, o.times));
+      if (o.U_final || o.V_final || o.tau_final) CHK(bnmf_get_state(hs[b], o.U_final, o.V_final, o.tau_final));
       taken[b] = 1;
       continue;
     }

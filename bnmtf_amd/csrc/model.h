@@ -109,6 +109,7 @@ struct SmallModel {
   // per-call buffers, grown on demand: [gunit | rec | clock] and the samples
   char* call_buf = nullptr; size_t call_cap = 0;
   float* smp = nullptr; size_t smp_cap = 0;
+  float* state_host = nullptr; size_t state_host_cap = 0;    // page-locked staging of a batch's final states (owned by the call's first model)
 };
 
 }  // namespace bnmtf

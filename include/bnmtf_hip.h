@@ -138,9 +138,12 @@ BNMTF_API int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_ou
  * parallel_matrix_cross_validation.py:40-74).  Models on the one-launch path (small models: DESIGN.md section 4,
  * kernel_small.hip -- one block per model, the whole run in one launch) that share a device go down in ONE grid; any other
  * handle in the list is run by bnmf_gibbs_run in turn.  Every model draws exactly the chain its own bnmf_gibbs_run call
- * would draw.  The output arrays are arrays of n_models pointers (or NULL), each as in bnmf_gibbs_run. */
+ * would draw.  The output arrays are arrays of n_models pointers (or NULL), each as in bnmf_gibbs_run; U_final [I][K], V_final [J][K],
+ * tau_final [1] (doubles): the state each model ends with -- what bnmf_get_state would return, fetched for the whole batch with one
+ * synchronisation. */
 BNMTF_API int bnmf_gibbs_run_many(const bnmtf_handle* hs, int n_models, int n_iter, int update, float* const* U_outs, float* const* V_outs,
-                        double* const* tau_outs, double* const* perf_outs, double* const* times_outs);
+                        double* const* tau_outs, double* const* perf_outs, double* const* times_outs,
+                        double* const* U_final, double* const* V_final, double* const* tau_final);
 
 /* ---- BNMTF Gibbs (bnmtf_gibbs_optimised.py) ---------------------------- */
 BNMTF_API int bnmtf_set_state(bnmtf_handle h, const double* F, const double* S, const double* G, double tau);

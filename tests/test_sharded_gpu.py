@@ -41,8 +41,13 @@ def _run_ranks(R, M, K, U0, V0, tau0, world, iters, update, token):
     return out
 
 
+@pytest.mark.parametrize("exchange", ["streams", "serial"])
 @pytest.mark.parametrize("I,J,K,world", [(640, 512, 24, 2), (515, 389, 40, 3)])
-def test_sharded_run_equals_single_rank_run(I, J, K, world):
+def test_sharded_run_equals_single_rank_run(monkeypatch, I, J, K, world, exchange):
+    """exchange = "streams": the collectives on the exchange stream beside the own-rows Gram, the relayout and the contraction's
+    own-rows slices (the default); "serial" (BNMTF_EXCHANGE=serial): all of them on the compute stream in program order."""
+    if exchange == "serial":
+        monkeypatch.setenv("BNMTF_EXCHANGE", "serial")
     R, M, _, _ = generate_bnmf(I, J, K, 0.12, seed_data=5, seed_mask=6)
     rs = np.random.RandomState(3)
     U0 = rs.exponential(1.0, (I, K)); V0 = rs.exponential(1.0, (J, K)); tau0 = 0.7
