@@ -274,8 +274,11 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
       if (!d.use_wide) return pi;
       const int r = pi / wide_blocks, c = pi % wide_blocks;
       const int blk = (r & 1) ? wide_blocks - 1 - c : c;
+      // rank 0 = the pairs with the most slots.  The lightest quarter goes to waves 0-3, the waves of the sampler window (sampler
+      // and table filler: sweep_chip.inc, RL) -- their role needs registers the heaviest slot class does not have, and a light
+      // wave reaches the column's first barrier early, with the word-only half of its candidate done by the time the others arrive
       const int t = r >> 2, sx = r & 3;
-      return blk * 16 + 4 * t + ((t & 1) ? 3 - sx : sx);
+      return blk * 16 + 4 * (3 - t) + ((t & 1) ? 3 - sx : sx);
     };
     std::vector<int> umap((size_t)d.f_npairs * 2, -1);
     std::vector<uint32_t> pE(d.f_npairs, 0u), pB(d.f_npairs, 0u);
