@@ -45,7 +45,7 @@ void launch_sweep_fast(const SweepArgs& a, const FastArgs& f, hipStream_t st) {
 #endif
   if (f.nch == 2) launch_chip_two_chunks(a, f, st);                 // an inner extent of two LDS panels (9 185 .. 18 368)
   else if (f.nw == 2 || f.nw == 4) launch_sweep_small(a, f, st);    // kernel_sweep_small.hip
-  else if (chip_split_enabled()) launch_chip<8, 0, 1>(a, f, st);
+  else if (chip_split_enabled() || a.mode == kSweepVB) launch_chip<8, 0, 1>(a, f, st);      // (the variational sweep: split-sampler shapes only)
   else launch_chip<8, 0, 0>(a, f, st);
 }
 

@@ -396,6 +396,42 @@ __global__ __launch_bounds__(256) void vb_pieces_kernel(int n, int n0, int KP, i
   if (threadIdx.x < 6) out[(size_t)blockIdx.x * 8 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// the same with sum_miss S2other / sum_miss Eother^2 taken from the slabs of kernel_maskgemm.hip ([msplit][n_pad][2 KP], local
+// unit rows), added in slab order as the sweep adds them
+__global__ __launch_bounds__(256) void vb_pieces_slabs_kernel(int n, int n0, int KP, int K, const float* mu, const float* tauq, const float* ex,
+                                                               const float* var, const float* lambda, const float* mslabs, int msplit, int n_pad, double* out) {
+  const int lane = threadIdx.x & 63, u = blockIdx.x * 4 + (threadIdx.x >> 6);
+  double p[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (u < n && lane < K) {
+    const size_t q = (size_t)(n0 + u) * KP + lane;
+    const double m = (double)mu[q], t = (double)tauq[q], e = (double)ex[q], v = (double)var[q];
+    const double dm = e - m;
+    const size_t el = (size_t)u * (2 * KP) + lane;
+    const float asq = slab_sum_ordered(mslabs, msplit, (size_t)n_pad * (2 * KP), el);
+    const float vsq = slab_sum_ordered(mslabs, msplit, (size_t)n_pad * (2 * KP), el + KP);
+    p[0] = 0.5 * t * (v + dm * dm);
+    p[1] = log(0.5 * erfc(-m * sqrt(t) * 0.7071067811865476));
+    p[2] = log(t);
+    p[3] = (double)lambda[(size_t)u * KP + lane] * e;
+    p[4] = (v + e * e) * (double)asq;
+    p[5] = e * e * (double)vsq;
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) p[c] += __shfl_xor(p[c], s, 64);
+  }
+  __shared__ double red[4][6];
+  if (lane == 0) for (int c = 0; c < 6; ++c) red[threadIdx.x >> 6][c] = p[c];
+  sync_with_dma();
+  if (threadIdx.x < 6) out[(size_t)blockIdx.x * 8 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+void launch_vb_pieces_slabs(int n, int n0, int KP, int K, const float* mu, const float* tauq, const float* ex, const float* var,
+                            const float* lambda, const float* mslabs, int msplit, int n_pad, double* out, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(vb_pieces_slabs_kernel, dim3((n + 3) / 4), dim3(256), 0, st, n, n0, KP, K, mu, tauq, ex, var, lambda, mslabs, msplit, n_pad, out);
+}
+
 void launch_vb_pieces(int n, int n0, int KP, int K, const float* mu, const float* tauq, const float* ex, const float* var,
                       const float* lambda, const float* asq, const float* vsq, double* out, hipStream_t st) {
   if (n <= 0) return;

@@ -8,6 +8,6 @@ bool sweep_wide_supported(int KP, int pw) { return pw <= kChipPanelStride && swe
 
 // f describes the pairs this launch owns (f.npairs of them, at most kWideMaxSlots slots each), 16 pairs per block.
 void launch_sweep_wide(const SweepArgs& a, const FastArgs& f, hipStream_t st) {
-  if (chip_split_enabled()) launch_chip<16, 0, 1>(a, f, st); else launch_chip<16, 0, 0>(a, f, st); }
+  if (chip_split_enabled() || a.mode == kSweepVB) launch_chip<16, 0, 1>(a, f, st); else launch_chip<16, 0, 0>(a, f, st); }
 
 }  // namespace bnmtf

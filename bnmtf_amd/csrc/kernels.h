@@ -26,6 +26,23 @@ struct GemmArgs {
 void launch_gemm(const GemmArgs& a, int KP, hipStream_t st);
 
 // ---------------------------------------------------------------------------
+// VB (kernel_maskgemm.hip): out[u][0:2KP] = sum_{r in miss(u)} [S2o | Eo^2][r][:] as a product with the mask's bits
+//   bits : [ldw][n_pad] u32, bit b of word w = entry (unit, inner 32 w + b) is missing (zero beyond the inner extent)
+//   XB   : the moments of the other factor as three bf16 planes (hi, mid, lo) in fragment layout [3][rows_pad / 8][2 KP][8]
+//   slabs: [split][n_pad][2 KP] partial sums (inner slices as K1/K2), added by the consumer in slab order
+// ---------------------------------------------------------------------------
+struct MaskGemmArgs {
+  const uint32_t* bits; int ldw;
+  const uint32_t* XB; int rows_pad;
+  float* slabs;
+  int n_pad, split, inner_per_wave;
+  int ncol = 0;                  // 2 KP (set by launch_maskgemm)
+};
+void launch_maskgemm(const MaskGemmArgs& a, int KP, hipStream_t st);
+void launch_vb_planes(const float* S2, const float* E, int rows, int rows_pad, int KP, uint32_t* XB, hipStream_t st);
+void launch_mask_bits(const uint8_t* M, int I, int J, int by_rows, int unit0, int n, int m, int n_pad, int ldw, uint32_t* bits, hipStream_t st);
+
+// ---------------------------------------------------------------------------
 // Gram: C[a][b] = sum_r X[r][a] X[r][b] (fp64 accumulate), colsum[a] = sum_r X[r][a]
 //   also for VB: colsum2[a] = sum_r S2[r][a] when S2 != nullptr
 // ---------------------------------------------------------------------------
@@ -106,6 +123,9 @@ struct FastArgs {
   // VB sweep (kernel_sweep_vb.hip)
   const float* XoS;            // other factor's (E, S2) pair panels [KP][ld2_o][2]
   float* vb_asq; float* vb_vsq;  // [rows][KP] per (unit, column): sum_miss S2other, sum_miss Eother^2 (for vb_pieces_kernel)
+  // VB on the on-chip kernels (sweep_chip.inc, MODE = kSweepVB): the two masked sums of every (unit, column), from
+  // kernel_maskgemm.hip: [msplit][n_pad][2 KP] slabs, columns [0, KP) = sum_miss S2other, [KP, 2 KP) = sum_miss Eother^2
+  const float* mslabs; int msplit;
 };
 // 2/4/8-wave instantiations (kernel_sweep_fast.hip): pairs that need more than kFastMaxSlots slots per lane go to the generic kernel
 constexpr int kFastMaxSlots = 56;
@@ -131,6 +151,9 @@ int sweep_vb_blocks(int npairs, int nw = 8);  // blocks (= rows of FastArgs::sta
 void launch_sweep_vb(const SweepArgs& a, const FastArgs& f, hipStream_t st);
 void launch_vb_pieces(int n, int n0, int KP, int K, const float* mu, const float* tauq, const float* ex, const float* var,
                       const float* lambda, const float* asq, const float* vsq, double* out, hipStream_t st);
+// the same pieces with the two masked sums taken from the slabs of kernel_maskgemm.hip (the on-chip VB sweep)
+void launch_vb_pieces_slabs(int n, int n0, int KP, int K, const float* mu, const float* tauq, const float* ex, const float* var,
+                            const float* lambda, const float* mslabs, int msplit, int n_pad, double* out, hipStream_t st);
 
 // relayout + Gram after a sweep / state upload: X -> XT, XT2, partial Gram slabs; then the reduction
 struct PostArgs {
