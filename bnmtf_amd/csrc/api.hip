@@ -453,7 +453,7 @@ static void free_dir(Dir& d) {
   dfree(d.f_pair_base); dfree(d.f_off); dfree(d.f_off16); dfree(d.stats); dfree(d.f_gen_units);
   dfree(d.vb_stats);
   dfree(d.ho_in); dfree(d.ho_out); dfree(d.ho_pk); dfree(d.ho_region_ofs); dfree(d.ho_region); dfree(d.f_row_blk);
-  dfree(d.mu); dfree(d.tauq); dfree(d.var); dfree(d.S2); dfree(d.S2T); dfree(d.XS); dfree(d.vb_asq); dfree(d.vb_vsq); dfree(d.mbits); dfree(d.XB); dfree(d.mslabs); dfree(d.numer); dfree(d.taup);
+  dfree(d.mu); dfree(d.tauq); dfree(d.var); dfree(d.S2); dfree(d.S2T); dfree(d.XS); dfree(d.vb_asq); dfree(d.vb_vsq); dfree(d.mbits); dfree(d.XB); dfree(d.mslabs); dfree(d.xb_umax); dfree(d.xb_cexp); dfree(d.numer); dfree(d.taup);
 }
 
 // ---------------------------------------------------------------- profiling
@@ -531,12 +531,18 @@ static void enqueue_gemm(bnmtf_model* h, Dir& d, const Dir& other, int kid, int 
   launch_gemm(g, d.KP, h->stream);
 }
 // relayout (XT, XT2) + Gram of a factor that was just written
+// the variational half sweep of direction d (other factor o) runs on the on-chip kernels (api_models.inc: enqueue_vb_sweep)
+static bool vb_chip_ok(const Dir& d, const Dir& o) {
+  return d.mbits && o.XB && d.mslabs && d.nch == 1 && sweep_fast_supported(d.KP, d.pw) && !getenv("BNMTF_VB_PAIRS");
+}
 static void enqueue_post(bnmtf_model* h, Dir& d, bool vb = false) {
   PostArgs g;
   memset(&g, 0, sizeof(g));
   g.X = d.X; g.rows = d.nglob; g.KP = d.KP; g.XT = d.XT; g.ldT = d.ldT; g.XT2 = d.XT2; g.ld2 = d.ldT;
   g.Cpart = d.Cpart; g.spart = d.spart; g.C64 = d.C64; g.C32 = d.C32; g.colsum = d.colsum;
   if (vb) { g.S2 = d.S2; g.S2T = d.S2T; g.s2part = d.s2part; g.colsum2 = d.colsum2; g.XS = d.XS; }
+  // (the (E, S2) pair panels are read by the pair-panel VB kernel only: the on-chip path takes its masked sums from kernel_maskgemm.hip)
+  if (vb && vb_chip_ok(h->rows, h->cols) && vb_chip_ok(h->cols, h->rows)) g.XS = nullptr;
   g.snap = d.snap_dst; g.snapW = d.W; d.snap_dst = nullptr;
   launch_post(g, h->stream);
 }

@@ -28,18 +28,19 @@ void launch_gemm(const GemmArgs& a, int KP, hipStream_t st);
 // ---------------------------------------------------------------------------
 // VB (kernel_maskgemm.hip): out[u][0:2KP] = sum_{r in miss(u)} [S2o | Eo^2][r][:] as a product with the mask's bits
 //   bits : [ldw][n_pad] u32, bit b of word w = entry (unit, inner 32 w + b) is missing (zero beyond the inner extent)
-//   XB   : the moments of the other factor as three bf16 planes (hi, mid, lo) in fragment layout [3][rows_pad / 8][2 KP][8]
-//   slabs: [split][n_pad][2 KP] partial sums (inner slices as K1/K2), added by the consumer in slab order
+//   XB   : the moments of the other factor on a per-column fixed-point grid (2^(cexp[c] - 22)) as three planes of balanced
+//          base-256 digits in fragment layout [3][rows_pad / 16][2 KP][16 bytes]; umax: scratch of vb_colmax_kernel
+//   slabs: [split][n_pad][2 KP] fp32 partial sums (one per inner slice; integer inside), added by the consumer in slab order
 // ---------------------------------------------------------------------------
 struct MaskGemmArgs {
   const uint32_t* bits; int ldw;
-  const uint32_t* XB; int rows_pad;
+  const uint32_t* XB; int rows_pad; const int* cexp;
   float* slabs;
   int n_pad, split, inner_per_wave;
   int ncol = 0;                  // 2 KP (set by launch_maskgemm)
 };
 void launch_maskgemm(const MaskGemmArgs& a, int KP, hipStream_t st);
-void launch_vb_planes(const float* S2, const float* E, int rows, int rows_pad, int KP, uint32_t* XB, hipStream_t st);
+void launch_vb_planes(const float* S2, const float* E, int rows, int rows_pad, int KP, unsigned* umax, int which, int* cexp, uint32_t* XB, hipStream_t st);   // umax: two sets of 2 KP words (zero at first use), used in turn
 void launch_mask_bits(const uint8_t* M, int I, int J, int by_rows, int unit0, int n, int m, int n_pad, int ldw, uint32_t* bits, hipStream_t st);
 
 // ---------------------------------------------------------------------------

@@ -88,7 +88,8 @@ struct Dir {
   float *XS = nullptr, *vb_asq = nullptr, *vb_vsq = nullptr;   // fast VB sweep: (E, S2) pair panels; per (unit, column) sums for the ELBO pieces
   // VB on the on-chip sweep kernels (kernel_maskgemm.hip): the mask's bits of the local units [inner_pad / 32][n_pad], this
   // factor's moments as bf16 planes for the OTHER direction's masked sums, and the slabs of this direction's masked sums
-  uint32_t* mbits = nullptr; uint32_t* XB = nullptr; int xb_rows = 0; float* mslabs = nullptr;
+  uint32_t* mbits = nullptr; uint32_t* XB = nullptr; int xb_rows = 0; float* mslabs = nullptr; int msplit = 0, mipw = 0;
+  unsigned* xb_umax = nullptr; int xb_which = 0; int* xb_cexp = nullptr;       // per column of [S2 | E^2]: largest element's bits, exponent of the fixed-point grid
   bool wide_can = false;                 // the 16-wave kernels can run on this direction (<= kWideMaxSlots slots per lane, LDS fits)
   double* colsum2 = nullptr;
   double* vb_stats = nullptr;           // VB: [n][8] per-unit partial sums (generic sweep) or [ceil(n/4)][8] per-block (fast sweep)
