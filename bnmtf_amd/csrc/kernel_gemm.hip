@@ -182,7 +182,7 @@ __device__ __forceinline__ void split3(const float (&v)[8], u32x4& hi, u32x4& mi
   }
 }
 
-template <int MT, int NSET, int TW>
+template <int MT, int NSET, int TW, int RB = 1>      // RB = 0 (BNMTF_GEMM_RING=old, A/B only): the ring with its loads behind conditions
 __global__ __launch_bounds__(256, (TW == 4 ? 1 : 2)) void gemm_bf16x3_kernel(GemmArgs a) {
   typedef float f32xT __attribute__((ext_vector_type(TW)));   // TW column tiles per wave: one TW-dword load per lane per row
   constexpr int KP = MT * 32;
@@ -209,15 +209,15 @@ __global__ __launch_bounds__(256, (TW == 4 ? 1 : 2)) void gemm_bf16x3_kernel(Gem
 
   f32xT braw[NSET][8];
   float araw[NSET][MT][8];
-  auto load_step = [&](f32xT (&b)[8], float (&av)[MT][8]) {
+  auto load_step = [&](int gi, f32xT (&b)[8], float (&av)[MT][8]) {
+    const float* bpg = bp + (size_t)gi * 16 * (size_t)a.ld;
+    const float* xpg = xp + (size_t)gi * 16 * KP;
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
-      b[rr] = __builtin_nontemporal_load(reinterpret_cast<const f32xT*>(bp + (size_t)rr * a.ld));   // streamed once: keep it out of the way of X and the slabs in L2
+      b[rr] = __builtin_nontemporal_load(reinterpret_cast<const f32xT*>(bpg + (size_t)rr * a.ld));   // streamed once: keep it out of the way of X and the slabs in L2
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) av[mt][rr] = xp[rr * KP + mt * 32];
+      for (int mt = 0; mt < MT; ++mt) av[mt][rr] = xpg[rr * KP + mt * 32];
     }
-    bp += 16 * (size_t)a.ld;
-    xp += 16 * KP;
   };
   auto mul_step = [&](const f32xT (&b)[8], const float (&av)[MT][8]) {
     u32x4 ah[MT], am[MT], al[MT];
@@ -245,18 +245,43 @@ __global__ __launch_bounds__(256, (TW == 4 ? 1 : 2)) void gemm_bf16x3_kernel(Gem
     }
   };
   const int nsteps = ipw / 16;                    // ipw is a multiple of 32 (host pads)
-  // ring of NSET raw-operand register sets: NSET-1 steps (8 KiB of R~ each) in flight behind the one being multiplied
+  // ring of NSET raw-operand register sets: NSET-1 steps (8 KiB of R~ each) in flight behind the one being multiplied.
+  // No branch in the steady state (round 4): with the loads behind `if (more steps)` the compiler's wait counts at the join
+  // points came out as vmcnt(0) at the top of every NSET steps -- the ring was drained once per trip, one step in flight where
+  // two were meant.  A load that would run past the slice re-reads the slice's last step instead; the scheduling fences keep a
+  // later step's splits from being hoisted above the loads they would then wait for.  Same products in the same order.
+  const int last = nsteps - 1;
+  if constexpr (RB == 0) {
+    int nl = 0;
 #pragma unroll
-  for (int j = 0; j < NSET - 1; ++j)
-    if (j < nsteps) load_step(braw[j], araw[j]);
-  for (int g = 0; g < nsteps; g += NSET) {
+    for (int j = 0; j < NSET - 1; ++j)
+      if (j < nsteps) load_step(nl++, braw[j], araw[j]);
+    for (int g = 0; g < nsteps; g += NSET) {
 #pragma unroll
-    for (int j = 0; j < NSET; ++j) {
-      if (g + j < nsteps) {
-        if (g + j + NSET - 1 < nsteps) load_step(braw[(j + NSET - 1) % NSET], araw[(j + NSET - 1) % NSET]);
-        mul_step(braw[j], araw[j]);
+      for (int j = 0; j < NSET; ++j) {
+        if (g + j < nsteps) {
+          if (g + j + NSET - 1 < nsteps) load_step(nl++, braw[(j + NSET - 1) % NSET], araw[(j + NSET - 1) % NSET]);
+          mul_step(braw[j], araw[j]);
+        }
       }
     }
+  } else {
+#pragma unroll
+  for (int j = 0; j < NSET - 1; ++j) load_step(j < last ? j : last, braw[j], araw[j]);
+  int g = 0;
+  for (; g + NSET <= nsteps; g += NSET) {
+#pragma unroll
+    for (int j = 0; j < NSET; ++j) {
+      const int gl = g + j + NSET - 1;
+      load_step(gl < last ? gl : last, braw[(j + NSET - 1) % NSET], araw[(j + NSET - 1) % NSET]);
+      __builtin_amdgcn_sched_barrier(0);
+      mul_step(braw[j], araw[j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NSET - 1; ++j)
+    if (g + j < nsteps) mul_step(braw[j], araw[j]);
   }
 
   // cross-wave tree reduction through LDS: (2,3) -> (0,1), then 1 -> 0
@@ -313,6 +338,13 @@ void launch_gemm(const GemmArgs& a, int KP, hipStream_t st) {
     // three raw-operand register sets (two 8 KiB steps in flight per wave); deeper rings measured no faster
     // TW = 4 column tiles (128 columns) per wave, one wave per SIMD.  TW = 2 with two waves per SIMD (grid n_pad/64) was
     // measured slower: 68-70 us against 60-62 us (the factor operand is split twice as often per MFMA).
+    const char* ring = getenv("BNMTF_GEMM_RING");
+    if (ring && !strcmp(ring, "old")) {
+      if (KP == 32) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 3, 4, 0>), grid, block, 0, st, a);
+      else if (a.tw == 2) hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, 2, 0>), dim3(a.n_pad / 64, ns), block, 0, st, a);
+      else          hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, 4, 0>), grid, block, 0, st, a);
+      return;
+    }
     if (KP == 32) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 3, 4>), grid, block, 0, st, a);
     else if (a.tw == 2) hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, 2>), dim3(a.n_pad / 64, ns), block, 0, st, a);
     else          hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, 4>), grid, block, 0, st, a);
