@@ -532,8 +532,13 @@ static void enqueue_gemm(bnmtf_model* h, Dir& d, const Dir& other, int kid, int 
 }
 // relayout (XT, XT2) + Gram of a factor that was just written
 // the variational half sweep of direction d (other factor o) runs on the on-chip kernels (api_models.inc: enqueue_vb_sweep)
+// Policy (same-box A/Bs): the product's fixed cost (bits x digit planes, column maxima, planes, slab reads) pays when
+// a column loop is 64 columns of a 16-wave block -- 8192^2, K = 64: +7 % -- and does not at K <= 32 (4096^2: -15 %, 8192^2: -5 %),
+// where the pair-panel kernel (kernel_sweep_vb.hip) stays.  BNMTF_VB_PATH=masked / pairs forces one of them (read per call).
 static bool vb_chip_ok(const Dir& d, const Dir& o) {
-  return d.mbits && o.XB && d.mslabs && d.nch == 1 && sweep_fast_supported(d.KP, d.pw) && !getenv("BNMTF_VB_PAIRS");
+  if (!(d.mbits && o.XB && d.mslabs && d.nch == 1 && sweep_fast_supported(d.KP, d.pw))) return false;
+  if (const char* e = getenv("BNMTF_VB_PATH")) { if (!strcmp(e, "masked")) return true; if (!strcmp(e, "pairs")) return false; }
+  return d.KP == 64 && d.use_wide;
 }
 static void enqueue_post(bnmtf_model* h, Dir& d, bool vb = false) {
   PostArgs g;

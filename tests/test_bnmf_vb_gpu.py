@@ -13,13 +13,22 @@ pytestmark = pytest.mark.gpu
 # 8192 x 8192 configuration runs, sweep_vb_kernel<., 16, 0> with the fp32 moments routine on wave 0 -- on any size
 # -- with q handed over between the half sweeps (the default there) and, "1-prepass", rebuilt by every sweep's
 # pre-pass (BNMTF_HANDOVER=0)
-SHAPES = pytest.mark.parametrize("wide", [None, "1", "1-prepass"], ids=["8wave", "16wave", "16wave-prepass"])
+# "...-masked" (BNMTF_VB_PATH=masked, read per call): the sweep on the Gibbs sweep's on-chip kernels (sweep_chip.inc, MODE =
+# kSweepVB) with the two chain-independent masked sums of every (unit, column) from kernel_maskgemm.hip (bits x int8 digit
+# planes) -- the path the 8192 x 8192, K = 64 configuration takes by itself; the others force the pair-panel kernel
+SHAPES = pytest.mark.parametrize("wide", [None, "1", "1-prepass", "masked", "1-masked", "1-prepass-masked"],
+                                 ids=["8wave", "16wave", "16wave-prepass", "8wave-masked", "16wave-masked", "16wave-prepass-masked"])
 
 
 def _shape(monkeypatch, wide):
+    masked = wide is not None and wide.endswith("masked")
+    monkeypatch.setenv("BNMTF_VB_PATH", "masked" if masked else "pairs")
+    if masked:
+        wide = wide[:-len("masked")].rstrip("-") or None
     if wide is not None:
         monkeypatch.setenv("BNMTF_WIDE", "1")
         monkeypatch.setenv("BNMTF_HANDOVER", "0" if wide.endswith("prepass") else "1")
+    return wide
 
 
 @SHAPES
@@ -28,7 +37,7 @@ def test_toy_trajectory_matches_reference(golden, monkeypatch, wide):
     The q-parameters live on the device in fp32 (reductions fp64); 20 deterministic fixed-point
     iterations amplify that rounding (the run passes through a fast transition around iterations 8-12): rel 1e-3 on
     MSE and exptau, 2e-4 on the ELBO; the first iterations, before any amplification, 2e-5."""
-    _shape(monkeypatch, wide)
+    wide = _shape(monkeypatch, wide)
     g = golden("bnmf_vb.npz").case("toy")
     t = golden("toy_data.npz").case("bnmf")
     I, J = t["R"].shape; K = 10
@@ -56,7 +65,7 @@ def test_toy_trajectory_matches_reference(golden, monkeypatch, wide):
 
 @SHAPES
 def test_ragged_case_matches_reference(golden, monkeypatch, wide):
-    _shape(monkeypatch, wide)
+    wide = _shape(monkeypatch, wide)
     g = golden("bnmf_vb.npz").case("r31x23")
     K = 4
     b = bnmf_vb_optimised(g["R"], g["M"], K, dict(alpha=2., beta=.5, lambdaU=g["lambdaU"], lambdaV=g["lambdaV"]), verbose=False)
@@ -68,13 +77,15 @@ def test_ragged_case_matches_reference(golden, monkeypatch, wide):
     assert np.abs(b.expU - g["it10/expU"]).max() < 2e-3 * np.abs(g["it10/expU"]).max()
 
 
+@pytest.mark.parametrize("path", ["pairs", "masked"])
 @pytest.mark.parametrize("handover", ["1", "0"])
-def test_a_run_split_in_two_calls_is_the_same_trajectory(monkeypatch, handover):
+def test_a_run_split_in_two_calls_is_the_same_trajectory(monkeypatch, handover, path):
     """run(3); run(4) is run(7), bit for bit: the second call finds the device state it left (no upload) and, with the hand-over,
     q of the missing entries where the first call's last half sweep put it."""
     from bnmtf_amd.synthetic import generate_bnmf
     monkeypatch.setenv("BNMTF_WIDE", "1")
     monkeypatch.setenv("BNMTF_HANDOVER", handover)
+    monkeypatch.setenv("BNMTF_VB_PATH", path)
     I, J, K = 600, 500, 20
     R, M, _, _ = generate_bnmf(I, J, K, 0.15, seed_data=3, seed_mask=4)
     pri = dict(alpha=1., beta=1., lambdaU=0.1, lambdaV=0.1)
@@ -147,7 +158,7 @@ def test_fast_vb_sweep_equals_generic_sweep(monkeypatch, wide):
     """The register/LDS-resident VB sweep (kernel_sweep_vb.hip + vb_pieces_kernel) against the generic kernel on a
     ragged problem: same fixed-point iteration, fp32 rounding differences only."""
     from bnmtf_amd.synthetic import generate_bnmf
-    _shape(monkeypatch, wide)
+    wide = _shape(monkeypatch, wide)
     I, J, K = 600, 500, 20
     R, M, _, _ = generate_bnmf(I, J, K, 0.15, seed_data=3, seed_mask=4)
     pri = dict(alpha=1., beta=1., lambdaU=0.1, lambdaV=0.1)
