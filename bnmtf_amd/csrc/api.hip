@@ -453,7 +453,7 @@ static void free_dir(Dir& d) {
   dfree(d.f_pair_base); dfree(d.f_off); dfree(d.f_off16); dfree(d.stats); dfree(d.f_gen_units);
   dfree(d.vb_stats);
   dfree(d.ho_in); dfree(d.ho_out); dfree(d.ho_pk); dfree(d.ho_region_ofs); dfree(d.ho_region); dfree(d.f_row_blk);
-  dfree(d.mu); dfree(d.tauq); dfree(d.var); dfree(d.S2); dfree(d.S2T); dfree(d.XS); dfree(d.vb_asq); dfree(d.vb_vsq); dfree(d.mbits); dfree(d.XB); dfree(d.mslabs); dfree(d.xb_umax); dfree(d.xb_cexp); dfree(d.numer); dfree(d.taup);
+  dfree(d.mu); dfree(d.tauq); dfree(d.var); dfree(d.S2); dfree(d.S2T); dfree(d.XS); dfree(d.vb_asq); dfree(d.vb_vsq); dfree(d.mbits); dfree(d.XB); dfree(d.mslabs); dfree(d.xb_umax); dfree(d.xb_cexp); dfree(d.xb_mpart); dfree(d.numer); dfree(d.taup);
 }
 
 // ---------------------------------------------------------------- profiling
@@ -547,7 +547,12 @@ static void enqueue_post(bnmtf_model* h, Dir& d, bool vb = false) {
   g.Cpart = d.Cpart; g.spart = d.spart; g.C64 = d.C64; g.C32 = d.C32; g.colsum = d.colsum;
   if (vb) { g.S2 = d.S2; g.S2T = d.S2T; g.s2part = d.s2part; g.colsum2 = d.colsum2; g.XS = d.XS; }
   // (the (E, S2) pair panels are read by the pair-panel VB kernel only: the on-chip path takes its masked sums from kernel_maskgemm.hip)
-  if (vb && vb_chip_ok(h->rows, h->cols) && vb_chip_ok(h->cols, h->rows)) g.XS = nullptr;
+  if (vb && vb_chip_ok(h->rows, h->cols) && vb_chip_ok(h->cols, h->rows)) {
+    g.XS = nullptr;
+    // ... and needs the column maxima of [S2 | E^2] (the fixed-point grid of its digit planes): the Gram blocks see every row anyway
+    g.mpart = d.xb_mpart; g.umax = d.xb_umax;
+    d.xb_umax_posted = d.xb_mpart != nullptr;
+  } else d.xb_umax_posted = false;
   g.snap = d.snap_dst; g.snapW = d.W; d.snap_dst = nullptr;
   launch_post(g, h->stream);
 }
@@ -1221,7 +1226,9 @@ int bnmtf_kernel_stats(bnmtf_handle h, int kernel, double* total_ms, uint64_t* l
   return BNMTF_OK;
 }
 int bnmtf_describe(bnmtf_handle h, char* buf, size_t buflen) {
-  snprintf(buf, buflen, "%s", h->description.c_str());
+  // (+ which kernels the last variational half sweep ran on: the path is chosen per call, vb_chip_ok)
+  static const char* const kVbPath[] = {"", " vb_sweep=generic", " vb_sweep=pairs", " vb_sweep=masked"};
+  snprintf(buf, buflen, "%s%s", h->description.c_str(), kVbPath[h->last_vb_path & 3]);
   return BNMTF_OK;
 }
 

@@ -43,9 +43,9 @@ __device__ __forceinline__ uint32_t mg_pack_rne(float a0, float a1) {
 
 // per column c of [S2 | E^2]: the largest element's fp32 bits (non-negative floats order like unsigned integers).  256 blocks
 // (with 64 the kernel is the latency of 64 dependent trips per thread: 23 us), the sub-rows of a block combined through LDS,
-// one atomic per block and column (an atomic per thread: 15 us).  umax holds TWO sets of 2 KP words used in
-// turn (`which`): this launch also zeroes the other set for the next one (a memset is a 4.6 us launch of its own).
-__global__ __launch_bounds__(256) void vb_colmax_kernel(const float* S2, const float* E, int rows, int KP, unsigned* umax, int which) {
+// one atomic per block and column (an atomic per thread: 15 us).  The fall-back when the relayout has not left the maxima
+// (PostArgs::umax): it costs a memset and this launch, ~12 us.
+__global__ __launch_bounds__(256) void vb_colmax_kernel(const float* S2, const float* E, int rows, int KP, unsigned* umax) {
   __shared__ float part[256];
   const int ncol = 2 * KP;
   const int col = threadIdx.x % ncol, sub = threadIdx.x / ncol, nsub = 256 / ncol;       // ncol = 64 or 128
@@ -63,8 +63,7 @@ __global__ __launch_bounds__(256) void vb_colmax_kernel(const float* S2, const f
   __syncthreads();
   if (sub == 0) {
     for (int q = 1; q < nsub; ++q) m = fmaxf(m, part[q * ncol + col]);
-    atomicMax(umax + which * ncol + col, __builtin_bit_cast(unsigned, m));
-    if (blockIdx.x == 0) umax[(1 - which) * ncol + col] = 0u;
+    atomicMax(umax + col, __builtin_bit_cast(unsigned, m));
   }
 }
 
@@ -105,11 +104,14 @@ __global__ __launch_bounds__(256) void vb_planes_kernel(const float* S2, const f
   *reinterpret_cast<u32x4*>(XB + plane + o) = d1;
   *reinterpret_cast<u32x4*>(XB + 2 * plane + o) = d2;
 }
-void launch_vb_planes(const float* S2, const float* E, int rows, int rows_pad, int KP, unsigned* umax, int which, int* cexp, uint32_t* XB, hipStream_t st) {
+void launch_vb_planes(const float* S2, const float* E, int rows, int rows_pad, int KP, unsigned* umax, bool have_max, int* cexp, uint32_t* XB, hipStream_t st) {
   const long total = (long)(rows_pad / 16) * 2 * KP;
   if (total <= 0) return;
-  hipLaunchKernelGGL(vb_colmax_kernel, dim3(256), dim3(256), 0, st, S2, E, rows, KP, umax, which);
-  hipLaunchKernelGGL(vb_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, S2, E, rows, rows_pad, KP, (const unsigned*)(umax + which * 2 * KP), cexp, XB);
+  if (!have_max) {
+    (void)hipMemsetAsync(umax, 0, sizeof(unsigned) * 2 * KP, st);
+    hipLaunchKernelGGL(vb_colmax_kernel, dim3(256), dim3(256), 0, st, S2, E, rows, KP, umax);
+  }
+  hipLaunchKernelGGL(vb_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, S2, E, rows, rows_pad, KP, (const unsigned*)umax, cexp, XB);
 }
 
 // bits[w][ul] for the local units ul < n_pad (rows of padding: zero), w < ldw: bit b = entry (unit0 + ul, 32 w + b) is missing

@@ -77,13 +77,24 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
       // column sums: thread = column + 64 * group, a group adds every fourth row, the four partials meet in LDS
       {
         const int col = tid & 63, grp = tid >> 6;
-        double sp = 0.0;
+        double sp = 0.0, mx = 0.0;
         if (col < KP)
 #pragma unroll
-          for (int r = grp; r < RB; r += 4) sp += dtile[r * LDD + col];
+          for (int r = grp; r < RB; r += 4) { const double v = dtile[r * LDD + col]; sp += v; mx = fmax(mx, v); }
         dred[grp * 64 + col] = sp;
         __syncthreads();
         if (tid < KP) (pass == 0 ? a.spart : a.s2part)[(size_t)blockIdx.x * KP + tid] = (dred[tid] + dred[64 + tid]) + (dred[128 + tid] + dred[192 + tid]);
+        if (VB && a.mpart) {
+          // VB, whole-factor launches: the block's largest S2 (columns [0, KP)) and largest E^2 ([KP, 2 KP)) per column -- the
+          // fixed-point grid of kernel_maskgemm.hip's digit planes (E >= 0: the largest square is the square of the largest)
+          __syncthreads();
+          dred[grp * 64 + col] = mx;
+          __syncthreads();
+          if (tid < KP) {
+            const float m = (float)fmax(fmax(dred[tid], dred[64 + tid]), fmax(dred[128 + tid], dred[192 + tid]));
+            a.mpart[(size_t)blockIdx.x * 2 * KP + (pass == 0 ? KP : 0) + tid] = pass == 0 ? m * m : m;
+          }
+        }
       }
     }
     return;
@@ -128,6 +139,30 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
 __global__ __launch_bounds__(1024) void gram_reduce_kernel(PostArgs a, int nblk) {
   __shared__ double red[1024];
   const int KP = a.KP;
+  if (a.S2 && a.mpart && a.umax && (int)blockIdx.x == (int)gridDim.x - 2) {
+    // one more extra block (launch_post adds it): the column maxima of [S2 | E^2] over the blocks' partials -- the bits of the
+    // largest element (non-negative floats order like unsigned integers), read by vb_planes_kernel.  Thread = column + 128 * group,
+    // eight loads in flight.  (Inside the column-sum block this doubled the kernel's 6 us.)
+    float* fred = reinterpret_cast<float*>(red);
+    const int c = threadIdx.x & 127, g8 = threadIdx.x >> 7;           // 8 groups of 128 columns
+    float m = 0.f;
+    if (c < 2 * KP)
+      for (int b0 = g8; b0 < nblk; b0 += 8 * 8) {
+        float w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = b0 + 8 * u < nblk ? a.mpart[(size_t)(b0 + 8 * u) * 2 * KP + c] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m = fmaxf(m, w[u]);
+      }
+    fred[threadIdx.x] = m;
+    __syncthreads();
+    if (g8 == 0 && c < 2 * KP) {
+#pragma unroll
+      for (int j = 1; j < 8; ++j) m = fmaxf(m, fred[c + 128 * j]);
+      a.umax[c] = __builtin_bit_cast(unsigned, m);
+    }
+    return;
+  }
   if ((int)blockIdx.x == (int)gridDim.x - 1) {
     // the extra block: column sums, in parallel with the Gram blocks.  Thread = column + 64 * group: a wave reads one
     // coalesced row of partials per load, eight loads in flight, 16 groups summed through LDS in a fixed order
@@ -192,7 +227,8 @@ void launch_post(const PostArgs& a0, hipStream_t st) {
   const int nblk = post_blocks(a.rows);
   if (a.S2) hipLaunchKernelGGL(post_kernel<true>, dim3(nblk, 2), dim3(256), 0, st, a); else hipLaunchKernelGGL(post_kernel<false>, dim3(nblk, 2), dim3(256), 0, st, a);
   const int nt = a.KP / 4, ps = nt * (nt + 1) / 2 * 16;
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3((ps + 31) / 32 + 1), dim3(1024), 0, st, a, nblk);
+  const int extra = (a.S2 && a.mpart && a.umax) ? 2 : 1;      // the column-sum block, and (VB with the masked sums) the column-maximum block
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3((ps + 31) / 32 + extra), dim3(1024), 0, st, a, nblk);
 }
 
 void launch_post_layout(const PostArgs& a0, hipStream_t st) {

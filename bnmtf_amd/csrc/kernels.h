@@ -40,7 +40,9 @@ struct MaskGemmArgs {
   int ncol = 0;                  // 2 KP (set by launch_maskgemm)
 };
 void launch_maskgemm(const MaskGemmArgs& a, int KP, hipStream_t st);
-void launch_vb_planes(const float* S2, const float* E, int rows, int rows_pad, int KP, unsigned* umax, int which, int* cexp, uint32_t* XB, hipStream_t st);   // umax: two sets of 2 KP words (zero at first use), used in turn
+// umax [2 KP]: the column maxima's bits.  have_max: already there (the relayout's Gram blocks and gram_reduce_kernel: PostArgs::umax);
+// otherwise a pass of its own takes them first
+void launch_vb_planes(const float* S2, const float* E, int rows, int rows_pad, int KP, unsigned* umax, bool have_max, int* cexp, uint32_t* XB, hipStream_t st);
 void launch_mask_bits(const uint8_t* M, int I, int J, int by_rows, int unit0, int n, int m, int n_pad, int ldw, uint32_t* bits, hipStream_t st);
 
 // ---------------------------------------------------------------------------
@@ -165,6 +167,7 @@ struct PostArgs {
   // VB: second moment matrix S2 = var + exp^2
   const float* S2; float* S2T; double* s2part; double* colsum2;
   float* XS;                             // VB: [KP][ldT][2] (E, S2) interleaved per row: pair panels of the fast VB sweep, or null
+  float* mpart; unsigned* umax;          // VB, whole-factor launches (or null): per-block and final column maxima of [S2 | E^2] (kernel_maskgemm.hip)
   // which half of the work a launch does (launch_post: both, every row).  Several GPUs: the Gram partial is formed over the
   // rank's OWN rows [own0, own1) only (blocks blk0 .. of 32 rows; rows outside the range count as zero) and the partial
   // C64 | colsum is summed over the ranks by one all-reduce; the layouts are written for all rows once they are gathered.

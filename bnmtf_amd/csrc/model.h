@@ -89,7 +89,7 @@ struct Dir {
   // VB on the on-chip sweep kernels (kernel_maskgemm.hip): the mask's bits of the local units [inner_pad / 32][n_pad], this
   // factor's moments as bf16 planes for the OTHER direction's masked sums, and the slabs of this direction's masked sums
   uint32_t* mbits = nullptr; uint32_t* XB = nullptr; int xb_rows = 0; float* mslabs = nullptr; int msplit = 0, mipw = 0;
-  unsigned* xb_umax = nullptr; int xb_which = 0; int* xb_cexp = nullptr;       // per column of [S2 | E^2]: largest element's bits, exponent of the fixed-point grid
+  unsigned* xb_umax = nullptr; int* xb_cexp = nullptr; float* xb_mpart = nullptr; bool xb_umax_posted = false;       // per column of [S2 | E^2]: largest element's bits, exponent of the fixed-point grid
   bool wide_can = false;                 // the 16-wave kernels can run on this direction (<= kWideMaxSlots slots per lane, LDS fits)
   double* colsum2 = nullptr;
   double* vb_stats = nullptr;           // VB: [n][8] per-unit partial sums (generic sweep) or [ceil(n/4)][8] per-block (fast sweep)
@@ -184,6 +184,7 @@ struct bnmtf_model {
   std::vector<hipEvent_t> event_pool;
   bnmtf::Comm* comm = nullptr;
   std::string description;
+  int last_vb_path = 0;                 // 0: no variational sweep yet, 1 generic kernel, 2 pair-panel kernel, 3 on-chip kernel + masked sums
   // sample hand-off (all_U / all_V ...): device snapshots + a copy stream (api.hip, SampleSink)
   hipStream_t copy_stream = nullptr;
   float* snap_dev = nullptr; size_t snap_dev_cap = 0;       // [depth][floats per iteration]

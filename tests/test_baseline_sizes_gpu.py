@@ -58,6 +58,7 @@ def test_bnmf_vb_8192_fixed_point_properties():
     b = bnmf_vb_optimised(R, M, K, dict(alpha=1., beta=1., lambdaU=0.1, lambdaV=0.1), verbose=False)
     b.initialise("exp")
     b.run(12)
+    assert "vb_sweep=masked" in b.describe()      # this configuration takes the on-chip sweep with the masked sums from the matrix cores by itself
     elbo = np.array(b.all_elbo); mse = np.array(b.all_performances["MSE"])
     # coordinate ascent: the bound does not go down (fp32 storage of the factors: allow 1e-7 of its size).  The bound is
     # -inf, as in the reference, while some entry has mu sqrt(tau) < -37.5 (log of an underflown erfc,

@@ -65,6 +65,7 @@ def test_toy_trajectory_matches_reference(golden, monkeypatch, wide):
 
 @SHAPES
 def test_ragged_case_matches_reference(golden, monkeypatch, wide):
+    masked = wide is not None and wide.endswith("masked")
     wide = _shape(monkeypatch, wide)
     g = golden("bnmf_vb.npz").case("r31x23")
     K = 4
@@ -72,6 +73,7 @@ def test_ragged_case_matches_reference(golden, monkeypatch, wide):
     b.initialise('exp', {"tauU": g["tauU0"], "tauV": g["tauV0"]})
     assert ("sweep_nw=16" in b.describe()) == (wide is not None) and ("handover=1" in b.describe()) == (wide == "1")   # (small problems: only when asked for)
     b.run(10)
+    assert ("vb_sweep=masked" if masked else "vb_sweep=pairs") in b.describe()      # the path that was asked for is the one that ran
     np.testing.assert_allclose(b.all_performances['MSE'], g["mse"], rtol=1e-3)
     np.testing.assert_allclose(b.all_elbo, g["elbo"], rtol=1e-4)
     assert np.abs(b.expU - g["it10/expU"]).max() < 2e-3 * np.abs(g["it10/expU"]).max()
