@@ -138,6 +138,15 @@ class bnmf_vb_optimised(DeviceModel):
         self.alpha_s = self.alpha + self.size_Omega / 2.0
         self.beta_s = self.beta + 0.5 * self.exp_square_diff()
 
+    def masked_sums(self, which):
+        """Hook (tests): sum over the MISSING entries of a unit of the other factor's S2 = var + exp^2 and of its exp^2, per column --
+        the chain-independent parts of tauU / muU (which = 0) or tauV / muV (which = 1), from the matrix-core product run() uses."""
+        self._push()
+        n = self.I if which == 0 else self.J
+        asq = np.zeros((n, self.K)); vsq = np.zeros((n, self.K))
+        _lib.check(_lib.lib().bnmf_vb_masked_sums(self._handle(), int(which), asq.ctypes.data, vsq.ctypes.data))
+        return asq, vsq
+
     def exp_square_diff(self):
         """:185-187 (fp64 on the device)."""
         for n in ("muU", "tauU", "muV", "tauV"):          # the test-suite sets exp/var only

@@ -338,13 +338,15 @@ void launch_gemm(const GemmArgs& a, int KP, hipStream_t st) {
     // three raw-operand register sets (two 8 KiB steps in flight per wave); deeper rings measured no faster
     // TW = 4 column tiles (128 columns) per wave, one wave per SIMD.  TW = 2 with two waves per SIMD (grid n_pad/64) was
     // measured slower: 68-70 us against 60-62 us (the factor operand is split twice as often per MFMA).
-    const char* ring = getenv("BNMTF_GEMM_RING");
+#ifdef BNMTF_EXPERIMENTS
+    const char* ring = getenv("BNMTF_GEMM_RING");      // "old": the ring with its loads behind conditions (tools/ab_gemm_ring.sh; make EXPERIMENTS=1)
     if (ring && !strcmp(ring, "old")) {
       if (KP == 32) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 3, 4, 0>), grid, block, 0, st, a);
       else if (a.tw == 2) hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, 2, 0>), dim3(a.n_pad / 64, ns), block, 0, st, a);
       else          hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, 4, 0>), grid, block, 0, st, a);
       return;
     }
+#endif
     if (KP == 32) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 3, 4>), grid, block, 0, st, a);
     else if (a.tw == 2) hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, 2>), dim3(a.n_pad / 64, ns), block, 0, st, a);
     else          hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, 4>), grid, block, 0, st, a);

@@ -166,6 +166,13 @@ BNMTF_API int bnmf_vb_get_state(bnmtf_handle h, double* muU, double* tauU, doubl
 BNMTF_API int bnmf_vb_update(bnmtf_handle h, int which, int k, int moments);
 /* exp_square_diff() (:185-187) */
 BNMTF_API int bnmf_vb_exp_square_diff(bnmtf_handle h, double* out);
+/* Hook (tests): the two chain-independent masked sums that update_U(k) / update_V(k) use for every (unit, column) of one
+ * direction (which = 0: rows i, other factor V; which = 1: columns j, other factor U), formed the way run() forms them on its
+ * on-chip path (csrc/kernel_maskgemm.hip: the mask's bits x fixed-point digit planes of the moments on the int8 matrix cores):
+ *   asq[u][k] = sum_{r: M = 0} (varO[r][k] + expO[r][k]^2)     (tauU[i][k] = exptau * (sum_j S2V[j][k] - asq[i][k]),  :189-199)
+ *   vsq[u][k] = sum_{r: M = 0} expO[r][k]^2                     (the unit's own term of the numerator of muU)
+ * for the rank's local units, [n][K] doubles each. */
+BNMTF_API int bnmf_vb_masked_sums(bnmtf_handle h, int which, double* asq, double* vsq);
 /* run(iterations) (:121-153).  exptau_out[n_iter] (all_exp_tau), perf_out[n_iter][3], times_out[n_iter],
  * elbo_terms_out[n_iter][10] = the O(I*J) / O((I+J)K) pieces of elbo() (:163-177) that live on the device:
  *   {exp_square_diff, beta_s,

@@ -180,3 +180,33 @@ def test_fast_vb_sweep_equals_generic_sweep(monkeypatch, wide):
     assert np.abs(f[3] - g[3]).max() < 2e-3 * np.abs(g[3]).max()
     assert np.abs(f[4] - g[4]).max() < 5e-3 * np.abs(g[4]).max()
     np.testing.assert_allclose(f[5], g[5], rtol=1e-4)
+
+
+@pytest.mark.parametrize("I,J,K,frac", [(515, 389, 40, 0.15), (600, 500, 20, 0.3), (130, 97, 7, 0.6)])
+def test_masked_sums_from_the_matrix_cores_against_fp64(I, J, K, frac):
+    """csrc/kernel_maskgemm.hip through the hook bnmf_vb_masked_sums: sum over a unit's MISSING entries of the other factor's
+    S2 = var + exp^2 and of its exp^2 (the chain-independent parts of tauU / muU, bnmf_vb_optimised.py:189-199), formed from the
+    mask's bits and the moments on a per-column 22-bit fixed-point grid with integer accumulation.  Stated error: an element
+    is off by at most 2^(e_c - 23) with 2^(e_c - 1) <= max of the column < 2^e_c, i.e. <= max_c * 2^-22; the sum of n elements by
+    at most n times that (in practice ~sqrt(n)), plus one fp32 rounding per slab.  The moments span six decades here."""
+    from bnmtf_amd.synthetic import generate_bnmf
+    R, M, _, _ = generate_bnmf(I, J, K, frac, seed_data=11, seed_mask=12)
+    rs = np.random.RandomState(5)
+    b = bnmf_vb_optimised(R, M, K, dict(alpha=1., beta=1., lambdaU=0.1, lambdaV=0.1), verbose=False)
+    b.initialise('exp')
+    b.expU = 10. ** rs.uniform(-4, 1, (I, K)); b.varU = 10. ** rs.uniform(-6, 0, (I, K))
+    b.expV = 10. ** rs.uniform(-4, 1, (J, K)); b.varV = 10. ** rs.uniform(-6, 0, (J, K))
+    miss = 1.0 - M
+    for which, (mm, ex, var) in enumerate([(miss, b.expV, b.varV), (miss.T, b.expU, b.varU)]):
+        e32 = ex.astype(np.float32).astype(np.float64); v32 = var.astype(np.float32).astype(np.float64)     # what the device holds
+        s2 = (v32.astype(np.float32) + (e32 * e32).astype(np.float32)).astype(np.float64)                     # S2 as the device forms it (fp32)
+        e2 = (e32 * e32).astype(np.float32).astype(np.float64)
+        asq, vsq = b.masked_sums(which)
+        n_miss = mm.sum(1)[:, None]
+        for got, op in ((asq, s2), (vsq, e2)):
+            ref = mm @ op
+            bound = n_miss * op.max(0)[None, :] * 2.0 ** -22 + 3e-7 * ref + 1e-30
+            assert np.all(np.abs(got - ref) <= bound), float((np.abs(got - ref) / bound).max())
+            # ... and in practice far inside it: the relative error of the sums that matter (those not dwarfed by the column's maximum)
+            big = ref > 1e-3 * op.max(0)[None, :] * np.maximum(n_miss, 1)
+            assert np.abs(got - ref)[big].max() <= 2e-6 * ref[big].max()

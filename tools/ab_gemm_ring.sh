@@ -1,5 +1,6 @@
 #!/bin/bash
-# same-box A/B of the contraction's register ring (BNMTF_GEMM_RING=old: loads behind conditions) -- bench lines, no profiler
+# same-box A/B of the contraction's register ring (BNMTF_GEMM_RING=old: loads behind conditions; needs a library built with
+# `make EXPERIMENTS=1`, the shipped one ignores the switch) -- bench lines, no profiler
 for rep in 1 2; do
 for r in old new; do
   for w in bnmf_8192_k64 bnmf_4096_k32 vb_8192_k64; do
