@@ -13,16 +13,19 @@
 //    missing entries by ~1e-8 of itself -- below the rounding of the fp32 result;
 //  * the mask bits become bytes 0 / 1 in registers (B operand); the three digit planes (A operand) accumulate in three
 //    i32 tiles -- integer sums: no rounding, no dependence on the order of the additions or on how the inner range is cut;
-//  * after the cross-wave reduction (LDS, integers) wave 0 forms d0 2^16 + d1 2^8 + d2 (exact in fp64), scales by
-//    2^(e_c - 22) and writes ONE fp32 slab per inner slice; the consumers (sweep prologue, vb_pieces_slabs_kernel) add
-//    the slabs in slab order as they add the contraction's.
+//  * at the end a wave forms d0 2^16 + d1 2^8 + d2 (exact in fp64), scales by 2^(e_c - 22) and writes its columns of the fp32
+//    slab of the block's inner slice; the consumers (sweep prologue, vb_pieces_slabs_kernel) add the slabs in slab order as they
+//    add the contraction's.
 //  * B operand: bits[r / 32][u] -- one u32 per unit and 32 inner indices, the unit index contiguous (8 MB at 8192^2): the 32
 //    lanes of a tile read 128 contiguous bytes; lane l takes the 16 bits of its half (l >> 5) of the step's 32 inner rows
 //  * A operand: XB[plane][r / 16][col][r % 16] bytes: a lane reads the 16 inner rows of its half as one 16-byte load
 //    (which k index of the instruction a given (half, byte) lands on is irrelevant: both operands use the same places)
-//  * launch shape as K1/K2 (kernel_gemm.hip): a wave owns 128 units x 64 output columns and a private inner slice, the four
-//    waves of a block reduce through LDS.  History: three bf16 planes (fp32-exact as well, 6.7e-4 drift on the reference's toy
-//    trajectory against 1.5e-3 of the pair-panel sweep) took 48 us at cfg5; two planes (16 bits) drifted 2.0e-3.
+//  * launch shape and the software pipeline of a step: see maskgemm_kernel.  History (cfg5): three bf16 planes
+//    (fp32-exact as well, 6.7e-4 drift on the reference's toy trajectory against 1.5e-3 of the pair-panel sweep) 48 us; two planes
+//    (16 bits) drifted 2.0e-3; int8 digit planes with every wave expanding its own mask bits 31 us; the expansion shared
+//    through LDS, a deeper operand ring, an fp32 instead of an fp64 ending: 33-35 us each (none of them was the limit); every
+//    non-product instruction of a step placed in the gaps between its products: 24 us.  (`-DBNMTF_MG_TIMING`: cycle and
+//    wall-clock stamps around the loop; tools/micro/mfma_i8_rate.hip: the instruction's issue rate, 32 cycles like the bf16 form.)
 #include <cstdlib>
 
 #include "kernels.h"
@@ -147,165 +150,173 @@ __device__ __forceinline__ int mg_bits4(uint32_t w, int b) {
   return (int)(__umul24(__builtin_amdgcn_ubfe(w, b, 4), 0x204081u) & 0x01010101u);
 }
 
-// A wave owns 128 units (TW = 4 tiles) x 32 output columns (one "column group" of the 2 KP) x three digit planes -- 192
-// accumulator registers: with 64 columns (384) the compiler shuttles tiles between the two register files inside the loop --
-// and a private inner slice; grid = unit groups x column groups x inner slices.
+// A block owns one (or, at 2 KP = 64, two) group(s) of 128 units (TW = 4 tiles), ALL 2 KP output columns and an inner slice: its
+// four waves take the 32-column groups -- 128 units x 32 columns x three digit planes = 192 accumulator registers each (with 64
+// columns per wave, 384, the compiler shuttles tiles between the two register files inside the loop).  The waves of a unit
+// group need the SAME mask bytes: each expands its share of the four tiles (12 vector instructions per tile), puts it in LDS and
+// all read the four fragments back.  One barrier per step (two fragment buffers).  Each wave writes its own columns of the slab of
+// the block's inner slice: no cross-wave reduction.
+template <int NCG>      // column groups of 32 = waves per unit group: 2 KP / 32 = 2 or 4
 __global__ __launch_bounds__(256, 1) void maskgemm_kernel(MaskGemmArgs a) {
-  constexpr int MT = 1, TW = 4, NSET = 3;
-  constexpr int NRED = MT * TW * 16;                     // one plane per pass of the LDS reduction (64 KiB of LDS)
-  __shared__ int red[2][NRED * 64];
+  constexpr int TW = 4, NSET = 6;                        // five steps of operands in flight (14 registers each): with two, a step waited for its loads
+  __shared__ i32x4 bfrag[2][2][TW][64];                 // [buffer][unit group of the block][tile][lane]: 16 KiB
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, c = lane & 31;
-  const int ncol = a.ncol;                               // 2 KP
-  // block id -> (unit group bx, column group cg, inner slice s).  Blocks b and b + 8 share an XCD and its 4 MiB L2: the blocks
-  // of an XCD take the same inner slice(s), so its L2 holds a 1 / split part of the digit planes
-  const int nxg = a.n_pad / (32 * TW), ncg = ncol / (32 * MT), nx = nxg * ncg, nb = nx * a.split;
-  int bq = (int)blockIdx.x % nx, s = (int)blockIdx.x / nx;
+  const int ncol = a.ncol;                               // 2 KP: 64 or 128
+  constexpr int ncg = NCG;
+  constexpr int ugpb = 4 / ncg;                          // unit groups per block: 2 or 1
+  constexpr int tpw = TW / ncg;                          // tiles a wave expands per step: 2 or 1
+  const int ug = wave / ncg, cg = wave % ncg;
+  // block id -> (unit-group slot bx, inner slice s).  Blocks b and b + 8 share an XCD and its 4 MiB L2: the blocks of an XCD take
+  // the same inner slice(s), so its L2 holds a 1 / split part of the digit planes
+  const int nug = a.n_pad / (32 * TW), nx = (nug + ugpb - 1) / ugpb, nb = nx * a.split;
+  int bx = (int)blockIdx.x % nx, s = (int)blockIdx.x / nx;
   if (nb % 8 == 0 && a.split <= 8 && 8 % a.split == 0) {
     const int g = 8 / a.split, xcd = (int)blockIdx.x & 7, li = (int)blockIdx.x >> 3;
-    s = xcd / g; bq = li * g + xcd % g;
+    s = xcd / g; bx = li * g + xcd % g;
   }
-  const int bx = bq / ncg, cg = bq % ncg;
-  const int col0 = bx * (32 * TW);
-  const int ipw = a.inner_per_wave;                      // multiple of 32
-  const int r0 = (s * 4 + wave) * ipw;
+  const int ugi = bx * ugpb + ug;
+  const bool live = ugi < nug;                           // (2 KP = 64 and an odd number of unit groups: the last block's second pair of waves goes through the motions)
+  const int col0 = (live ? ugi : nug - 1) * (32 * TW);
+  const int ipb = a.inner_per_wave;                      // inner rows of the BLOCK's slice, a multiple of 32
+  const int r0 = s * ipb;
 
-  // A fragments: plane p, tile mt of step g: 16 bytes at XB + p * plane + (((r0 >> 4) + 2 g + h) * ncol + cg * 64 + mt * 32 + c) * 4 words
+  // A fragments: plane p of step g: 16 bytes at XB + p * plane + (((r0 >> 4) + 2 g + h) * ncol + cg * 32 + c) * 4 words
   const size_t plane = (size_t)(a.rows_pad / 16) * ncol * 4;
-  const uint32_t* ap = a.XB + ((size_t)((r0 >> 4) + h) * ncol + cg * (32 * MT) + c) * 4;
-  const uint32_t* bp = a.bits + (size_t)(r0 >> 5) * a.n_pad + col0 + c;
+  const uint32_t* ap = a.XB + ((size_t)((r0 >> 4) + h) * ncol + cg * 32 + c) * 4;
+  const uint32_t* bp = a.bits + (size_t)(r0 >> 5) * a.n_pad + col0 + 32 * (cg * tpw) + c;      // the wave's own tile(s)
 
-  i32x16 acc[3][MT][TW];
+  i32x16 acc[3][TW];
 #pragma unroll
   for (int p = 0; p < 3; ++p)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int t = 0; t < TW; ++t)
 #pragma unroll
-      for (int t = 0; t < TW; ++t)
-#pragma unroll
-        for (int g = 0; g < 16; ++g) acc[p][mt][t][g] = 0;
+      for (int g = 0; g < 16; ++g) acc[p][t][g] = 0;
 
-  i32x4 araw[NSET][3][MT];
-  uint32_t wraw[NSET][TW];
-  auto load_step = [&](int g, i32x4 (&av)[3][MT], uint32_t (&wv)[TW]) {
+  i32x4 araw[NSET][3];
+  uint32_t wraw[NSET][2];
+  auto load_step = [&](int g, i32x4 (&av)[3], uint32_t (&wv)[2]) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) av[p][mt] = *reinterpret_cast<const i32x4*>(ap + p * plane + ((size_t)(2 * g) * ncol + mt * 32) * 4);
-#pragma unroll
-    for (int t = 0; t < TW; ++t) wv[t] = bp[(size_t)g * a.n_pad + 32 * t];      // (raw: a shift here would wait for the load it follows)
+    for (int p = 0; p < 3; ++p) av[p] = *reinterpret_cast<const i32x4*>(ap + p * plane + (size_t)(2 * g) * ncol * 4);
+    wv[0] = bp[(size_t)g * a.n_pad];                       // (raw: a shift here would wait for the load it follows)
+    wv[1] = bp[(size_t)g * a.n_pad + 32 * (tpw - 1)];      // (the wave's second tile, or the first again: no branch in the ring)
   };
-  auto expand = [&](uint32_t w16) {
-    i32x4 b;
+  // this wave's share of the unit group's mask bytes of one step -> LDS buffer `buf`
+  auto put = [&](int buf, const uint32_t (&wv)[2]) {
+    auto one = [&](uint32_t w, int t) {
+      const uint32_t w16 = w >> (16 * h);
+      i32x4 b;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) b[p] = mg_bits4(w16, 4 * p);
-    return b;
+      for (int p = 0; p < 4; ++p) b[p] = mg_bits4(w16, 4 * p);
+      bfrag[buf][ug][t][lane] = b;
+    };
+    one(wv[0], cg * tpw);
+    if (tpw == 2) one(wv[1], cg * tpw + 1);
   };
-  auto mul_step = [&](const i32x4 (&av)[3][MT], const uint32_t (&wv)[TW]) {
-    // tile t's MFMAs with the expansion of tile t + 1's mask bits in their gaps (an MFMA holds the vector issue for 8 of its 32
-    // cycles: three 4-cycle instructions per gap are free)
-    i32x4 b[2];
-    b[0] = expand(wv[0] >> (16 * h));
+  auto products = [&](const i32x4 (&av)[3], const i32x4 (&b)[TW], int t0, int t1) {
 #pragma unroll
-    for (int t = 0; t < TW; ++t) {
-      if (t + 1 < TW) b[(t + 1) & 1] = expand(wv[t + 1] >> (16 * h));
+    for (int t = t0; t < t1; ++t)
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          acc[p][mt][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[p][mt], b[t & 1], acc[p][mt][t], 0, 0, 0);
-      if (t + 1 < TW) {
-#pragma unroll
-        for (int i = 0; i < 3 * MT; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // four vector instructions
-        }
-      }
-    }
+      for (int p = 0; p < 3; ++p) acc[p][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[p], b[t], acc[p][t], 0, 0, 0);
   };
-  const int nsteps = ipw / 32;
-  // ring of NSET operand sets, NSET - 1 steps in flight behind the one being multiplied.  No branch inside the steady state: a
-  // load that would run past the slice re-reads its last step instead (with the loads behind conditions the compiler's wait
-  // counts at the join points drained the ring every step)
+  const int nsteps = ipb / 32;
+  // the blocks of an XCD walk the SAME slice of the digit planes: every block starts somewhere else in its slice and wraps round
+  // (integer sums do not care about the order)
+  const int g0 = (int)(((unsigned)bx * 11u) % (unsigned)nsteps);
+  auto at = [&](int i) { const int g = g0 + i; return g >= nsteps ? g - nsteps : g; };
+  // Software pipeline (one wave per SIMD issues in order and blocks on the matrix pipe: whatever is not placed in the gaps
+  // between a step's twelve products adds to it -- measured 900 cycles per step with the loads, the expansion and the exchange
+  // ahead of the products, against 384 of matrix pipe):
+  //   step i = barrier ; { products of step i } with, in their gaps: fragments of step i + 1 <- LDS (written during step i - 1,
+  //   published by the barrier), operand loads of step i + NSET - 1, bytes of step i + 2 -> LDS.
+  // A fragment buffer is rewritten one barrier after the reads of its previous contents were issued.  No branch in the steady
+  // state: loads and expansions past the slice repeat its last step (their results are not used).
   const int last = nsteps - 1;
+#ifdef BNMTF_MG_TIMING
+  const unsigned long long tk0 = __builtin_readcyclecounter(), tw0 = wall_clock64();
+#endif
 #pragma unroll
-  for (int j = 0; j < NSET - 1; ++j) load_step(j < last ? j : last, araw[j], wraw[j]);
+  for (int j = 0; j < NSET - 1; ++j) load_step(at(j < last ? j : last), araw[j], wraw[j]);
+  i32x4 bcur[TW], bnxt[TW];
+  put(0, wraw[0]);
+  put(1, wraw[1]);
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < TW; ++t) bcur[t] = bfrag[0][ug][t][lane];
+  auto step = [&](int i, const i32x4 (&av)[3], i32x4 (&anew)[3], uint32_t (&wnew)[2], const uint32_t (&w2)[2]) {
+    __syncthreads();                                       // (LDS counter only: the operand loads of the steps ahead stay in flight)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < TW; ++t) bnxt[t] = bfrag[(i + 1) & 1][ug][t][lane];
+    const int gl = i + NSET - 1;
+    load_step(at(gl < last ? gl : last), anew, wnew);
+    put(i & 1, w2);                                        // step i + 2's bytes into the buffer step i's came from
+    products(av, bcur, 0, TW);
+#pragma unroll
+    for (int q = 0; q < 3 * TW; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one product
+      __builtin_amdgcn_sched_group_barrier(0x326, 5, 0);   // five of the others (vector / scalar ALU, loads, LDS reads and writes)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < TW; ++t) bcur[t] = bnxt[t];
+  };
+  // (set j holds step i = g + j; step i + 2's mask words are in set (j + 2) % NSET, loaded NSET - 3 steps ago; the new loads go
+  // to set (j + NSET - 1) % NSET, which held step i - 1)
+  static_assert(NSET >= 4, "the words of step i + 2 must not be the set being reloaded");
   int g = 0;
   for (; g + NSET <= nsteps; g += NSET) {
 #pragma unroll
-    for (int j = 0; j < NSET; ++j) {
-      const int gl = g + j + NSET - 1;
-      load_step(gl < last ? gl : last, araw[(j + NSET - 1) % NSET], wraw[(j + NSET - 1) % NSET]);
-      __builtin_amdgcn_sched_barrier(0);      // (nothing of a later step -- the cheap shifts of its mask words, say -- is scheduled
-      mul_step(araw[j], wraw[j]);             //  up here, where it would wait for loads that have only just been issued)
-      __builtin_amdgcn_sched_barrier(0);
+    for (int j = 0; j < NSET; ++j) step(g + j, araw[j], araw[(j + NSET - 1) % NSET], wraw[(j + NSET - 1) % NSET], wraw[(j + 2) % NSET]);
+  }
+#pragma unroll
+  for (int j = 0; j < NSET - 1; ++j)            // (every wave of the block runs the same number of steps: the barriers match)
+    if (g + j < nsteps) step(g + j, araw[j], araw[(j + NSET - 1) % NSET], wraw[(j + NSET - 1) % NSET], wraw[(j + 2) % NSET]);
+
+#ifdef BNMTF_MG_TIMING
+  const unsigned long long tk1 = __builtin_readcyclecounter(), tw1 = wall_clock64();
+#endif
+  if (live) {
+    // D: reg g, lane l -> column i = (g & 3) + 8 (g >> 2) + 4 h of the tile, unit j = c.  d0 2^16 + (d1 2^8 + d2), each digit sum
+    // exact as an fp32 (< 2^24), the inner sum off by < 2^-32 of the total, one rounding in the outer FMA; the scale is a power of
+    // two.  (In fp64 -- three quarter-rate conversions per value -- this end was ~8 us of the kernel's 35.)
+    float* out = a.slabs + (size_t)s * a.n_pad * ncol + cg * 32;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int colb = cg * 32 + 8 * g4 + 4 * h;
+      int sc[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sc[q] = a.cexp[colb + q] - 22;
+#pragma unroll
+      for (int t = 0; t < TW; ++t) {
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int gg = 4 * g4 + q;
+          const float n = fmaf((float)acc[0][t][gg], 65536.0f, fmaf((float)acc[1][t][gg], 256.0f, (float)acc[2][t][gg]));
+          v[q] = __builtin_ldexpf(n, sc[q]);               // (v_ldexp_f32: exact, whatever the column's size)
+        }
+        *reinterpret_cast<f32x4*>(out + (size_t)(col0 + 32 * t + c) * ncol + 8 * g4 + 4 * h) = v;
+      }
     }
   }
-#pragma unroll
-  for (int j = 0; j < NSET - 1; ++j)
-    if (g + j < nsteps) mul_step(araw[j], wraw[j]);
-
-  // cross-wave tree reduction through LDS (integers: exact), one digit plane at a time: (2,3) -> (0,1), then 1 -> 0
-#pragma unroll
-  for (int p = 0; p < 3; ++p) {
-    auto put = [&](int* dst) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int t = 0; t < TW; ++t)
-#pragma unroll
-          for (int g = 0; g < 16; ++g) dst[((mt * TW + t) * 16 + g) * 64 + lane] = acc[p][mt][t][g];
-    };
-    auto add = [&](const int* src) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int t = 0; t < TW; ++t)
-#pragma unroll
-          for (int g = 0; g < 16; ++g) acc[p][mt][t][g] += src[((mt * TW + t) * 16 + g) * 64 + lane];
-    };
-    if (p > 0) __syncthreads();
-    if (wave >= 2) put(red[wave - 2]);
-    __syncthreads();
-    if (wave < 2) add(red[wave]);
-    __syncthreads();
-    if (wave == 1) put(red[0]);
-    __syncthreads();
-    if (wave == 0) add(red[0]);
-  }
-  if (wave == 0) {
-    // D: reg g, lane l -> column i = (g & 3) + 8 (g >> 2) + 4 h of the tile, unit j = c
-    float* out = a.slabs + (size_t)s * a.n_pad * ncol + cg * (32 * MT);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int colb = cg * (32 * MT) + mt * 32 + 8 * g4 + 4 * h;
-        double sc[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) sc[q] = __builtin_ldexp(1.0, a.cexp[colb + q] - 22);
-#pragma unroll
-        for (int t = 0; t < TW; ++t) {
-          f32x4 v;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int gg = 4 * g4 + q;
-            const double n = (double)acc[0][mt][t][gg] * 65536.0 + (double)acc[1][mt][t][gg] * 256.0 + (double)acc[2][mt][t][gg];
-            v[q] = (float)(n * sc[q]);
-          }
-          *reinterpret_cast<f32x4*>(out + (size_t)(col0 + 32 * t + c) * ncol + mt * 32 + 8 * g4 + 4 * h) = v;
-        }
-      }
-  }
+#ifdef BNMTF_MG_TIMING
+  const unsigned long long tk2 = __builtin_readcyclecounter(), tw2 = wall_clock64();
+  if ((blockIdx.x % 37) == 0 && threadIdx.x == 0)
+    printf("maskgemm block %d: loop %llu cycles / %llu wall ticks (100 MHz), end %llu cycles / %llu ticks, %d steps\n", (int)blockIdx.x, tk1 - tk0, tw1 - tw0, tk2 - tk1, tw2 - tw1, nsteps);
+#endif
 }
 
 void launch_maskgemm(const MaskGemmArgs& a, int KP, hipStream_t st) {
   if (a.split <= 0 || a.n_pad <= 0) return;
   MaskGemmArgs b = a;
   b.ncol = 2 * KP;
-  dim3 grid((a.n_pad / 128) * (b.ncol / 32) * a.split), block(256);
-  hipLaunchKernelGGL(maskgemm_kernel, grid, block, 0, st, b);
+  const int ugpb = 4 / (b.ncol / 32), nug = a.n_pad / 128;
+  dim3 grid(((nug + ugpb - 1) / ugpb) * a.split), block(256);
+  if (b.ncol == 64) hipLaunchKernelGGL(maskgemm_kernel<2>, grid, block, 0, st, b);
+  else hipLaunchKernelGGL(maskgemm_kernel<4>, grid, block, 0, st, b);
 }
 
 }  // namespace bnmtf

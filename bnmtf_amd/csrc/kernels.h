@@ -36,7 +36,7 @@ struct MaskGemmArgs {
   const uint32_t* bits; int ldw;
   const uint32_t* XB; int rows_pad; const int* cexp;
   float* slabs;
-  int n_pad, split, inner_per_wave;
+  int n_pad, split, inner_per_wave;      // inner_per_wave: inner rows of a BLOCK's slice here (its four waves share the slice and split the columns)
   int ncol = 0;                  // 2 KP (set by launch_maskgemm)
 };
 void launch_maskgemm(const MaskGemmArgs& a, int KP, hipStream_t st);
