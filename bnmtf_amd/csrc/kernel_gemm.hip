@@ -242,6 +242,9 @@ __global__ __launch_bounds__(256, (TW == 4 ? 1 : 2)) void gemm_bf16x3_kernel(Gem
         d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[mt]), __builtin_bit_cast(bf16x8, bh), d, 0, 0, 0);
         acc[mt][t] = d;
       }
+#ifdef BNMTF_GEMM_SLEEP          // (tools/variant.sh experiment: a pause behind every tile's products -- does a cooler contraction buy the sweep a higher clock?)
+      __builtin_amdgcn_s_sleep(BNMTF_GEMM_SLEEP);
+#endif
     }
   };
   const int nsteps = ipw / 16;                    // ipw is a multiple of 32 (host pads)
@@ -322,6 +325,9 @@ __global__ __launch_bounds__(256, (TW == 4 ? 1 : 2)) void gemm_bf16x3_kernel(Gem
   }
 }
 
+#ifndef BNMTF_GEMM_NSET
+#define BNMTF_GEMM_NSET 3        // raw-operand register sets of the ring (tools/variant.sh builds try 4)
+#endif
 void launch_gemm(const GemmArgs& a, int KP, hipStream_t st) {
   // (a launch covers the inner slices [split0, split0 + nsplit): all of them, or -- several GPUs -- first the ones over the rank's
   // own rows of the factor, the rest once the other ranks' blocks have arrived; every slice writes its own slab either way)
@@ -347,9 +353,9 @@ void launch_gemm(const GemmArgs& a, int KP, hipStream_t st) {
       return;
     }
 #endif
-    if (KP == 32) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 3, 4>), grid, block, 0, st, a);
-    else if (a.tw == 2) hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, 2>), dim3(a.n_pad / 64, ns), block, 0, st, a);
-    else          hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, 4>), grid, block, 0, st, a);
+    if (KP == 32) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, BNMTF_GEMM_NSET, 4>), grid, block, 0, st, a);
+    else if (a.tw == 2) hipLaunchKernelGGL((gemm_bf16x3_kernel<2, BNMTF_GEMM_NSET, 2>), dim3(a.n_pad / 64, ns), block, 0, st, a);
+    else          hipLaunchKernelGGL((gemm_bf16x3_kernel<2, BNMTF_GEMM_NSET, 4>), grid, block, 0, st, a);
     return;
   }
 #ifdef BNMTF_EXPERIMENTS
