@@ -225,6 +225,42 @@ def _small_model(w, R, M, seed):
     return m
 
 
+def _clock_beside(work, sync, seconds=2.0):
+    """Median shader clock (MHz) and socket power (W) by rocm-smi while `work()` is repeated for ~`seconds` (untimed)."""
+    import re, shutil, statistics, subprocess, threading
+    if shutil.which("rocm-smi") is None:
+        return None
+    rows, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            try:
+                card = json.loads(subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=10).stdout)
+                card = card[sorted(card)[0]]
+                sclk = next((float(re.sub(r"[^0-9.]", "", str(v))) for k, v in card.items() if k.lower().startswith("sclk") and "mhz" in str(v).lower()), None)
+                power = next((float(v) for k, v in card.items() if "power" in k.lower() and re.fullmatch(r"[0-9.]+", str(v))), None)
+                if sclk is not None:
+                    rows.append((sclk, power))
+            except Exception:      # noqa: BLE001 -- a reading is optional
+                return
+            stop.wait(0.05)
+
+    th = threading.Thread(target=sampler, daemon=True)
+    work(); sync()
+    th.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        work()
+        sync()
+    stop.set(); th.join(timeout=15)
+    rows = [r for r in rows if r[0] > 500.0]          # (a reading taken after the loop ended shows the idle clock)
+    if not rows:
+        return None
+    pw = [r[1] for r in rows if r[1] is not None]
+    return {"sclk_mhz_median": statistics.median(r[0] for r in rows), "power_w_median": statistics.median(pw) if pw else None, "readings": len(rows),
+            "what": "rocm-smi beside ~%.0f s of the device-resident loop, after the timed regions (untimed)" % seconds}
+
+
 def main_small(a, w):
     """The shapes the reference publishes numbers for: ONE small model through the class API (what its timing scripts do), a batch
     of independent models in one launch (folds / ranks / restarts of a model search), and the cost of building a model."""
@@ -330,6 +366,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps iterations each; value = median")
     ap.add_argument("--workload", default="bnmf_8192_k64", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-clock", action="store_true", help="skip the rocm-smi reading of shader clock / socket power behind the timed regions")
     ap.add_argument("--no-samples", action="store_true", help="leave the samples on the device in the timed loop too (then `value` is NOT the reference's iteration)")
     ap.add_argument("--batch", type=int, nargs="*", default=[16, 256], help="small workloads: models per batched call")
     ap.add_argument("--slots", type=int, nargs="*", default=[1, 4], help="cv_gdsc: replica slots on the GPU")
@@ -452,6 +489,11 @@ def main():
         run(a.steps)
         sync(); resident = a.steps / cp.allreduce_max(time.perf_counter() - t1)
 
+    # what the box sustains under this loop: the pool's boxes differ by +-5 % in rate, and that spread is the shader clock
+    # (~861 k cycles per iteration of the headline on either kind) -- rocm-smi read a few times beside ~2 s of the
+    # device-resident loop, after everything that is timed; None when rocm-smi is not there or says nothing
+    clock = _clock_beside(lambda: run(max(a.steps, 50)), sync) if world == 1 and not a.no_clock else None
+
     import ctypes as C_
     ck, cr = C_.c_int(), C_.c_int()
     _lib.check(L.bnmtf_comm_info(h, C_.byref(ck), C_.byref(cr)))
@@ -511,6 +553,7 @@ def main():
                                   ("none (the variational run() stores no samples)" if kind == "vb" else "device-resident (--no-samples)")},
             "repeats": {"n": len(dts), "values": [a.steps / d for d in dts], "min": a.steps / max(dts), "median": a.steps / dt, "max": a.steps / min(dts)},
             "device_resident": None if resident is None else {"value": resident, "unit": "iterations/s", "what": "same loop, samples left on the device"},
+            "clock": clock,
             "roofline": roof,
             "roofline_sweep": {"bound": "valu", "kernel": "sweep_cols: K sequential conditional updates per unit (LDS gathers + fp32 vector FMAs)",
                                "achieved": sweep_ach, "peak": PEAK_F32_VECTOR_TFLOPS, "unit": "TFLOP/s", "frac": sweep_ach / PEAK_F32_VECTOR_TFLOPS,
