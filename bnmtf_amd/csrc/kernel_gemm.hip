@@ -247,6 +247,9 @@ __global__ __launch_bounds__(256, (TW == 4 ? 1 : 2)) void gemm_bf16x3_kernel(Gem
 #endif
     }
   };
+#ifdef BNMTF_GEMM_STAGGER        // (tools/variant.sh experiment: the block's four waves -- one per SIMD -- a fraction of a step apart, so that their product bursts do not coincide)
+  for (int i = 0; i < wave; ++i) __builtin_amdgcn_s_sleep(BNMTF_GEMM_STAGGER);
+#endif
   const int nsteps = ipw / 16;                    // ipw is a multiple of 32 (host pads)
   // ring of NSET raw-operand register sets: NSET-1 steps (8 KiB of R~ each) in flight behind the one being multiplied.
   // No branch in the steady state (round 4): with the loads behind `if (more steps)` the compiler's wait counts at the join
