@@ -212,3 +212,13 @@ def test_gdsc_text_loader_round_trip(tmp_path):
     assert np.array_equal(M2, M) and np.array_equal(X2, X * M) and drugs == ["d1", "d2", "d3"] and cells == ["c1", "c2"] and tissues == ["s1", "s2"]
     assert np.array_equal(Xmin, np.where(M == 1, X - (-2.0 - 1), 0.0))
     assert np.array_equal(data.negate_gdsc(X2, M2), np.where(M == 1, -X + 4.0, 0.0))
+
+
+def test_bench_clock_reading_is_optional():
+    """bench.py's `clock` object: rocm-smi read beside an untimed loop.  Without a GPU (or without rocm-smi) it is None and nothing raises."""
+    import importlib.util, os, time
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    got = bench._clock_beside(lambda: time.sleep(0.01), lambda: None, seconds=0.3)
+    assert got is None or (got["sclk_mhz_median"] > 0 and got["readings"] >= 1)
