@@ -20,6 +20,7 @@
 // summed with ONE all-reduce -- the "K x L Gram" exchange -- after which every rank walks the same chain.
 // K, L <= 32 (one 32 x 32 MFMA tile per column / per row of A); larger ranks keep the per-row path of kernel_bnmtf.hip.
 #include <algorithm>
+#include <cstring>
 #include <type_traits>
 
 #include "sweep_common.h"
@@ -286,25 +287,78 @@ void launch_ssys_sum_parts(const float* slabs, int nsplit, size_t n, float* A, h
   hipLaunchKernelGGL(ssys_sum_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slabs, nsplit, n, A);
 }
 
-// r = b - A S (fp64 accumulation: b and A S nearly cancel at convergence), one wave per row
-// r = b - A S (fp64 dots), one wave per row.  Lanes 0-3 of the wave also make the first four sampler candidates of the
-// row's entry for the coming chain (random words only: they depend on (entry, iteration, key), not on A) -- a Philox call
-// each, hidden behind the dot product instead of standing at the head of the one-block chain kernel.
+// Ti_k = (I + N_k)^-1 for the chain's rows (ssys_chain_kernel, below): N_k[l][l''] = B[l''][l] / B[l][l] for l'' < l, B the
+// diagonal block k of A.  Unit lower triangular: column j of the inverse by forward substitution in fp64, one lane per column,
+// the row of N a broadcast LDS read; ~500 FMAs of one wave, beside the residual's dot products on other CUs.  A dead entry
+// (tau_p = tau A_aa <= 0 in fp32: what the chain tests) gets the unit row: it is drawn as 0 whatever stands before it.
+// Out: [32][32] per k, zeros beyond L (unit diagonal inside).
+__device__ __forceinline__ void ssys_tinv_body(const float* A, int K, int L, int k, float tau, float* out) {
+  __shared__ double Nl[32][32];
+  const int n2 = K * L, tid = threadIdx.x;
+  for (int e = tid; e < 1024; e += 256) {
+    const int l = e >> 5, m = e & 31;
+    double v = 0.0;
+    if (l < L && m < l) {
+      const float dg = A[(size_t)(k * L + l) * n2 + k * L + l];
+      if (tau * dg > 0.0f) v = (double)A[(size_t)(k * L + m) * n2 + k * L + l] / (double)dg;
+    }
+    Nl[l][m] = v;
+  }
+  __syncthreads();
+  if (tid >= 32) return;
+  const int j = tid;
+  double X[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    double s = i == j ? 1.0 : 0.0;
+#pragma unroll
+    for (int m = 0; m < i; ++m) s = fma(-Nl[i][m], X[m], s);
+    X[i] = (i < L && j < L) ? s : 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < 32; ++i) out[(size_t)k * 1024 + i * 32 + j] = (float)X[i];
+}
+
+// r = b - A S (fp64 dots: b and A S nearly cancel at convergence), one wave per row.  Lanes 0-3 of the wave also make the first
+// four sampler candidates of the row's entry for the coming chain (random words only: they depend on (entry, iteration, key),
+// not on A) -- a Philox call each, hidden behind the dot product instead of standing at the head of the one-block chain kernel.
 // (bparts != nullptr: b is still in its nparts per-block parts -- summed here, in part order, as ssys_sum_parts_kernel would, and
-// written to b as well)
+// written to b as well.)  K blocks behind the rows' make the chain's Ti (tinv != nullptr).
 __global__ __launch_bounds__(256) void ssys_residual_kernel(const float* A, float* b, const float* bparts, int nparts, const float* S, int n2, float* r,
-                                                            float4* cands, uint32_t it, uint32_t key0, uint32_t key1) {
+                                                            float4* cands, uint32_t it, uint32_t key0, uint32_t key1, float* tinv, int K, int L, const float* tau,
+                                                            float4* own8, float4* recT, float* Tn) {
+#pragma clang fp contract(off)
+  const int rblocks = (n2 + 3) / 4;
+  if ((int)blockIdx.x >= rblocks) { ssys_tinv_body(A, K, L, (int)blockIdx.x - rblocks, *tau, tinv); return; }
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n2) return;
   if (cands && lane < 4) {
     const U4 rr = philox4x32_10(0u, (uint32_t)row, it, kStreamS + 16u * (uint32_t)lane, key0, key1);
     const TnCand cd = tn_cand_pre(rr.x, rr.y);
     cands[row * 4 + lane] = make_float4(cd.nl, cd.z, cd.u2, 0.f);
+    if (own8) {                                                     // the chain's records (ssys_chain_kernel): everything of a draw that needs tau_p and the random words only
+      const TnPre pre = tn_fast_pre(*tau * A[(size_t)row * n2 + row]);
+      const float w2 = -1.38629436f * __builtin_amdgcn_logf(cd.u2);              // -2 ln u2 (v_log_f32 is log2)
+      const float4 rc4 = make_float4(cd.z * pre.irt, 2.0f * cd.nl - 2.0f, 2.0f * cd.nl * pre.irt, __builtin_amdgcn_sqrtf(w2));
+      recT[row * 4 + lane] = rc4;
+      if (lane == 0) {
+        own8[2 * row] = pre.live ? make_float4(rc4.x, pre.rcp, -kTnA0 * pre.irt, -pre.tpirt) : make_float4(0.f, 0.f, -__builtin_inff(), 0.f);
+        own8[2 * row + 1] = make_float4(rc4.y, rc4.z, rc4.w, 0.f);
+      }
+    }
   }
-  double s = 0.0;
-  for (int t = lane; t < n2; t += 64) s = fma((double)A[(size_t)row * n2 + t], (double)S[t], s);
+  // (so: the row's own old values up to itself put back -- sum_{l <= lp} S_(k,l) A[(k,l)][(k,lp)], row = (k, lp): the part of the
+  // same products that lies in the row's diagonal block at or before the diagonal; A is symmetric.  The chain adds it to r.)
+  const int blk0 = L > 0 ? row / L * L : 0;
+  double s = 0.0, so = 0.0;
+  for (int t = lane; t < n2; t += 64) {
+    const double p = (double)A[(size_t)row * n2 + t] * (double)S[t];
+    s += p;
+    if (t >= blk0 && t <= row) so += p;
+  }
 #pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+  for (int m = 32; m >= 1; m >>= 1) { s += __shfl_xor(s, m, 64); so += __shfl_xor(so, m, 64); }
+  if (lane == 0 && Tn) Tn[row] = (float)so;
   if (lane == 0) {
     float bv;
     if (bparts) {
@@ -321,8 +375,10 @@ __global__ __launch_bounds__(256) void ssys_residual_kernel(const float* A, floa
     r[row] = (float)((double)bv - s);
   }
 }
-void launch_ssys_residual(const float* A, float* b, const float* bparts, int nparts, const float* S, int n2, float* r, hipStream_t st, float* cands, uint32_t it, uint32_t key0, uint32_t key1) {
-  hipLaunchKernelGGL(ssys_residual_kernel, dim3((n2 + 3) / 4), dim3(256), 0, st, A, b, bparts, nparts, S, n2, r, reinterpret_cast<float4*>(cands), it, key0, key1);
+void launch_ssys_residual(const float* A, float* b, const float* bparts, int nparts, const float* S, int n2, float* r, hipStream_t st, float* cands, uint32_t it, uint32_t key0, uint32_t key1,
+                          float* tinv, int K, int L, const float* tau, float* own8, float* recT, float* Tn) {
+  hipLaunchKernelGGL(ssys_residual_kernel, dim3((n2 + 3) / 4 + (tinv ? K : 0)), dim3(256), 0, st, A, b, bparts, nparts, S, n2, r, reinterpret_cast<float4*>(cands), it, key0, key1, tinv, K, L, tau,
+                     reinterpret_cast<float4*>(own8), reinterpret_cast<float4*>(recT), Tn);
 }
 
 // The K.L sequential conditionals, row-major (k, l) (bnmtf_gibbs_optimised.py:157-160), one block of 8 waves.
@@ -347,7 +403,7 @@ void launch_ssys_residual(const float* A, float* b, const float* bparts, int npa
 //     out of registers, against the staged off-diagonal block.
 //   cond >= 0: only evaluate entry `cond` (numer, tau_p) and change nothing -- the tauS / muS hook.
 template <int UPDATE>      // 0: draws, 1: mode updates (ICM / the deterministic harness)
-__global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
+__global__ __launch_bounds__(512) void ssys_chain_seq_kernel(SSysChainArgs a) {
 #pragma clang fp contract(off)
   constexpr int NH = 4;                                            // hoisted candidates per entry
   // Od(k, k+1) is staged during row k-1 and read during row k+1: three buffers.  Spare rows / entries behind Om and the
@@ -638,7 +694,365 @@ __global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
   if (tid == 0 && (a.it == 30u || a.it == 31u)) printf("chain it %u: prologue %llu, row-pro %llu, steps %llu, barrier %llu cycles; slow %d taking %llu\n", a.it, c_begin - c_k0, c_pro, c_steps, c_wait, n_slow, c_slow);
 #endif
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the chain by ROWS.  The L conditionals of row k are one unit-lower-triangular system: with B the diagonal block of
+// A, base_l = -lambda_l + tau (r_l + sum_{l'' <= l} Sold_l'' B_l''l) (everything that does not depend on the row's new values)
+// and c_l = base_l / tau_p,l + z_l sigma_l (the entry's first candidate), the sequential steps are
+//     x_l = c_l - sum_{l'' < l} N_ll'' x_l'' ,   N_ll'' = B_l''l / B_ll        <=>        (I + N) x = c        <=>        x = Ti c ,
+// as long as every entry is in the normal regime and accepts its first candidate.  Ti = (I + N)^-1 depends on A only: K small
+// triangular inversions, made in fp64 by blocks that ride behind ssys_residual_kernel.  So the chain wave does NOT walk the
+// entries: it forms c (one FMA per lane), multiplies by Ti (16 FMAs per lane, the two halves of the wave take half of the
+// sum each) and TESTS the row in one go -- lane l is fine when x_l is a non-negative finite number and mu_l = x_l - z_l sigma_l
+// lies in the normal regime.  The first lane f that is not fine has a VALID conditional mean (it depends on the lanes before
+// it only, and they are fine): it is drawn on its own (the other hoisted candidates; the translated-exponential regime;
+// Philox rounds) and the value it ends with is put into the lanes behind it by ONE more FMA, x_l += Ti[l][f] (x_f' - x_f) --
+// the row's solution for the right-hand side with c_f replaced --, then the test is repeated for the lanes behind f.
+// tools/micro/lone_wave.hip: a lone wave issues a vector instruction every ~4 cycles, dependent or not (8 for rcp / sqrt; ~8
+// per instruction on a compare -> scalar -> readlane hop; an LDS read comes back after ~64).  A row is ~90 instructions and
+// three LDS round trips; a lane that leaves the fast form ~35 instructions, its records fetched while the lane before it is
+// still being drawn.  Mode updates (ICM, the deterministic harness): the same with c_l = base_l / tau_p,l and "fine" = the
+// clamp leaves x_l alone.
+// The translated-exponential draw (oracle/rng.py: e = nl / lam, accepted iff u2 <= exp(-(e - d)^2 / 2), x = e / sqrt(tau_p);
+// a = -mu sqrt(tau_p), d = 2 / (sqrt(a^2 + 4) + a), lam = a + d) is stated with 1 / lam = d (Robert's rate: lam d = 1):
+//     rc = 1 / (sqrt(a^2 + 4) + a),  t = e - d = (2 nl - 2) rc,  x = (2 nl sigma) rc,  accepted iff |t| <= sqrt(-2 ln u2)
+// -- the same events and values up to rounding, one reciprocal and no exponential on the chain; (2 nl - 2), 2 nl sigma and the
+// square root are per-candidate constants made by ssys_residual_kernel beside its dot products.
+// Rounding: Ti c sums the same products as the forward substitution in another order (both fp32; against the fp64 oracle they
+// are equally far, tests/test_bnmtf_gibbs_gpu.py); the chain is deterministic and the same on 1 and N GPUs (Ti is made from the
+// summed A).
+template <int UPDATE>      // 0: draws, 1: mode updates
+__global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
+#pragma clang fp contract(off)
+  constexpr int NH = 4, TS = 36;                                   // hoisted candidates per entry; row stride of a staged Ti (16-byte rows, conflict-free b128 reads)
+  __shared__ __align__(16) float r[1024];
+  __shared__ __align__(16) float delta[2][32];
+  __shared__ __align__(16) float cs[32];
+  __shared__ float Sl[1024], laml[1024], Tn[1024], Od[3][32 * 33];
+  __shared__ __align__(16) float Ti[2][32 * TS];
+  __shared__ float4 own8[2 * 1024];                                // per entry: {z0 sigma, 1 / tau_p, -A0 sigma, -sqrt(tau_p)}, {2 nl0 - 2, 2 nl0 sigma, sqrt(-2 ln u2_0), -}; dead: {0, 0, -inf, 0}
+  __shared__ float4 recT[UPDATE == 0 ? 1024 * NH : 1];             // per candidate: {z_c sigma, 2 nl - 2, 2 nl sigma, sqrt(-2 ln u2)}: the cold path
+  const int K = a.K, L = a.L, n2 = K * L, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float tau = *a.tau;
+#ifdef CHAIN_CLOCK
+  const unsigned long long c_k0 = __builtin_amdgcn_s_memtime();
+#endif
+  if (a.cond >= 0) {                                               // tauS(k,l) / muS(k,l) hook: the residual already holds everything
+    if (tid == 0) {
+      const float aaa = a.A[(size_t)a.cond * n2 + a.cond];
+      a.numer_out[0] = (double)fmaf(tau, a.r0[a.cond] + a.S[a.cond] * aaa, -a.lambdaS[a.cond]);
+      a.tau_out[0] = (double)(tau * aaa);
+    }
+    return;
+  }
+  // ---- background register pipeline: waves 1-3 and 5-7 (wave 4 shares wave 0's SIMD and idles).  The small blocks (Ti of a
+  // row, the block of A towards the next row) are issued in one row and stored in the next; the rows of A that fold a row's
+  // deltas into the residual of the rows behind it are issued TWO rows ahead of their use in two register sets that take turns
+  // (a row is short now: one row of slack did not cover the loads' latency).  Every thread issues the same loads in the same
+  // order whatever its items are (out of range: the buffer descriptor returns zeros; rows past the end: clamped), the small
+  // ones AHEAD of the fold's, so the wait in front of a store is "all but the newest twenty", not "all".
+  constexpr int NT = 512, NB = 384, QB = 3, QF = 5;
+  const bool bg = (wave & 3) != 0;
+  const int bt = (wave - 1 - (wave >> 2)) * 64 + lane;
+  float sm[QB], sd[QB];
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 fs0[QF][4], fs1[QF][4];
+  const bool vec = (L & 3) == 0;
+  const __amdgpu_buffer_rsrc_t rsAm = panel_rsrc(a.A, (size_t)n2 * n2 * 4);
+  // (invalid items are sent past the end of the descriptor by ARITHMETIC on the offset -- a select makes this compiler split the
+  // loads over divergent branches with a full wait in between)
+  constexpr int kPast = 0x40000000;
+  int od_off[QB], od_dst[QB];                                       // block (kk, kk+1) of A: byte offset inside the block's rows (past the end: none) / place in Od
+#pragma unroll
+  for (int q = 0; q < QB; ++q) {
+    const int t = bt + q * NB;
+    const bool v = t < L * L;
+    const int l1 = v ? t / L : 0, l2 = v ? t % L : 0;
+    od_off[q] = v ? 4 * (l1 * n2 + l2) : kPast; od_dst[q] = v ? l1 * 33 + l2 : -1;
+  }
+  int f_off[QF], f_row[4];                                          // fold items: byte offset of (row h, column 4 g) / kPast for the rows h + 8 j >= L
+#pragma unroll
+  for (int q = 0; q < QF; ++q) { const int w = bt + q * NB; f_off[q] = 4 * ((w & 7) * n2 + 4 * (w >> 3)); }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) f_row[j] = (bt & 7) + 8 * j < L ? 4 * 8 * j * n2 : kPast;
+  auto issue_blocks = [&](int kk) {                                // Ti of row kk and block (kk, kk+1) of A -> registers
+    const int sbase = kk + 1 < K ? 4 * (kk * L * n2 + (kk + 1) * L) : kPast;
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      sm[q] = a.Tinv[(size_t)kk * 1024 + min(bt + q * NB, 1023)];
+      sd[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsAm, od_off[q], sbase, 0));
+    }
+  };
+  auto store_blocks = [&](int kk) {
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      const int t = bt + q * NB;
+      if (t < 1024) Ti[kk & 1][(t >> 5) * TS + (t & 31)] = sm[q];
+      if (od_dst[q] >= 0) Od[kk % 3][od_dst[q]] = sd[q];
+    }
+  };
+  auto issue_fold = [&](int kk, f32x4 (&fs)[QF][4]) {              // A[(kk, h + 8 j)][t0 + 4 g ..+3], t0 = (kk + 2) L: item w = (g, h)
+    const int t0 = (kk + 2) * L, items = 2 * (n2 - t0);
+    const int sbase = 4 * (kk * L * n2 + t0);
+#pragma unroll
+    for (int q = 0; q < QF; ++q) {
+      const int w = bt + q * NB;
+      const int past = ((items - 1 - w) >> 31) & kPast;            // w >= items
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        fs[q][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsAm, f_off[q] + f_row[j] + past, sbase, 0));
+    }
+  };
+  auto consume_fold = [&](int kk, const f32x4 (&fs)[QF][4], const float* dp) {   // r[t] -= sum_l delta_(kk,l) A[(kk,l)][t] for t >= (kk + 2) L
+    const int t0 = (kk + 2) * L, items = 2 * (n2 - t0);
+#pragma unroll
+    for (int q = 0; q < QF; ++q) {
+      const int w = bt + q * NB, g = w >> 3, h = w & 7;
+      f32x4 sv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = dp[(h + 8 * j) & 31];
+        sv.x = fmaf(d, fs[q][j].x, sv.x); sv.y = fmaf(d, fs[q][j].y, sv.y); sv.z = fmaf(d, fs[q][j].z, sv.z); sv.w = fmaf(d, fs[q][j].w, sv.w);
+      }
+      // the eight residues sit in eight adjacent lanes: xor 1, xor 2, then the other quad of the eight (the same tree as a butterfly)
+#pragma unroll
+      for (int cidx = 0; cidx < 4; ++cidx) {
+        float v = sv[cidx];
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+        sv[cidx] = v;
+      }
+      if (h == 0 && w < items) {
+        float4* rp = reinterpret_cast<float4*>(&r[t0 + 4 * g]);
+        float4 o = *rp;
+        o.x -= sv.x; o.y -= sv.y; o.z -= sv.z; o.w -= sv.w;
+        *rp = o;
+      }
+    }
+  };
+  // ---- prologue: every array the chain reads is a straight copy of what ssys_residual_kernel left in global memory -- LDS-DMA
+  // through buffer descriptors (1 KiB per wave instruction, no registers, past the end: zeros), ONE memory round trip.  The
+  // background waves' first loads go out around it.
+  if (bg) issue_blocks(0);
+  {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    int ch = wave;                                                  // chunks of 1 KiB, dealt round the eight waves across all the arrays
+    auto dma = [&](const void* src, size_t bytes, void* dst, int chunks) {
+      const __amdgpu_buffer_rsrc_t rs = panel_rsrc(reinterpret_cast<const float*>(src), bytes);
+      for (; ch < chunks; ch += 8)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(reinterpret_cast<char*>(dst) + (size_t)ch * 1024), 16, lane * 16, ch * 1024, 0, 0);
+      ch -= chunks;
+    };
+    const int c4 = (n2 * 4 + 1023) / 1024;
+    dma(a.r0, (size_t)n2 * 4, r, c4);
+    dma(a.S, (size_t)n2 * 4, Sl, c4);
+    dma(a.lambdaS, (size_t)n2 * 4, laml, c4);
+    dma(a.Tn, (size_t)n2 * 4, Tn, c4);
+    dma(a.own8, (size_t)n2 * 32, own8, (n2 * 32 + 1023) / 1024);
+    if (UPDATE == 0) dma(a.recT, (size_t)n2 * 64, recT, (n2 * 64 + 1023) / 1024);
+  }
+  if (tid < 64) { delta[0][tid & 31] = 0.f; delta[1][tid & 31] = 0.f; }
+  for (int t = tid; t < 3 * 32 * 33; t += NT) (&Od[0][0])[t] = 0.f;
+  if (bg) {
+    store_blocks(0); issue_blocks(min(1, K - 1));
+    if (vec) issue_fold(0, fs0);
+  }
+  // the copies are older than the loads just issued: "all but the newest" covers them (26 = 6 small + 20 fold loads; the
+  // scalar path of L not a multiple of four, and the waves without loads, wait for everything)
+  if (bg && vec) asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
+  else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef CHAIN_CLOCK
+  unsigned long long c_pro = 0, c_fix = 0, c_wait = 0, c_t0 = __builtin_amdgcn_s_memtime(), c_begin = c_t0; int n_fix = 0, n_cold = 0;
+#endif
+  if (wave == 0) {
+    const int l32 = lane & 31, hb = lane & 32 ? 16 : 0;
+    const bool on = l32 < L;
+    const uint32_t lmask = L >= 32 ? 0xffffffffu : ((1u << L) - 1u);
+    for (int k = 0; k < K; ++k) {
+      const int cur = k & 1;
+      const int me = k * L + (on ? l32 : 0);
+      float my_eta = r[me];
+      const float4 o0 = own8[2 * me], o1 = own8[2 * me + 1];
+      const float my_sold = Sl[me], my_lam = laml[me], my_tn = Tn[me];
+      float trow[32];                                               // the lane's row of Ti: the product below, and the column a corrected lane spreads by
+      {
+        const float4* tp4 = reinterpret_cast<const float4*>(Ti[cur] + l32 * TS);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float4 v = tp4[j]; trow[4 * j] = v.x; trow[4 * j + 1] = v.y; trow[4 * j + 2] = v.z; trow[4 * j + 3] = v.w; }
+      }
+      if (k > 0) {                                                  // the previous row's deltas, which the background pass has not folded in yet
+        const float* od = Od[(k - 1) % 3] + hb * 33 + l32;
+        const float* dq = delta[cur ^ 1] + hb;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = fmaf(dq[j], od[j * 33], acc);
+        my_eta -= half_swap_sum(acc);
+      }
+      const float base = fmaf(tau, my_eta + my_tn, -my_lam);
+      float c = on ? fmaf(base, o0.y, UPDATE == 0 ? o0.x : 0.f) : 0.f;
+      // (an overflowed numerator: the entry is drawn as a dead one, 0 -- and must not poison the row's product)
+      const uint32_t forced = (uint32_t)__builtin_amdgcn_ballot_w64(!(fabsf(c) < __builtin_inff())) & lmask;
+      c = fabsf(c) < __builtin_inff() ? c : 0.f;
+      cs[l32] = c;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      float x = 0.f;
+      {
+        const float4* cp4 = reinterpret_cast<const float4*>(cs);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float4 v = cp4[j];
+          x = fmaf(trow[4 * j], v.x, x); x = fmaf(trow[4 * j + 1], v.y, x); x = fmaf(trow[4 * j + 2], v.z, x); x = fmaf(trow[4 * j + 3], v.w, x);
+        }
+      }
+#ifdef CHAIN_CLOCK
+      { const unsigned long long tt = __builtin_amdgcn_s_memtime(); c_pro += tt - c_t0; c_t0 = tt; }
+#endif
+      uint32_t todo = lmask;
+      for (;;) {
+        uint32_t bad, nrm = 0u, easy; float dlv, xv;                // lane f's correction and new value, where the lane can make them itself
+        if (UPDATE == 0) {
+          // every lane: its conditional mean, and -- should it turn out to be the first lane in the translated-exponential
+          // regime -- its first candidate there (header): the lane a correction is due for has a final mean
+          const float mu = x - o0.x, aa = mu * o0.w;
+          const float rc = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(aa, aa, 4.0f)) + aa);
+          const float tt = o1.x * rc;
+          xv = o1.y * rc;
+          dlv = xv - x;
+          unsigned long long mc;
+          asm("v_cmp_class_f32 %0, %1, %2" : "=s"(mc) : "v"(x), "s"(0x1C0));     // +0, +denormal, +normal
+          nrm = (uint32_t)__builtin_amdgcn_ballot_w64(mu > o0.z);                 // normal regime: a = -mu sqrt(tau_p) < A0 (a dead entry: always)
+          bad = todo & (~((uint32_t)mc & nrm) | forced);
+          easy = (uint32_t)__builtin_amdgcn_ballot_w64(fabsf(tt) <= o1.z) & ~nrm & ~forced;
+        } else {
+          xv = fmaxf((o0.y > 0.f && x > 0.f) ? x : 0.f, a.min_x);
+          dlv = xv - x;
+          bad = todo & (~(uint32_t)__builtin_amdgcn_ballot_w64(xv == x) | forced);
+          easy = ~forced;
+        }
+        if (bad == 0u) break;
+#ifdef CHAIN_CLOCK
+        ++n_fix;
+#endif
+        const int f = __builtin_ctz(bad);
+        todo &= 0xfffffffeu << f;
+        float xnew, dl;
+        if (__builtin_expect((easy >> f) & 1u, 1)) {
+          dl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dlv), f));
+          xnew = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xv), f));
+        } else {
+#ifdef CHAIN_CLOCK
+          ++n_cold;
+#endif
+          if (UPDATE == 0) {                                        // the other hoisted candidates (the first one in the normal regime), Philox rounds, overflow
+            const float vf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x - o0.x), f));
+            float xc = 0.f; unsigned long long m = 0ull;
+            if (((forced >> f) & 1u) == 0u) {
+              const float4 rec = recT[(k * L + f) * NH + (lane & (NH - 1))];
+              const float aa = vf * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o0.w), f));
+              const bool tail = ((nrm >> f) & 1u) == 0u;
+              if (tail) {
+                const float rc = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(aa, aa, 4.0f)) + aa);
+                xc = rec.z * rc;
+                m = __builtin_amdgcn_ballot_w64(fabsf(rec.y * rc) <= rec.w) & ((1ull << NH) - 1ull);
+              } else {
+                unsigned long long mt;
+                xc = vf + rec.x;
+                asm("v_cmp_class_f32 %0, %1, %2" : "=s"(mt) : "v"(xc), "s"(0x1C0));
+                m = mt & ((1ull << NH) - 1ull);
+              }
+              if (m == 0ull) {                                      // all four rejected: Philox rounds, candidates NH + 64 round + lane
+                const float sg = -4.0f * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o0.z), f));
+                static_assert(kTnA0 == 0.25f, "sigma above is -thr / A0");
+                TnFast tp; tp.mu = vf; tp.irt = sg; tp.a = aa; tp.live = true; tp.tail = tail;
+                tp.d = 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(aa, aa, 4.0f)) + aa); tp.ilam = __builtin_amdgcn_rcpf(aa + tp.d);
+                if (isfinite(aa) && sg < __builtin_inff())
+                  for (uint32_t round = 0; m == 0ull && round < 64u; ++round) {
+                    const U4 rr = philox4x32_10(0u, (uint32_t)(k * L + f), a.it, kStreamS + 16u * ((uint32_t)NH + round * 64u + (uint32_t)lane), a.key0, a.key1);
+                    const bool acc = tn_eval_fast(tp, rr.x, rr.y, &xc);
+                    m = __builtin_amdgcn_ballot_w64(acc && isfinite(xc) && xc >= 0.0f);
+                  }
+              }
+            }
+            if (m == 0ull) { xc = 0.f; m = 1ull; }                  // overflow, or 4100 rejections
+            xnew = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xc), __builtin_ctzll(m)));
+          } else {
+            xnew = fmaxf(0.f, a.min_x);
+          }
+          dl = xnew - __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), f));
+        }
+        x = fmaf(trow[f], dl, x);                                   // trow[f] = 0 in the lanes before f: their values stay as they are, bit for bit
+        x = lane == f ? xnew : x;                                   // lane f takes its value as it is (the mirror lane f + 32 keeps its own: nothing reads the upper half's x)
+      }
+#ifdef CHAIN_CLOCK
+      { const unsigned long long tt = __builtin_amdgcn_s_memtime(); c_fix += tt - c_t0; c_t0 = tt; }
+#endif
+      if (lane < L) { Sl[k * L + lane] = x; delta[cur][lane] = x - my_sold; }
+      __syncthreads();
+#ifdef CHAIN_CLOCK
+      { const unsigned long long tt = __builtin_amdgcn_s_memtime(); c_wait += tt - c_t0; c_t0 = tt; }
+#endif
+    }
+  } else {
+#ifdef CHAIN_CLOCK
+    unsigned long long b_work = 0, b_wait = 0, b_t0 = __builtin_amdgcn_s_memtime();
+#endif
+    auto bg_row = [&](int k, f32x4 (&fs)[QF][4]) {                  // fs: issued two rows ago = the rows of A for row k-1's deltas
+      if (bg) {
+        if (k + 1 < K) store_blocks(k + 1);
+        const float* dp = delta[(k & 1) ^ 1];
+        if (vec) {
+          if (k > 0) consume_fold(k - 1, fs, dp);
+        } else if (k > 0 && k + 1 < K) {
+          const int t0 = (k + 1) * L;
+          for (int t = t0 + bt; t < n2; t += NB) {
+            const float* col = a.A + (size_t)((k - 1) * L) * n2 + t;
+            float s = r[t];
+            for (int l0 = 0; l0 < L; l0 += 8) {
+              float av[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) av[j] = l0 + j < L ? col[(size_t)(l0 + j) * n2] : 0.f;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) s = fmaf(-dp[(l0 + j) & 31], av[j], s);
+            }
+            r[t] = s;
+          }
+        }
+        issue_blocks(min(k + 2, K - 1));
+        if (vec && k > 0) issue_fold(k + 1, fs);
+      }
+#ifdef CHAIN_CLOCK
+      { const unsigned long long tt = __builtin_amdgcn_s_memtime(); b_work += tt - b_t0; b_t0 = tt; }
+#endif
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef CHAIN_CLOCK
+      { const unsigned long long tt = __builtin_amdgcn_s_memtime(); b_wait += tt - b_t0; b_t0 = tt; }
+#endif
+    };
+    for (int k = 0; k < K; k += 2) {
+      bg_row(k, fs1);                                               // row k (even) consumes the fold of row k-1 (odd): set 1
+      if (k + 1 < K) bg_row(k + 1, fs0);
+    }
+#ifdef CHAIN_CLOCK
+    if ((tid == 64 || tid == 7 * 64) && a.it == 30u) printf("bg wave %d: work %llu wait %llu\n", wave, b_work, b_wait);
+#endif
+  }
+  for (int e = tid; e < n2; e += NT) a.S[e] = Sl[e];
+#ifdef CHAIN_CLOCK
+  if (tid == 0 && (a.it == 30u || a.it == 31u)) printf("chain it %u: prologue %llu, rows (solve) %llu, fixes %llu (%d entries, %d cold), barrier %llu cycles\n", a.it, c_begin - c_k0, c_pro, c_fix, n_fix, n_cold, c_wait);
+#endif
+}
 void launch_ssys_chain(const SSysChainArgs& a, hipStream_t st) {
+  static const bool seq = getenv("BNMTF_SCHAIN") != nullptr && !strcmp(getenv("BNMTF_SCHAIN"), "seq");
+  if (seq) {
+    if (a.update == 0) hipLaunchKernelGGL(ssys_chain_seq_kernel<0>, dim3(1), dim3(512), 0, st, a);
+    else               hipLaunchKernelGGL(ssys_chain_seq_kernel<1>, dim3(1), dim3(512), 0, st, a);
+    return;
+  }
   if (a.update == 0) hipLaunchKernelGGL(ssys_chain_kernel<0>, dim3(1), dim3(512), 0, st, a);
   else               hipLaunchKernelGGL(ssys_chain_kernel<1>, dim3(1), dim3(512), 0, st, a);
 }

@@ -333,14 +333,19 @@ void launch_ssys_b(const SSysBArgs& a, hipStream_t st);
 void launch_ssys_reduce(const float* slabs, int nsplit, int K, int L, float* A, hipStream_t st);   // sum the slabs on k <= k', mirror
 void launch_ssys_sum_parts(const float* parts, int nparts, size_t n, float* out, hipStream_t st);
 // r = b - A S.  bparts != nullptr: b is summed from its nparts per-block parts first (and stored).  cands [n2][4][4]: the chain's first candidates (draws)
+// tinv != nullptr: K more blocks make Ti_k = (I + N_k)^-1 [K][32][32] for the chain's rows (needs K, L, the device's tau)
 void launch_ssys_residual(const float* A, float* b, const float* bparts, int nparts, const float* S, int n2, float* r, hipStream_t st,
-                          float* cands = nullptr, uint32_t it = 0, uint32_t key0 = 0, uint32_t key1 = 0);
+                          float* cands = nullptr, uint32_t it = 0, uint32_t key0 = 0, uint32_t key1 = 0,
+                          float* tinv = nullptr, int K = 0, int L = 0, const float* tau = nullptr, float* own8 = nullptr, float* recT = nullptr, float* Tn = nullptr);
 struct SSysChainArgs {
   int K, L, update, cond;              // update: 0 draw, else mode (clamped from below by min_x); cond >= 0: evaluate entry cond only
   float min_x;
   const float* A; const float* r0; float* S; const float* lambdaS; const float* tau;
   uint32_t key0, key1, it;
   const float4* cands;                 // [K L][4] {-log u1, z, u2, -} of iteration `it` (ssys_residual_kernel); draws only
+  const float* Tinv;                   // [K][32][32]: (I + N_k)^-1 of every row's diagonal block (ssys_residual_kernel's extra blocks)
+  const float4* own8; const float4* recT;   // [K L][2] per-entry and [K L][4] per-candidate constants of the draws (ssys_residual_kernel)
+  const float* Tn;                     // [K L]: the row's own old values up to the entry put back (ssys_residual_kernel)
   double* numer_out; double* tau_out;
 };
 void launch_ssys_chain(const SSysChainArgs& a, hipStream_t st);

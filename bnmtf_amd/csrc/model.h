@@ -158,7 +158,7 @@ struct bnmtf_model {
   // the dense S system (kernel_ssys.hip): packed upper triangles of the per-column masked Grams (Wc) and of G_j G_j^T (Gc),
   // column-range slabs of their product, AB = [A (n2 x n2) | b (n2)] (one buffer, one all-reduce), the residual, the
   // per-block partials of b, and the chain's first sampler candidates of the iteration
-  float *ss_Wc = nullptr, *ss_Gc = nullptr, *ss_slabs = nullptr, *ss_AB = nullptr, *ss_r = nullptr, *ss_bpart = nullptr, *ss_cands = nullptr;
+  float *ss_Wc = nullptr, *ss_Gc = nullptr, *ss_slabs = nullptr, *ss_AB = nullptr, *ss_r = nullptr, *ss_bpart = nullptr, *ss_cands = nullptr, *ss_tinv = nullptr, *ss_rec = nullptr;
   // posterior means accumulated on the device (bnmtf_set_expectation): sums over the iterations burn_in, burn_in + thinning, ...
   int exp_burn = -1, exp_thin = 1; uint64_t exp_count = 0;
   double *exp_rows = nullptr, *exp_cols = nullptr, *exp_S = nullptr, *exp_tau = nullptr;

@@ -34,6 +34,15 @@ __device__ __forceinline__ float half_sum_upper_fused(float v) {
   asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
   return v;
 }
+// v[lane & 31] + v[(lane & 31) + 32] in every lane, the lower half's term first in both halves (gfx950's v_permlane32_swap:
+// the upper half of the first operand and the lower half of the second change places; written as asm because the builtin of
+// this compiler folds the two results of a swap of a register with its own copy into one).  s_nop 1: the wait states
+// behind the vector instruction that wrote the operands.
+__device__ __forceinline__ float half_swap_sum(float v) {
+  float lo = v, hi = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+  return lo + hi;
+}
 __device__ __forceinline__ double half_sum_d(double v) {
 #pragma unroll
   for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
