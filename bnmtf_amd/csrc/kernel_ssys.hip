@@ -816,14 +816,16 @@ __global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
         sv.x = fmaf(d, fs[q][j].x, sv.x); sv.y = fmaf(d, fs[q][j].y, sv.y); sv.z = fmaf(d, fs[q][j].z, sv.z); sv.w = fmaf(d, fs[q][j].w, sv.w);
       }
       // the eight residues sit in eight adjacent lanes: xor 1, xor 2, then the other quad of the eight (the same tree as a butterfly)
-#pragma unroll
-      for (int cidx = 0; cidx < 4; ++cidx) {
-        float v = sv[cidx];
-        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
-        sv[cidx] = v;
-      }
+      // (one instruction per step and component: through the builtin the compiler makes a DPP move and an add; s_nop 1 = the
+      // wait states a DPP read needs behind the vector instruction that wrote its source -- the four components hide each other's)
+      asm volatile("s_nop 1\n\t"
+                   "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf"
+                   : "+v"(sv.x), "+v"(sv.y), "+v"(sv.z), "+v"(sv.w));
       if (h == 0 && w < items) {
         float4* rp = reinterpret_cast<float4*>(&r[t0 + 4 * g]);
         float4 o = *rp;
@@ -1007,23 +1009,26 @@ __global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
         const float* dp = delta[(k & 1) ^ 1];
         if (vec) {
           if (k > 0) consume_fold(k - 1, fs, dp);
-        } else if (k > 0 && k + 1 < K) {
-          const int t0 = (k + 1) * L;
-          for (int t = t0 + bt; t < n2; t += NB) {
-            const float* col = a.A + (size_t)((k - 1) * L) * n2 + t;
-            float s = r[t];
-            for (int l0 = 0; l0 < L; l0 += 8) {
-              float av[8];
+          issue_blocks(min(k + 2, K - 1));
+          issue_fold(k + 1, fs);                                     // (past the last rows: every offset beyond the matrix, zeros)
+        } else {
+          if (k > 0 && k + 1 < K) {
+            const int t0 = (k + 1) * L;
+            for (int t = t0 + bt; t < n2; t += NB) {
+              const float* col = a.A + (size_t)((k - 1) * L) * n2 + t;
+              float s = r[t];
+              for (int l0 = 0; l0 < L; l0 += 8) {
+                float av[8];
 #pragma unroll
-              for (int j = 0; j < 8; ++j) av[j] = l0 + j < L ? col[(size_t)(l0 + j) * n2] : 0.f;
+                for (int j = 0; j < 8; ++j) av[j] = l0 + j < L ? col[(size_t)(l0 + j) * n2] : 0.f;
 #pragma unroll
-              for (int j = 0; j < 8; ++j) s = fmaf(-dp[(l0 + j) & 31], av[j], s);
+                for (int j = 0; j < 8; ++j) s = fmaf(-dp[(l0 + j) & 31], av[j], s);
+              }
+              r[t] = s;
             }
-            r[t] = s;
           }
+          issue_blocks(min(k + 2, K - 1));
         }
-        issue_blocks(min(k + 2, K - 1));
-        if (vec && k > 0) issue_fold(k + 1, fs);
       }
 #ifdef CHAIN_CLOCK
       { const unsigned long long tt = __builtin_amdgcn_s_memtime(); b_work += tt - b_t0; b_t0 = tt; }
