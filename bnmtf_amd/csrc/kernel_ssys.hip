@@ -728,8 +728,9 @@ __global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
   __shared__ __align__(16) float r[1024];
   __shared__ __align__(16) float delta[2][32];
   __shared__ __align__(16) float cs[32];
-  __shared__ float Sl[1024], laml[1024], Tn[1024], Od[3][32 * 33];
-  __shared__ __align__(16) float Ti[2][32 * TS];
+  __shared__ __align__(16) float Sl[1024], laml[1024], Tn[1024];
+  __shared__ __align__(16) float Od[3][32 * 32];                   // block (kk, kk+1) of A, by kk mod 3: stored during row kk-1, read during row kk+1
+  __shared__ __align__(16) float Ti[2][32 * TS];                   // Ti of row kk, by kk mod 2: stored during row kk-1
   __shared__ float4 own8[2 * 1024];                                // per entry: {z0 sigma, 1 / tau_p, -A0 sigma, -sqrt(tau_p)}, {2 nl0 - 2, 2 nl0 sigma, sqrt(-2 ln u2_0), -}; dead: {0, 0, -inf, 0}
   __shared__ float4 recT[UPDATE == 0 ? 1024 * NH : 1];             // per candidate: {z_c sigma, 2 nl - 2, 2 nl sigma, sqrt(-2 ln u2)}: the cold path
   const int K = a.K, L = a.L, n2 = K * L, tid = threadIdx.x, lane = tid & 63;
@@ -746,51 +747,56 @@ __global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
     }
     return;
   }
-  // ---- background register pipeline: waves 1-3 and 5-7 (wave 4 shares wave 0's SIMD and idles).  The small blocks (Ti of a
-  // row, the block of A towards the next row) are issued in one row and stored in the next; the rows of A that fold a row's
-  // deltas into the residual of the rows behind it are issued TWO rows ahead of their use in two register sets that take turns
-  // (a row is short now: one row of slack did not cover the loads' latency).  Every thread issues the same loads in the same
-  // order whatever its items are (out of range: the buffer descriptor returns zeros; rows past the end: clamped), the small
-  // ones AHEAD of the fold's, so the wait in front of a store is "all but the newest twenty", not "all".
-  constexpr int NT = 512, NB = 384, QB = 3, QF = 5;
+  // ---- the other waves.  Waves 1-3 and 5-7 FOLD: the rows of A that put a row's deltas into the residual of the rows behind it
+  // are loaded TWO rows ahead of their use into two register sets that take turns (a row is short now: one row of slack did not
+  // cover the loads' latency); every thread issues the same twenty loads per row whatever its items are (out of range: the buffer
+  // descriptor returns zeros), and these waves issue no other vector-memory operation inside the loop, so the compiler's wait in
+  // front of a set's first use is "all but the newest twenty".  Wave 4 -- on wave 0's SIMD, where it costs the chain ~40 issue
+  // slots a row -- STAGES what the chain wave reads besides the residual: Ti of a row and the block of A towards the next row,
+  // loaded two rows ahead, stored one row ahead (registers in between; its waits concern nothing else).
+  constexpr int NT = 512, NB = 384, QF = 5;
   const bool bg = (wave & 3) != 0;
   const int bt = (wave - 1 - (wave >> 2)) * 64 + lane;
-  float sm[QB], sd[QB];
   typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) void* lds_ptr;
   f32x4 fs0[QF][4], fs1[QF][4];
   const bool vec = (L & 3) == 0;
   const __amdgpu_buffer_rsrc_t rsAm = panel_rsrc(a.A, (size_t)n2 * n2 * 4);
   // (invalid items are sent past the end of the descriptor by ARITHMETIC on the offset -- a select makes this compiler split the
   // loads over divergent branches with a full wait in between)
   constexpr int kPast = 0x40000000;
-  int od_off[QB], od_dst[QB];                                       // block (kk, kk+1) of A: byte offset inside the block's rows (past the end: none) / place in Od
-#pragma unroll
-  for (int q = 0; q < QB; ++q) {
-    const int t = bt + q * NB;
-    const bool v = t < L * L;
-    const int l1 = v ? t / L : 0, l2 = v ? t % L : 0;
-    od_off[q] = v ? 4 * (l1 * n2 + l2) : kPast; od_dst[q] = v ? l1 * 33 + l2 : -1;
-  }
   int f_off[QF], f_row[4];                                          // fold items: byte offset of (row h, column 4 g) / kPast for the rows h + 8 j >= L
 #pragma unroll
   for (int q = 0; q < QF; ++q) { const int w = bt + q * NB; f_off[q] = 4 * ((w & 7) * n2 + 4 * (w >> 3)); }
 #pragma unroll
   for (int j = 0; j < 4; ++j) f_row[j] = (bt & 7) + 8 * j < L ? 4 * 8 * j * n2 : kPast;
-  auto issue_blocks = [&](int kk) {                                // Ti of row kk and block (kk, kk+1) of A -> registers
-    const int sbase = kk + 1 < K ? 4 * (kk * L * n2 + (kk + 1) * L) : kPast;
+  // the stager's pieces: 16 bytes per lane and piece; Ti of a row = 4 pieces (the row's 32 x 32 floats, contiguous), the block
+  // (kk, kk+1) of A = 4 pieces (a lane's four floats out of its row of A; rows / columns beyond L and the block behind the last
+  // row: past the descriptor, zeros)
+  f32x4 tq[4], oq[4];
+  auto stage_issue = [&](int kk) {
+    const int sb = kk + 1 < K ? 4 * (kk * L * n2 + (kk + 1) * L) : kPast;
 #pragma unroll
-    for (int q = 0; q < QB; ++q) {
-      sm[q] = a.Tinv[(size_t)kk * 1024 + min(bt + q * NB, 1023)];
-      sd[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsAm, od_off[q], sbase, 0));
+    for (int j = 0; j < 4; ++j) {
+      const int idx = j * 64 + lane;
+      tq[j] = *reinterpret_cast<const f32x4*>(a.Tinv + (size_t)kk * 1024 + 4 * idx);
+      const int l1 = idx >> 3, c4 = (idx & 7) * 4;
+      const int past = (((L - 1 - l1) | (L - 1 - c4)) >> 31) & kPast;
+      oq[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsAm, 4 * (l1 * n2 + c4) + past, sb, 0));
     }
   };
-  auto store_blocks = [&](int kk) {
+  auto stage_store = [&](int kk) {
 #pragma unroll
-    for (int q = 0; q < QB; ++q) {
-      const int t = bt + q * NB;
-      if (t < 1024) Ti[kk & 1][(t >> 5) * TS + (t & 31)] = sm[q];
-      if (od_dst[q] >= 0) Od[kk % 3][od_dst[q]] = sd[q];
+    for (int j = 0; j < 4; ++j) {
+      const int idx = j * 64 + lane;
+      *reinterpret_cast<f32x4*>(Ti[kk & 1] + (idx >> 3) * TS + (idx & 7) * 4) = tq[j];
+      if (vec) *reinterpret_cast<f32x4*>(Od[kk % 3] + 4 * idx) = oq[j];
     }
+    if (!vec)                                                       // L not a multiple of four (no aligned 16-byte pieces): the block element by element, at once
+      for (int t = lane; t < 1024; t += 64) {
+        const int l1 = t >> 5, l2 = t & 31;
+        Od[kk % 3][t] = (l1 < L && l2 < L && kk + 1 < K) ? a.A[(size_t)(kk * L + l1) * n2 + (kk + 1) * L + l2] : 0.f;
+      }
   };
   auto issue_fold = [&](int kk, f32x4 (&fs)[QF][4]) {              // A[(kk, h + 8 j)][t0 + 4 g ..+3], t0 = (kk + 2) L: item w = (g, h)
     const int t0 = (kk + 2) * L, items = 2 * (n2 - t0);
@@ -837,9 +843,7 @@ __global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
   // ---- prologue: every array the chain reads is a straight copy of what ssys_residual_kernel left in global memory -- LDS-DMA
   // through buffer descriptors (1 KiB per wave instruction, no registers, past the end: zeros), ONE memory round trip.  The
   // background waves' first loads go out around it.
-  if (bg) issue_blocks(0);
   {
-    typedef __attribute__((address_space(3))) void* lds_ptr;
     int ch = wave;                                                  // chunks of 1 KiB, dealt round the eight waves across all the arrays
     auto dma = [&](const void* src, size_t bytes, void* dst, int chunks) {
       const __amdgpu_buffer_rsrc_t rs = panel_rsrc(reinterpret_cast<const float*>(src), bytes);
@@ -856,15 +860,15 @@ __global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
     if (UPDATE == 0) dma(a.recT, (size_t)n2 * 64, recT, (n2 * 64 + 1023) / 1024);
   }
   if (tid < 64) { delta[0][tid & 31] = 0.f; delta[1][tid & 31] = 0.f; }
-  for (int t = tid; t < 3 * 32 * 33; t += NT) (&Od[0][0])[t] = 0.f;
-  if (bg) {
-    store_blocks(0); issue_blocks(min(1, K - 1));
-    if (vec) issue_fold(0, fs0);
-  }
-  // the copies are older than the loads just issued: "all but the newest" covers them (26 = 6 small + 20 fold loads; the
-  // scalar path of L not a multiple of four, and the waves without loads, wait for everything)
-  if (bg && vec) asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
-  else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (wave == 4) { stage_issue(0); stage_store(0); }
+  // (the builtin, not an asm statement: the compiler has to SEE that the copies have landed, or it puts a full wait in front of
+  // every LDS read it cannot tell apart from their destinations -- inside the row loops)
+  __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0)
+  if (wave == 4) stage_issue(min(1, K - 1));
+  // (row 0 runs the same code as every other row -- it "consumes" a set of zeros against deltas of zero, loaded from past the
+  // matrix --, so that at every first use of a set exactly twenty newer loads are in flight, on the first trip as on all others:
+  // the compiler's wait count is the worst case over the ways into the loop)
+  if (bg && vec) { issue_fold(K, fs1); issue_fold(0, fs0); }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #ifdef CHAIN_CLOCK
   unsigned long long c_pro = 0, c_fix = 0, c_wait = 0, c_t0 = __builtin_amdgcn_s_memtime(), c_begin = c_t0; int n_fix = 0, n_cold = 0;
@@ -886,11 +890,11 @@ __global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
         for (int j = 0; j < 8; ++j) { const float4 v = tp4[j]; trow[4 * j] = v.x; trow[4 * j + 1] = v.y; trow[4 * j + 2] = v.z; trow[4 * j + 3] = v.w; }
       }
       if (k > 0) {                                                  // the previous row's deltas, which the background pass has not folded in yet
-        const float* od = Od[(k - 1) % 3] + hb * 33 + l32;
+        const float* od = Od[(k - 1) % 3] + hb * 32 + l32;
         const float* dq = delta[cur ^ 1] + hb;
         float acc = 0.f;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc = fmaf(dq[j], od[j * 33], acc);
+        for (int j = 0; j < 16; ++j) acc = fmaf(dq[j], od[j * 32], acc);
         my_eta -= half_swap_sum(acc);
       }
       const float base = fmaf(tau, my_eta + my_tn, -my_lam);
@@ -999,18 +1003,20 @@ __global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
       { const unsigned long long tt = __builtin_amdgcn_s_memtime(); c_wait += tt - c_t0; c_t0 = tt; }
 #endif
     }
+  } else if (wave == 4) {                                            // the stager: its own loop (its registers do not meet the fold's)
+    for (int k = 0; k < K; ++k) {
+      if (k + 1 < K) { stage_store(k + 1); stage_issue(min(k + 2, K - 1)); }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
   } else {
 #ifdef CHAIN_CLOCK
     unsigned long long b_work = 0, b_wait = 0, b_t0 = __builtin_amdgcn_s_memtime();
 #endif
     auto bg_row = [&](int k, f32x4 (&fs)[QF][4]) {                  // fs: issued two rows ago = the rows of A for row k-1's deltas
       if (bg) {
-        if (k + 1 < K) store_blocks(k + 1);
         const float* dp = delta[(k & 1) ^ 1];
         if (vec) {
-          if (k > 0) consume_fold(k - 1, fs, dp);
-          issue_blocks(min(k + 2, K - 1));
-          issue_fold(k + 1, fs);                                     // (past the last rows: every offset beyond the matrix, zeros)
+          consume_fold(k - 1, fs, dp); issue_fold(k + 1, fs);       // (past the last rows: every offset beyond the matrix, zeros)
         } else {
           if (k > 0 && k + 1 < K) {
             const int t0 = (k + 1) * L;
@@ -1027,7 +1033,6 @@ __global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
               r[t] = s;
             }
           }
-          issue_blocks(min(k + 2, K - 1));
         }
       }
 #ifdef CHAIN_CLOCK
@@ -1038,9 +1043,13 @@ __global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
       { const unsigned long long tt = __builtin_amdgcn_s_memtime(); b_wait += tt - b_t0; b_t0 = tt; }
 #endif
     };
-    for (int k = 0; k < K; k += 2) {
-      bg_row(k, fs1);                                               // row k (even) consumes the fold of row k-1 (odd): set 1
-      if (k + 1 < K) bg_row(k + 1, fs0);
+    {                                                               // (two rows per trip and the odd last row peeled: a branch inside the trip makes the compiler move the sets between registers)
+      int k = 0;
+      for (; k + 1 < K; k += 2) {
+        bg_row(k, fs1);                                             // row k (even) consumes the fold of row k-1 (odd): set 1
+        bg_row(k + 1, fs0);
+      }
+      if (k < K) bg_row(k, fs1);
     }
 #ifdef CHAIN_CLOCK
     if ((tid == 64 || tid == 7 * 64) && a.it == 30u) printf("bg wave %d: work %llu wait %llu\n", wave, b_work, b_wait);
