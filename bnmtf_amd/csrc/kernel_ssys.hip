@@ -810,6 +810,7 @@ __global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
         fs[q][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsAm, f_off[q] + f_row[j] + past, sbase, 0));
     }
   };
+  f32x2 rq0 = {0.f, 0.f}, rq1 = {0.f, 0.f};
   auto consume_fold = [&](int kk, const f32x4 (&fs)[QF][4], const float* dp) {   // r[t] -= sum_l delta_(kk,l) A[(kk,l)][t] for t >= (kk + 2) L
     const int t0 = (kk + 2) * L, items = 2 * (n2 - t0);
 #pragma unroll
@@ -833,10 +834,15 @@ __global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
                    "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf"
                    : "+v"(sv.x), "+v"(sv.y), "+v"(sv.z), "+v"(sv.w));
       if (h == 0 && w < items) {
-        float4* rp = reinterpret_cast<float4*>(&r[t0 + 4 * g]);
-        float4 o = *rp;
-        o.x -= sv.x; o.y -= sv.y; o.z -= sv.z; o.w -= sv.w;
-        *rp = o;
+        // r[t0 + 4 g ..+3] -= sv as ONE asm statement on two register pairs of its own that live across the rows: through C++ the
+        // loaded quad lands in registers of the set being consumed and the compiler waits for the loads it believes pending on them
+        // -- on one of the two sets that was every load in flight
+        const uint32_t ra = (uint32_t)(size_t)(__attribute__((address_space(3))) float*)(&r[t0 + 4 * g]);
+        const f32x2 s01 = {sv.x, sv.y}, s23 = {sv.z, sv.w};
+        asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)\n\t"
+                     "v_pk_add_f32 %0, %0, %3 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %1, %1, %4 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                     "ds_write_b64 %2, %0\n\tds_write_b64 %2, %1 offset:8"
+                     : "+v"(rq0), "+v"(rq1) : "v"(ra), "v"(s01), "v"(s23) : "memory");
       }
     }
   };
@@ -1012,44 +1018,49 @@ __global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
 #ifdef CHAIN_CLOCK
     unsigned long long b_work = 0, b_wait = 0, b_t0 = __builtin_amdgcn_s_memtime();
 #endif
-    auto bg_row = [&](int k, f32x4 (&fs)[QF][4]) {                  // fs: issued two rows ago = the rows of A for row k-1's deltas
-      if (bg) {
-        const float* dp = delta[(k & 1) ^ 1];
-        if (vec) {
-          consume_fold(k - 1, fs, dp); issue_fold(k + 1, fs);       // (past the last rows: every offset beyond the matrix, zeros)
-        } else {
-          if (k > 0 && k + 1 < K) {
-            const int t0 = (k + 1) * L;
-            for (int t = t0 + bt; t < n2; t += NB) {
-              const float* col = a.A + (size_t)((k - 1) * L) * n2 + t;
-              float s = r[t];
-              for (int l0 = 0; l0 < L; l0 += 8) {
-                float av[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) av[j] = l0 + j < L ? col[(size_t)(l0 + j) * n2] : 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) s = fmaf(-dp[(l0 + j) & 31], av[j], s);
-              }
-              r[t] = s;
-            }
-          }
-        }
-      }
+    auto row_end = [&]() {
 #ifdef CHAIN_CLOCK
       { const unsigned long long tt = __builtin_amdgcn_s_memtime(); b_work += tt - b_t0; b_t0 = tt; }
 #endif
+      // LDS traffic only: the loads just issued stay in flight across the barrier
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #ifdef CHAIN_CLOCK
       { const unsigned long long tt = __builtin_amdgcn_s_memtime(); b_wait += tt - b_t0; b_t0 = tt; }
 #endif
     };
-    {                                                               // (two rows per trip and the odd last row peeled: a branch inside the trip makes the compiler move the sets between registers)
+    if (vec) {
+      // two rows per trip, the odd last row peeled (a branch inside the trip makes the compiler move the sets between registers);
+      // nothing else in this loop touches vector memory (a second path through it would set the wait counts to its worst case)
+      auto bg_row = [&](int k, f32x4 (&fs)[QF][4]) {                // fs: issued two rows ago = the rows of A for row k-1's deltas
+        consume_fold(k - 1, fs, delta[(k & 1) ^ 1]); issue_fold(k + 1, fs);   // (past the last rows: every offset beyond the matrix, zeros; every wave here folds: no branch)
+        row_end();
+      };
       int k = 0;
       for (; k + 1 < K; k += 2) {
         bg_row(k, fs1);                                             // row k (even) consumes the fold of row k-1 (odd): set 1
         bg_row(k + 1, fs0);
       }
       if (k < K) bg_row(k, fs1);
+    } else {                                                        // L not a multiple of four: element by element, no prefetch
+      for (int k = 0; k < K; ++k) {
+        if (k > 0 && k + 1 < K) {
+          const float* dp = delta[(k & 1) ^ 1];
+          const int t0 = (k + 1) * L;
+          for (int t = t0 + bt; t < n2; t += NB) {
+            const float* col = a.A + (size_t)((k - 1) * L) * n2 + t;
+            float s = r[t];
+            for (int l0 = 0; l0 < L; l0 += 8) {
+              float av[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) av[j] = l0 + j < L ? col[(size_t)(l0 + j) * n2] : 0.f;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) s = fmaf(-dp[(l0 + j) & 31], av[j], s);
+            }
+            r[t] = s;
+          }
+        }
+        row_end();
+      }
     }
 #ifdef CHAIN_CLOCK
     if ((tid == 64 || tid == 7 * 64) && a.it == 30u) printf("bg wave %d: work %llu wait %llu\n", wave, b_work, b_wait);
