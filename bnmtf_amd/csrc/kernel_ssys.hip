@@ -287,6 +287,7 @@ void launch_ssys_sum_parts(const float* slabs, int nsplit, size_t n, float* A, h
   hipLaunchKernelGGL(ssys_sum_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slabs, nsplit, n, A);
 }
 
+constexpr int kSsysWarmBlocks = 64;   // blocks (on XCD 0) that read the fold's part of A ahead of the chain kernel
 // Ti_k = (I + N_k)^-1 for the chain's rows (ssys_chain_kernel, below): N_k[l][l''] = B[l''][l] / B[l][l] for l'' < l, B the
 // diagonal block k of A.  Unit lower triangular: column j of the inverse by forward substitution in fp64, one lane per column,
 // the row of N a broadcast LDS read; ~500 FMAs of one wave, beside the residual's dot products on other CUs.  A dead entry
@@ -329,6 +330,22 @@ __global__ __launch_bounds__(256) void ssys_residual_kernel(const float* A, floa
                                                             float4* own8, float4* recT, float* Tn) {
 #pragma clang fp contract(off)
   const int rblocks = (n2 + 3) / 4;
+  if ((int)blockIdx.x >= rblocks + K) {
+    // Warm-up for the chain kernel that follows: it is ONE block, which the dispatcher puts on XCD 0 (block i of a grid goes to
+    // XCD i mod 8: tools/micro/xcc.hip), and its fold streams the upper block triangle of A (2 MB) through that one CU -- out
+    // of the Infinity Cache at ~24 B/clk, out of its own XCD's L2 several times faster.  So the blocks of this range that sit on
+    // XCD 0 read that triangle once (the rows dealt round kWarm blocks); the other seven of every eight leave at once.
+    const int ws = (rblocks + K + 7) & ~7, wb = (int)blockIdx.x - ws;
+    if (wb < 0 || (wb & 7) != 0) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int a0 = wb >> 3; a0 < n2; a0 += kSsysWarmBlocks) {
+      const int c0 = (a0 / L + 2) * L;                              // the columns of the rows of S behind the next one
+      const float4* rowp = reinterpret_cast<const float4*>(A + (size_t)a0 * n2);
+      for (int t = c0 / 4 + (int)threadIdx.x; t < n2 / 4; t += 256) { const float4 v = rowp[t]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 1.2345e38f) r[0] = acc.x;   // (never: keeps the loads)
+    return;
+  }
   if ((int)blockIdx.x >= rblocks) { ssys_tinv_body(A, K, L, (int)blockIdx.x - rblocks, *tau, tinv); return; }
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n2) return;
@@ -377,7 +394,7 @@ __global__ __launch_bounds__(256) void ssys_residual_kernel(const float* A, floa
 }
 void launch_ssys_residual(const float* A, float* b, const float* bparts, int nparts, const float* S, int n2, float* r, hipStream_t st, float* cands, uint32_t it, uint32_t key0, uint32_t key1,
                           float* tinv, int K, int L, const float* tau, float* own8, float* recT, float* Tn) {
-  hipLaunchKernelGGL(ssys_residual_kernel, dim3((n2 + 3) / 4 + (tinv ? K : 0)), dim3(256), 0, st, A, b, bparts, nparts, S, n2, r, reinterpret_cast<float4*>(cands), it, key0, key1, tinv, K, L, tau,
+  hipLaunchKernelGGL(ssys_residual_kernel, dim3((tinv && (L & 3) == 0 && n2 >= 256) ? (((n2 + 3) / 4 + K + 7) & ~7) + 8 * kSsysWarmBlocks : (n2 + 3) / 4 + (tinv ? K : 0)), dim3(256), 0, st, A, b, bparts, nparts, S, n2, r, reinterpret_cast<float4*>(cands), it, key0, key1, tinv, K, L, tau,
                      reinterpret_cast<float4*>(own8), reinterpret_cast<float4*>(recT), Tn);
 }
 
@@ -1063,7 +1080,7 @@ __global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
       }
     }
 #ifdef CHAIN_CLOCK
-    if ((tid == 64 || tid == 7 * 64) && a.it == 30u) printf("bg wave %d: work %llu wait %llu\n", wave, b_work, b_wait);
+    if (lane == 0 && a.it == 30u) printf("bg wave %d (simd %u): work %llu wait %llu\n", wave, (__builtin_amdgcn_s_getreg((3 << 11) | (4 << 6) | 4) & 3u), b_work, b_wait);   // HW_REG_HW_ID bits 5:4
 #endif
   }
   for (int e = tid; e < n2; e += NT) a.S[e] = Sl[e];
