@@ -329,13 +329,16 @@ __global__ __launch_bounds__(256) void ssys_residual_kernel(const float* A, floa
                                                             float4* cands, uint32_t it, uint32_t key0, uint32_t key1, float* tinv, int K, int L, const float* tau,
                                                             float4* own8, float4* recT, float* Tn) {
 #pragma clang fp contract(off)
-  const int rblocks = (n2 + 3) / 4;
-  if ((int)blockIdx.x >= rblocks + K) {
+  // the grid: K blocks for Ti (tinv != nullptr; FIRST: one wave of ~750 dependent fp64 instructions each, the longest blocks of
+  // the launch), the rows' blocks, the warm-up blocks
+  const int rblocks = (n2 + 3) / 4, kt = tinv ? K : 0;
+  if ((int)blockIdx.x < kt) { ssys_tinv_body(A, K, L, (int)blockIdx.x, *tau, tinv); return; }
+  if ((int)blockIdx.x >= rblocks + kt) {
     // Warm-up for the chain kernel that follows: it is ONE block, which the dispatcher puts on XCD 0 (block i of a grid goes to
     // XCD i mod 8: tools/micro/xcc.hip), and its fold streams the upper block triangle of A (2 MB) through that one CU -- out
     // of the Infinity Cache at ~24 B/clk, out of its own XCD's L2 several times faster.  So the blocks of this range that sit on
     // XCD 0 read that triangle once (the rows dealt round kWarm blocks); the other seven of every eight leave at once.
-    const int ws = (rblocks + K + 7) & ~7, wb = (int)blockIdx.x - ws;
+    const int ws = (rblocks + kt + 7) & ~7, wb = (int)blockIdx.x - ws;
     if (wb < 0 || (wb & 7) != 0) return;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int a0 = wb >> 3; a0 < n2; a0 += kSsysWarmBlocks) {
@@ -346,13 +349,14 @@ __global__ __launch_bounds__(256) void ssys_residual_kernel(const float* A, floa
     if (acc.x + acc.y + acc.z + acc.w == 1.2345e38f) r[0] = acc.x;   // (never: keeps the loads)
     return;
   }
-  if ((int)blockIdx.x >= rblocks) { ssys_tinv_body(A, K, L, (int)blockIdx.x - rblocks, *tau, tinv); return; }
-  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, row = ((int)blockIdx.x - kt) * 4 + (threadIdx.x >> 6);
   if (row >= n2) return;
   if (cands && lane < 4) {
     const U4 rr = philox4x32_10(0u, (uint32_t)row, it, kStreamS + 16u * (uint32_t)lane, key0, key1);
     const TnCand cd = tn_cand_pre(rr.x, rr.y);
-    cands[row * 4 + lane] = make_float4(cd.nl, cd.z, cd.u2, 0.f);
+#ifdef BNMTF_EXPERIMENTS
+    cands[row * 4 + lane] = make_float4(cd.nl, cd.z, cd.u2, 0.f);       // (what the entry-by-entry chain reads)
+#endif
     if (own8) {                                                     // the chain's records (ssys_chain_kernel): everything of a draw that needs tau_p and the random words only
       const TnPre pre = tn_fast_pre(*tau * A[(size_t)row * n2 + row]);
       const float w2 = -1.38629436f * __builtin_amdgcn_logf(cd.u2);              // -2 ln u2 (v_log_f32 is log2)
@@ -368,10 +372,31 @@ __global__ __launch_bounds__(256) void ssys_residual_kernel(const float* A, floa
   // same products that lies in the row's diagonal block at or before the diagonal; A is symmetric.  The chain adds it to r.)
   const int blk0 = L > 0 ? row / L * L : 0;
   double s = 0.0, so = 0.0;
-  for (int t = lane; t < n2; t += 64) {
-    const double p = (double)A[(size_t)row * n2 + t] * (double)S[t];
-    s += p;
-    if (t >= blk0 && t <= row) so += p;
+  if ((n2 & 3) == 0) {                                              // 16 bytes per lane and load, all of a row's loads in flight at once (n2 <= 1024: four)
+    float4 av[4], sv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t = 4 * lane + 256 * i;
+      av[i] = t < n2 ? *reinterpret_cast<const float4*>(A + (size_t)row * n2 + t) : make_float4(0.f, 0.f, 0.f, 0.f);
+      sv[i] = t < n2 ? *reinterpret_cast<const float4*>(S + t) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t = 4 * lane + 256 * i;
+      const float ae[4] = {av[i].x, av[i].y, av[i].z, av[i].w}, se[4] = {sv[i].x, sv[i].y, sv[i].z, sv[i].w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const double p = (double)ae[c] * (double)se[c];
+        s += p;
+        if (t + c >= blk0 && t + c <= row) so += p;
+      }
+    }
+  } else {
+    for (int t = lane; t < n2; t += 64) {
+      const double p = (double)A[(size_t)row * n2 + t] * (double)S[t];
+      s += p;
+      if (t >= blk0 && t <= row) so += p;
+    }
   }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) { s += __shfl_xor(s, m, 64); so += __shfl_xor(so, m, 64); }
@@ -398,6 +423,7 @@ void launch_ssys_residual(const float* A, float* b, const float* bparts, int npa
                      reinterpret_cast<float4*>(own8), reinterpret_cast<float4*>(recT), Tn);
 }
 
+#ifdef BNMTF_EXPERIMENTS   // the chain as rounds 2-4 walked it, entry by entry: for same-box comparisons (make EXPERIMENTS=1, BNMTF_SCHAIN=seq)
 // The K.L sequential conditionals, row-major (k, l) (bnmtf_gibbs_optimised.py:157-160), one block of 8 waves.
 // Measured with -DCHAIN_CLOCK (tools/variant.sh): a lone wave issues an instruction every ~9 cycles, so the chain's cost is
 // its instruction count: ~195 cycles a step in the normal regime, ~280 more in the translated-exponential one.
@@ -711,6 +737,8 @@ __global__ __launch_bounds__(512) void ssys_chain_seq_kernel(SSysChainArgs a) {
   if (tid == 0 && (a.it == 30u || a.it == 31u)) printf("chain it %u: prologue %llu, row-pro %llu, steps %llu, barrier %llu cycles; slow %d taking %llu\n", a.it, c_begin - c_k0, c_pro, c_steps, c_wait, n_slow, c_slow);
 #endif
 }
+
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Round 5: the chain by ROWS.  The L conditionals of row k are one unit-lower-triangular system: with B the diagonal block of
@@ -1089,12 +1117,14 @@ __global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
 #endif
 }
 void launch_ssys_chain(const SSysChainArgs& a, hipStream_t st) {
+#ifdef BNMTF_EXPERIMENTS
   static const bool seq = getenv("BNMTF_SCHAIN") != nullptr && !strcmp(getenv("BNMTF_SCHAIN"), "seq");
   if (seq) {
     if (a.update == 0) hipLaunchKernelGGL(ssys_chain_seq_kernel<0>, dim3(1), dim3(512), 0, st, a);
     else               hipLaunchKernelGGL(ssys_chain_seq_kernel<1>, dim3(1), dim3(512), 0, st, a);
     return;
   }
+#endif
   if (a.update == 0) hipLaunchKernelGGL(ssys_chain_kernel<0>, dim3(1), dim3(512), 0, st, a);
   else               hipLaunchKernelGGL(ssys_chain_kernel<1>, dim3(1), dim3(512), 0, st, a);
 }
