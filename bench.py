@@ -363,7 +363,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps iterations each; value = median")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps iterations each (at least this many); value = median")
+    ap.add_argument("--min-timed-s", type=float, default=1.0, help="keep adding timed regions until they total this many seconds (at most 400 regions)")
     ap.add_argument("--workload", default="bnmf_8192_k64", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clock", action="store_true", help="skip the rocm-smi reading of shader clock / socket power behind the timed regions")
@@ -449,14 +450,17 @@ def main():
     model.set_profiling(True, kernel=ROOF, every=4)
     perf_first = None
     dts = []
-    for rep in range(max(1, a.repeats)):
+    # (every region is EXACTLY --steps iterations between two barriers; regions are added until they total --min-timed-s, so that
+    # the timed work is seconds, not milliseconds -- the count is the same on every rank: it follows the max-reduced times)
+    while len(dts) < max(1, a.repeats) or (sum(dts) < a.min_timed_s and len(dts) < 400):
         perf = np.zeros((a.steps, 3))
         sync()
         t0 = time.perf_counter()
         run(a.steps, perf, samples=bufs)
         sync()
         dts.append(cp.allreduce_max(time.perf_counter() - t0))
-        trajectory += [float(x) for x in perf[:, 0]]
+        if len(trajectory) < 400:
+            trajectory += [float(x) for x in perf[:, 0]]
         if perf_first is None:
             perf_first = perf
     dt = float(np.median(dts))
@@ -529,6 +533,16 @@ def main():
             roof = {"bound": "hbm", "kernel": ("gemm_rows: P = R~.(G S^T)" if kind == "bnmtf" else "gemm_cols: Pv = R~^T.U") + " (bf16x3 MFMA 32x32x16, fp32-exact products)", "achieved": ach,
                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": traffic}
         roof.update({"algorithmic_per_launch": {"flop": flops, "bytes": bytes_alg}, "avg_launch_us": g["avg_us"], "traffic_source": traffic_note})
+        # what makes a rate comparable between the boxes of a pool (their sustained shader clock differs by +-5 %, and the iteration
+        # follows it): the clock read beside the loop, the iteration in shader cycles, and the times of the other kernels of the
+        # iteration -- inside `roofline`, the object a reader of the bench record keeps
+        sclk = clock["sclk_mhz_median"] if clock else None
+        roof.update({"sclk_mhz": sclk, "power_w": clock["power_w_median"] if clock else None,
+                     "cycles_per_iteration": None if sclk is None else sclk * ms_step * 1e3,
+                     "cycles_per_iteration_device_resident": None if (sclk is None or resident is None) else sclk * 1e6 / resident,
+                     "timed_seconds": float(sum(dts)), "timed_regions": len(dts),
+                     "kernels_us": {nm: round(v["avg_us"], 2) for nm, v in stats.items()},
+                     "iteration_frac_of_bound": max(t_mfma, t_hbm) / (dt / a.steps)})
         # the sweep kernels (K sequential conditional updates per unit) are bound by vector issue + LDS gathers, not by HBM
         # or the matrix cores: algorithmic fp32 work per launch = 8 flop per (missing entry, column) -- the q rebuild
         # (1 FMA), sum q.v, sum v^2 and the q update (3 FMAs) -- against the fp32 vector peak
@@ -551,7 +565,7 @@ def main():
                        "samples": ("handed to the host every iteration (all_U/all_V: %.1f MiB per iteration, page-locked arrays, copy stream)" % (
                                        4.0 * (I * K + J * Wc + (K * Wc if kind == "bnmtf" else 0)) / 2 ** 20)) if with_samples else
                                   ("none (the variational run() stores no samples)" if kind == "vb" else "device-resident (--no-samples)")},
-            "repeats": {"n": len(dts), "values": [a.steps / d for d in dts], "min": a.steps / max(dts), "median": a.steps / dt, "max": a.steps / min(dts)},
+            "repeats": {"n": len(dts), "timed_seconds": float(sum(dts)), "values": [a.steps / d for d in dts[:40]], "min": a.steps / max(dts), "median": a.steps / dt, "max": a.steps / min(dts)},
             "device_resident": None if resident is None else {"value": resident, "unit": "iterations/s", "what": "same loop, samples left on the device"},
             "clock": clock,
             "roofline": roof,

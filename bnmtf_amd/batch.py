@@ -5,12 +5,19 @@
 The reference fits the candidates of a model search -- folds x ranks x restarts -- one after the other
 (code/cross_validation/line_search_cross_validation.py:54-131, line_search_bnmf.py:53-76) or in a process pool
 (parallel_matrix_cross_validation.py:40-74).  Small BNMF Gibbs / ICM models run on the device as ONE block each
-(csrc/kernel_small.hip), so a list of them is one launch; models that do not qualify are run in turn."""
+(csrc/kernel_small.hip), so a list of them is one launch; models that do not qualify are run in turn.  ICM models (nmf_icm:
+their own run(), update rule and minimum_TN) are not taken: ReplicaPool runs them one by one."""
 import ctypes as C
 
 import numpy as np
 
 from . import _lib
+
+
+def takes(model):
+    """Is `model` one that run_many fits as its own run() would?  (The Gibbs class itself -- or a subclass that keeps its run().)"""
+    from .bnmf_gibbs import bnmf_gibbs_optimised
+    return isinstance(model, bnmf_gibbs_optimised) and type(model).run is bnmf_gibbs_optimised.run
 
 
 def run_many(models, iterations, update='draw', store_samples=True, expectation=None):
@@ -19,8 +26,12 @@ def run_many(models, iterations, update='draw', store_samples=True, expectation=
     models = list(models)
     if not models:
         return []
-    if not all(hasattr(m, "_run_prepare") for m in models):
-        raise TypeError("run_many takes bnmf_gibbs_optimised models")
+    if not all(takes(m) for m in models):
+        # (nmf_icm inherits the Gibbs class and overrides run(): its update rule, minimum_TN and Gamma mode are not what the
+        # batched entry point runs -- it would come back fitted by Gibbs draws)
+        raise TypeError("run_many takes models whose run() is bnmf_gibbs_optimised.run (got %s)" % sorted({type(m).__name__ for m in models if not takes(m)}))
+    if int(iterations) == 0:                  # run(0) changes nothing (the C entry point returns before it fills the final states)
+        return [None for _ in models]
     bufs = [m._run_prepare(iterations, store_samples, expectation) for m in models]
     n = len(models)
     states = [(np.zeros((m.I, m.K)), np.zeros((m.J, m.K)), np.zeros(1)) for m in models]      # what every model ends with

@@ -194,12 +194,12 @@ def fit_models(jobs, shared):
     """The same for a list of jobs at once: all models are built first, those that bnmtf_amd.run_many takes (BNMF Gibbs) and
     that ask for the same run (iterations, expectation) go to the device as ONE call -- small models share a launch, one
     block each --, then every model is scored.  Results in job order, each what fit_model(job) returns."""
-    from ..batch import run_many
+    from ..batch import run_many, takes
     models = [_build(j, shared) for j in jobs]
     kws = [_run_kw(j, m) for j, m in zip(jobs, models)]
     groups = {}
     for i, (m, (kw, _)) in enumerate(zip(models, kws)):
-        if hasattr(m, "_run_prepare") and "minimum_TN" not in kw:
+        if takes(m) and "minimum_TN" not in kw:                     # (nmf_icm inherits _run_prepare but not the Gibbs run(): one by one)
             groups.setdefault((kw["iterations"], kw.get("expectation"), kw.get("store_samples", True)), []).append(i)
         else:
             m.run(**kw)

@@ -265,6 +265,7 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
     d.wide_can = wide_can;
     d.use_wide = wide_can && wide_blocks >= 192;
     if (const char* e = getenv("BNMTF_WIDE")) d.use_wide = wide_can && atoi(e) != 0;      // 0: never, 1: whenever it can run
+    if (const char* e = getenv("BNMTF_VB_PATH")) d.vb_path = !strcmp(e, "masked") ? 1 : !strcmp(e, "pairs") ? 2 : 0;
     d.use_turns = false;
 #ifdef BNMTF_EXPERIMENTS
     if (const char* e = getenv("BNMTF_TURNS")) d.use_turns = d.use_wide && sweep_turns_supported(d.KP, d.pw) && atoi(e) != 0;
@@ -534,10 +535,12 @@ static void enqueue_gemm(bnmtf_model* h, Dir& d, const Dir& other, int kid, int 
 // the variational half sweep of direction d (other factor o) runs on the on-chip kernels (api_models.inc: enqueue_vb_sweep)
 // Policy (same-box A/Bs): the product's fixed cost (bits x digit planes, column maxima, planes, slab reads) pays when
 // a column loop is 64 columns of a 16-wave block -- 8192^2, K = 64: +7 % -- and does not at K <= 32 (4096^2: -15 %, 8192^2: -5 %),
-// where the pair-panel kernel (kernel_sweep_vb.hip) stays.  BNMTF_VB_PATH=masked / pairs forces one of them (read per call).
+// where the pair-panel kernel (kernel_sweep_vb.hip) stays.  BNMTF_VB_PATH=masked / pairs forces one of them -- read ONCE, when the
+// model's layout is built: the relayout of one half sweep builds what the next one's kernel reads (the pair panels or not), so a
+// switch flipped between two calls must not change the path of a model that exists (round 4's advice).
 static bool vb_chip_ok(const Dir& d, const Dir& o) {
   if (!(d.mbits && o.XB && d.mslabs && d.nch == 1 && sweep_fast_supported(d.KP, d.pw))) return false;
-  if (const char* e = getenv("BNMTF_VB_PATH")) { if (!strcmp(e, "masked")) return true; if (!strcmp(e, "pairs")) return false; }
+  if (d.vb_path != 0) return d.vb_path == 1;
   return d.KP == 64 && d.use_wide;
 }
 static void enqueue_post(bnmtf_model* h, Dir& d, bool vb = false) {
@@ -1226,7 +1229,7 @@ int bnmtf_kernel_stats(bnmtf_handle h, int kernel, double* total_ms, uint64_t* l
   return BNMTF_OK;
 }
 int bnmtf_describe(bnmtf_handle h, char* buf, size_t buflen) {
-  // (+ which kernels the last variational half sweep ran on: the path is chosen per call, vb_chip_ok)
+  // (+ which kernels the last variational half sweep ran on: vb_chip_ok)
   static const char* const kVbPath[] = {"", " vb_sweep=generic", " vb_sweep=pairs", " vb_sweep=masked"};
   snprintf(buf, buflen, "%s%s", h->description.c_str(), kVbPath[h->last_vb_path & 3]);
   return BNMTF_OK;

@@ -63,6 +63,7 @@ struct Dir {
   int gemm_tw = 4;                       // contraction: 32-column tiles per wave
   bool use_turns = false;                // the wide layout run by kernel_sweep_turns.hip (two unit groups per block taking turns)
   bool use_wide = false;                 // 16-wave sweep kernel (pairs dealt to blocks per wave class) instead of the 8-wave one
+  int vb_path = 0;                       // BNMTF_VB_PATH as it stood when the layout was built: 0 by policy, 1 masked sums, 2 pair panels (latched: the relayout builds what the chosen sweep reads)
   double* C64 = nullptr; float* C32 = nullptr; double* colsum = nullptr;   // Gram of X
   // q hand-over between the half sweeps (round 3, one GPU, 16-wave kernels on both directions): this direction's blocks end a
   // sweep by writing q = X_i . Xo_j of their missing entries, sorted by the OTHER direction's blocks, into that direction's

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 # 8192 x 8192 configuration runs, sweep_vb_kernel<., 16, 0> with the fp32 moments routine on wave 0 -- on any size
 # -- with q handed over between the half sweeps (the default there) and, "1-prepass", rebuilt by every sweep's
 # pre-pass (BNMTF_HANDOVER=0)
-# "...-masked" (BNMTF_VB_PATH=masked, read per call): the sweep on the Gibbs sweep's on-chip kernels (sweep_chip.inc, MODE =
+# "...-masked" (BNMTF_VB_PATH=masked, read when the model is built): the sweep on the Gibbs sweep's on-chip kernels (sweep_chip.inc, MODE =
 # kSweepVB) with the two chain-independent masked sums of every (unit, column) from kernel_maskgemm.hip (bits x int8 digit
 # planes) -- the path the 8192 x 8192, K = 64 configuration takes by itself; the others force the pair-panel kernel
 SHAPES = pytest.mark.parametrize("wide", [None, "1", "1-prepass", "masked", "1-masked", "1-prepass-masked"],

@@ -222,3 +222,18 @@ def test_bench_clock_reading_is_optional():
     spec.loader.exec_module(bench)
     got = bench._clock_beside(lambda: time.sleep(0.01), lambda: None, seconds=0.3)
     assert got is None or (got["sclk_mhz_median"] > 0 and got["readings"] >= 1)
+
+
+def test_run_many_takes_gibbs_models_only():
+    """The batch entry point fits a model as bnmf_gibbs_optimised.run would: a subclass with its own run() (nmf_icm: another
+    update rule, minimum_TN, the Gamma mode) is refused before anything reaches the device, and the replica pool's batching asks
+    the same question (round 4's advice: such jobs came back fitted by Gibbs draws)."""
+    from bnmtf_amd import nmf_icm, run_many
+    from bnmtf_amd.batch import takes
+    rs = np.random.RandomState(0)
+    R = rs.rand(6, 5); M = np.ones((6, 5))
+    pri = dict(alpha=1., beta=1., lambdaU=0.1, lambdaV=0.1)
+    assert takes(bnmf_gibbs_optimised(R, M, 2, pri)) and not takes(nmf_icm(R, M, 2, pri)) and not takes(object())
+    with pytest.raises(TypeError):
+        run_many([nmf_icm(R, M, 2, pri)], 3)
+    assert run_many([], 3) == []

@@ -110,7 +110,7 @@ def test_sharded_vb_run_equals_single_rank_run(monkeypatch, I, J, K, world, path
     """BNMF VB, rows / columns sharded (BASELINE configs[4] "1 vs 8 GPUs"): (E, S2) blocks gathered after each half sweep,
     the SSE-identity sums and the ELBO pieces exchanged as 20 doubles; deterministic, so every rank holds the single-rank
     trajectory (sums are formed in a different order: 1e-9 on the scalars, fp32 noise on the factors).  path: the pair-panel
-    sweep, or the on-chip sweep with the masked sums from kernel_maskgemm.hip (BNMTF_VB_PATH, read per call)."""
+    sweep, or the on-chip sweep with the masked sums from kernel_maskgemm.hip (BNMTF_VB_PATH, read when the model is built)."""
     from bnmtf_amd import bnmf_vb_optimised
     monkeypatch.setenv("BNMTF_VB_PATH", path)
     R, M, _, _ = generate_bnmf(I, J, K, 0.12, seed_data=5, seed_mask=6)

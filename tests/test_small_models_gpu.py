@@ -241,6 +241,31 @@ def test_batched_replica_pool_gives_the_sequential_results():
             assert a["performance"][k] == pytest.approx(b["performance"][k], rel=1e-12)
 
 
+def test_batched_replica_pool_fits_icm_jobs_by_icm():
+    """nmf_icm inherits the Gibbs class: a batched pool used to send its jobs (minimum_TN=None, the search drivers' default) through
+    run_many, i.e. fit them by Gibbs draws (round 4's advice).  They are run one by one now: batched == unbatched, and the batch
+    entry point refuses the class."""
+    from bnmtf_amd import nmf_icm
+    from bnmtf_amd.cross_validation.replicas import ReplicaPool, fit_model
+    R, M, _, _ = generate_bnmf(60, 50, 4, 0.2, seed_data=1, seed_mask=2)
+    jobs = [dict(classifier=nmf_icm, args=(K, PRI), init={"init": "random"}, iterations=12, burn_in=None, thinning=None, minimum_TN=None,
+                 M=M, test=None, metrics=["loglikelihood", "MSE"], seed=100 + K) for K in (2, 3, 4)]
+    seq = ReplicaPool(devices=[0], shared={"R": R}).map(fit_model, jobs)
+    bat = ReplicaPool(devices=[0], shared={"R": R}, batched=True).map(fit_model, jobs)
+    for a, b in zip(seq, bat):
+        for k in a["quality"]:
+            assert a["quality"][k] == pytest.approx(b["quality"][k], rel=1e-12)
+    m = nmf_icm(R, M, 3, PRI)
+    m.initialise('random')
+    with pytest.raises(TypeError):
+        bnmtf_amd.run_many([m], 3)
+    g = bnmf_gibbs_optimised(R, M, 3, PRI, verbose=False, seed=5)
+    g.initialise('random')
+    U0 = g.U.copy()
+    bnmtf_amd.run_many([g], 0)                  # (used to install the batch's zero-filled placeholders as the model's state)
+    assert np.array_equal(g.U, U0)
+
+
 @pytest.mark.parametrize("miss", [0.27, 0.34, 0.45])
 def test_the_slot_classes_above_32_follow_the_oracle(miss):
     """Masks with more missing entries than 1024 threads hold at 32 slots each (a training fold of a 19 %-missing 622 x 138 matrix has
