@@ -178,3 +178,42 @@ def test_sharded_bnmtf_run_equals_single_rank_run(I, J, K, L, world):
         if update == "mode":
             np.testing.assert_allclose(ranks[0][3], single.all_tau, rtol=1e-3)
             assert np.abs(ranks[0][2][-1] - single.all_G[-1]).max() <= 5e-3 * np.abs(single.all_G[-1]).max()
+
+
+def test_eight_ranks_at_the_headline_shard_shapes_draw_the_single_rank_chain():
+    """The multi-GPU code at the REAL shard shapes of the headline configuration (8192 x 8192, K = 64, rows 8 x 1024): eight ranks
+    of one process on ONE GPU (in-process transport) against the single-rank run.  Every kernel launch, shard range, row offset,
+    the contraction's part-1 / part-2 split around the exchange and the exchange stream's dependencies are the code an 8-GPU
+    run executes (exchange_factor, api.hip).  Every rank ends with the same bits; the chain is the single-rank chain -- the first
+    sweep of U element-wise but for flipped accept / reject decisions (the one GPU hands q over between its half sweeps, the
+    shards rebuild it), the first MSE to 1e-5, the trajectory together afterwards.  (Until round 5 a tool:
+    tools/shard_check_8192.py.)"""
+    I = J = 8192; K = 64; world = 8; iters = 4
+    R, M, _, _ = generate_bnmf(I, J, K, 0.1, tau=1.0, seed_data=0, seed_mask=1)
+    rs = np.random.RandomState(3)
+    U0 = rs.exponential(10.0, (I, K)); V0 = rs.exponential(10.0, (J, K)); tau0 = 1.0
+    s = bnmf_gibbs_optimised(R, M, K, PRI, verbose=False, seed=7)
+    s.U, s.V, s.tau = U0.copy(), V0.copy(), tau0
+    s.run(iters)
+    sm = np.array(s.all_performances["MSE"]); sU0 = s.all_U[0].copy()
+    s.close()
+    cid = b"BNMTFLOC8192T".ljust(128, b"\0")
+    out, err = [None] * world, [None] * world
+
+    def work(rank):
+        try:
+            b = bnmf_gibbs_optimised(R, M, K, PRI, verbose=False, seed=7, rank=rank, world=world, comm_id=cid)
+            b.U, b.V, b.tau = U0.copy(), V0.copy(), tau0
+            b.run(iters, store_samples=(rank == 0))
+            out[rank] = (np.array(b.all_performances["MSE"]), b.U.copy(), b.all_U[0].copy() if rank == 0 else None)
+            b.close()
+        except Exception as e:      # noqa: BLE001
+            err[rank] = e
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not any(err), err
+    for r in range(1, world):
+        assert np.array_equal(out[0][1], out[r][1]) and np.array_equal(out[0][0], out[r][0]), r
+    rel = np.abs(out[0][0] / sm - 1)
+    d0 = np.abs(out[0][2] - sU0) / (1e-3 + np.abs(sU0))
+    assert float(np.mean(d0 < 1e-3)) > 0.999 and rel[0] < 1e-5 and rel.max() < 5e-3, (float(np.mean(d0 < 1e-3)), rel)

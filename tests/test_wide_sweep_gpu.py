@@ -291,3 +291,43 @@ def test_inner_extent_of_two_panels_runs_the_two_chunk_kernel(monkeypatch, I, J,
     d0 = np.abs(runs["0"][0][0] - runs["1"][0][0]) / (np.abs(runs["1"][0][0]) + 1e-3)
     assert np.mean(d0 < 1e-3) > 0.995
     np.testing.assert_allclose(runs["0"][2][:2], runs["1"][2][:2], rtol=2e-3)
+
+
+def test_headline_shape_drawn_half_sweeps_against_the_oracles_sampler():
+    """8192 x 8192, K = 64 with DRAWS (the full-size whole-iteration tests run the mode update): one iteration of the kernels the
+    bench times, then for columns 0, 1, 31, 63 of U and of V the conditional parameters of that very column in NumPy fp64 -- the
+    reference's closed forms (bnmf_gibbs_optimised.py:167-177) on the state the column saw: the device's own new values of the
+    columns before it, the old values of the others -- go through the oracle's sampler (oracle/rng.tn_draw: the same Philox
+    counters, the same candidate sequence) and are compared element-wise with what the device drew.  An accept / reject decision
+    within rounding of its boundary may fall on the other side (fp32 device, fp64 oracle), hence "all but a few"."""
+    from oracle import rng as orng
+    I = J = 8192; K = 64; seed = 5
+    R, M, _, _ = generate_bnmf(I, J, K, 0.1, tau=1.0, seed_data=0, seed_mask=1)
+    rs = np.random.RandomState(3)
+    U0 = rs.exponential(10.0, (I, K)); V0 = rs.exponential(10.0, (J, K)); tau = 1.0     # far from the mode: every regime of the sampler occurs
+    b = bnmf_gibbs_optimised(R, M, K, PRI, verbose=False, seed=seed)
+    b.U, b.V, b.tau = U0.copy(), V0.copy(), tau
+    assert "sweep_nw=16" in b.describe()
+    b.run(1)
+    Un, Vn = np.asarray(b.all_U[0], dtype=np.float64), np.asarray(b.all_V[0], dtype=np.float64)
+    b.close()
+    R64 = R.astype(np.float64); M64 = M.astype(np.float64)
+    lam = 0.1
+
+    def check(Xn, X0, Y, Rm, Mm, stream, name):
+        n = X0.shape[0]
+        for k in (0, 1, 31, K - 1):
+            X = np.concatenate([Xn[:, :k], X0[:, k:]], axis=1)          # what column k saw
+            E = Mm * (Rm - X @ Y.T)
+            a = Mm @ (Y[:, k] ** 2)
+            t = tau * a
+            mu = (-lam + tau * (E @ Y[:, k] + X[:, k] * a)) / t
+            ref = orng.tn_draw(mu, t, np.arange(n), k, 0, stream, seed)
+            d = np.abs(Xn[:, k] - ref) / (1e-3 + np.abs(ref))
+            assert np.mean(d < 1e-3) > 0.99, (name, k, float(np.mean(d < 1e-3)))
+            # the regimes that occurred: normal proposal and translated exponential (a = -mu sqrt(tau) >= 0.25)
+            if k == 0 and name == "U":
+                aa = -mu * np.sqrt(t)
+                assert (aa >= 0.25).any() and (aa < 0.25).any()
+    check(Un, U0, V0, R64, M64, orng.STREAM_ROWS, "U")
+    check(Vn, V0, Un, np.ascontiguousarray(R64.T), np.ascontiguousarray(M64.T), orng.STREAM_COLS, "V")
