@@ -304,7 +304,7 @@ def test_headline_shape_drawn_half_sweeps_against_the_oracles_sampler():
     I = J = 8192; K = 64; seed = 5
     R, M, _, _ = generate_bnmf(I, J, K, 0.1, tau=1.0, seed_data=0, seed_mask=1)
     rs = np.random.RandomState(3)
-    U0 = rs.exponential(10.0, (I, K)); V0 = rs.exponential(10.0, (J, K)); tau = 1.0     # far from the mode: every regime of the sampler occurs
+    U0 = rs.exponential(1.0, (I, K)); V0 = rs.exponential(1.0, (J, K)); tau = 1.0       # at the data's scale: both proposals of the sampler occur
     b = bnmf_gibbs_optimised(R, M, K, PRI, verbose=False, seed=seed)
     b.U, b.V, b.tau = U0.copy(), V0.copy(), tau
     assert "sweep_nw=16" in b.describe()
@@ -325,9 +325,9 @@ def test_headline_shape_drawn_half_sweeps_against_the_oracles_sampler():
             ref = orng.tn_draw(mu, t, np.arange(n), k, 0, stream, seed)
             d = np.abs(Xn[:, k] - ref) / (1e-3 + np.abs(ref))
             assert np.mean(d < 1e-3) > 0.99, (name, k, float(np.mean(d < 1e-3)))
-            # the regimes that occurred: normal proposal and translated exponential (a = -mu sqrt(tau) >= 0.25)
-            if k == 0 and name == "U":
-                aa = -mu * np.sqrt(t)
-                assert (aa >= 0.25).any() and (aa < 0.25).any()
+            aa = -mu * np.sqrt(t)                                         # normal proposal: a < 0.25; translated exponential: a >= 0.25
+            seen[0] += int((aa < 0.25).sum()); seen[1] += int((aa >= 0.25).sum())
+    seen = [0, 0]
     check(Un, U0, V0, R64, M64, orng.STREAM_ROWS, "U")
     check(Vn, V0, Un, np.ascontiguousarray(R64.T), np.ascontiguousarray(M64.T), orng.STREAM_COLS, "V")
+    assert min(seen) > 1000, seen                                        # both regimes were exercised
