@@ -35,10 +35,15 @@ class MatrixNestedCrossValidation(object):
 
     def run(self):
         """:78-112.  Outer folds drawn first (the reference's draw order: outer split, then each inner cross-validation's own
-        splits as it runs), every inner search in turn, then the K outer models side by side."""
+        splits as it runs), every inner search in turn, then the K outer models side by side.
+        Deviation from the reference's loop, on purpose: it fits a fold's outer model inside the fold loop (run_model, :104); here
+        the K outer fits wait for all inner searches and run as ONE batch on the replica slots (they are independent once their
+        parameters are chosen) -- so a model that draws from the GLOBAL NumPy stream sees the inner searches' draws first.  A subclass
+        that overrides run_model() is honoured: its fits then run fold by fold through it, after the searches."""
         folds_test = mask.compute_folds_attempts(I=self.I, J=self.J, no_folds=self.K, attempts=attempts_generate_M, M=self.M)
         folds_training = mask.compute_Ms(folds_test)
         chosen = []
+        devices = self.devices
         for i, (train, test) in enumerate(zip(folds_training, folds_test)):
             print("Fold %s of nested cross-validation." % (i + 1))
             crossval = ParallelMatrixCrossValidation(method=self.method, X=self.X, M=train, K=self.K, parameter_search=self.parameter_search,
@@ -52,12 +57,16 @@ class MatrixNestedCrossValidation(object):
                 best_parameters = self.parameter_search[0]
                 print("Found no performances, dataset too sparse? Use first values instead for fold %s, %s." % (i + 1, best_parameters))
             chosen.append(best_parameters)
-            devices = crossval.devices
+            if devices is None:
+                devices = crossval.devices                       # (what the slots resolved to: once, from the first inner run)
         # the outer models: independent of one another once their parameters are known -- one batch
         jobs = [dict(method=self.method, parameters=p, train=train, test=test, train_config=self.train_config)
                 for p, train, test in zip(chosen, folds_training, folds_test)]
-        with ReplicaPool(devices=devices, shared={"X": self.X}) as pool:
-            results = pool.map(fold_job, jobs)
+        if type(self).run_model is not MatrixNestedCrossValidation.run_model:
+            results = [self.run_model(train, test, p) for p, train, test in zip(chosen, folds_training, folds_test)]
+        else:
+            with ReplicaPool(devices=devices, shared={"X": self.X}) as pool:
+                results = pool.map(fold_job, jobs)
         for i, performance_dict in enumerate(results):
             self.store_performances(performance_dict)
             print("Finished fold %s, with performances %s." % (i + 1, performance_dict))
@@ -82,3 +91,4 @@ class MatrixNestedCrossValidation(object):
         self.compute_average_performances()
         self.fout.write("Average performances: %s. \nAll performances: %s. \n" % (self.average_performances, self.all_performances))
         self.fout.flush()
+        self.fout.close()

@@ -41,5 +41,6 @@ def test_f32_mfma_contraction_equals_bf16x3_contraction_and_oracle(monkeypatch, 
         out += [b.U.copy(), b.V.copy(), np.array(b.all_tau)]
         got[mode] = out
         b.close()
-    for x, y in zip(got["bf16x3"], got.get("f32", got["bf16x3"])):
-        assert np.abs(x - y).max() <= 2e-5 * (np.abs(y).max() + 1.0)
+    if "f32" in got:                                # (the shipped build has one form: nothing to compare it with but the oracle, above)
+        for x, y in zip(got["bf16x3"], got["f32"]):
+            assert np.abs(x - y).max() <= 2e-5 * (np.abs(y).max() + 1.0)
