@@ -969,9 +969,12 @@ __global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
 #ifdef CHAIN_CLOCK
       { const unsigned long long tt = __builtin_amdgcn_s_memtime(); c_pro += tt - c_t0; c_t0 = tt; }
 #endif
-      uint32_t todo = lmask;
-      for (;;) {
-        uint32_t bad, nrm = 0u, easy; float dlv, xv;                // lane f's correction and new value, where the lane can make them itself
+      // A branch on a condition that comes out of a vector compare costs ~50 cycles on a lone wave (tools/micro/lone_wave.hip), so
+      // the loop of the usual correction -- a lane in the translated-exponential regime whose first candidate there is accepted --
+      // is tested at its BOTTOM: one such branch per correction.  Everything else (nothing left to correct; a lane that needs its
+      // other candidates) leaves it.
+      uint32_t todo = lmask, bad = 0u, nrm = 0u, easy = 0u; float dlv = 0.f, xv = 0.f; int f = 0; bool hot = false;
+      auto test = [&]() {                                           // lane f's correction and new value, where the lane can make them itself
         if (UPDATE == 0) {
           // every lane: its conditional mean, and -- should it turn out to be the first lane in the translated-exponential
           // regime -- its first candidate there (header): the lane a correction is due for has a final mean
@@ -991,59 +994,66 @@ __global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
           bad = todo & (~(uint32_t)__builtin_amdgcn_ballot_w64(xv == x) | forced);
           easy = ~forced;
         }
-        if (bad == 0u) break;
-#ifdef CHAIN_CLOCK
-        ++n_fix;
-#endif
-        const int f = __builtin_ctz(bad);
+        hot = (bad & (0u - bad) & easy) != 0u;                       // the lowest lane to correct exists and makes its own value
+        f = __builtin_ctz(bad | 0x80000000u);
+      };
+      auto apply = [&](float xnew, float dl) {
         todo &= 0xfffffffeu << f;
-        float xnew, dl;
-        if (__builtin_expect((easy >> f) & 1u, 1)) {
-          dl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dlv), f));
-          xnew = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xv), f));
-        } else {
-#ifdef CHAIN_CLOCK
-          ++n_cold;
-#endif
-          if (UPDATE == 0) {                                        // the other hoisted candidates (the first one in the normal regime), Philox rounds, overflow
-            const float vf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x - o0.x), f));
-            float xc = 0.f; unsigned long long m = 0ull;
-            if (((forced >> f) & 1u) == 0u) {
-              const float4 rec = recT[(k * L + f) * NH + (lane & (NH - 1))];
-              const float aa = vf * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o0.w), f));
-              const bool tail = ((nrm >> f) & 1u) == 0u;
-              if (tail) {
-                const float rc = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(aa, aa, 4.0f)) + aa);
-                xc = rec.z * rc;
-                m = __builtin_amdgcn_ballot_w64(fabsf(rec.y * rc) <= rec.w) & ((1ull << NH) - 1ull);
-              } else {
-                unsigned long long mt;
-                xc = vf + rec.x;
-                asm("v_cmp_class_f32 %0, %1, %2" : "=s"(mt) : "v"(xc), "s"(0x1C0));
-                m = mt & ((1ull << NH) - 1ull);
-              }
-              if (m == 0ull) {                                      // all four rejected: Philox rounds, candidates NH + 64 round + lane
-                const float sg = -4.0f * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o0.z), f));
-                static_assert(kTnA0 == 0.25f, "sigma above is -thr / A0");
-                TnFast tp; tp.mu = vf; tp.irt = sg; tp.a = aa; tp.live = true; tp.tail = tail;
-                tp.d = 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(aa, aa, 4.0f)) + aa); tp.ilam = __builtin_amdgcn_rcpf(aa + tp.d);
-                if (isfinite(aa) && sg < __builtin_inff())
-                  for (uint32_t round = 0; m == 0ull && round < 64u; ++round) {
-                    const U4 rr = philox4x32_10(0u, (uint32_t)(k * L + f), a.it, kStreamS + 16u * ((uint32_t)NH + round * 64u + (uint32_t)lane), a.key0, a.key1);
-                    const bool acc = tn_eval_fast(tp, rr.x, rr.y, &xc);
-                    m = __builtin_amdgcn_ballot_w64(acc && isfinite(xc) && xc >= 0.0f);
-                  }
-              }
-            }
-            if (m == 0ull) { xc = 0.f; m = 1ull; }                  // overflow, or 4100 rejections
-            xnew = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xc), __builtin_ctzll(m)));
-          } else {
-            xnew = fmaxf(0.f, a.min_x);
-          }
-          dl = xnew - __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), f));
-        }
         x = fmaf(trow[f], dl, x);                                   // trow[f] = 0 in the lanes before f: their values stay as they are, bit for bit
         x = lane == f ? xnew : x;                                   // lane f takes its value as it is (the mirror lane f + 32 keeps its own: nothing reads the upper half's x)
+      };
+      test();
+      for (;;) {
+        while (hot) {
+#ifdef CHAIN_CLOCK
+          ++n_fix;
+#endif
+          apply(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xv), f)),
+                __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dlv), f)));
+          test();
+        }
+        if (bad == 0u) break;
+#ifdef CHAIN_CLOCK
+        ++n_fix; ++n_cold;
+#endif
+        float xnew;
+        if (UPDATE == 0) {                                          // the other hoisted candidates (the first one in the normal regime), Philox rounds, overflow
+          const float vf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x - o0.x), f));
+          float xc = 0.f; unsigned long long m = 0ull;
+          if (((forced >> f) & 1u) == 0u) {
+            const float4 rec = recT[(k * L + f) * NH + (lane & (NH - 1))];
+            const float aa = vf * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o0.w), f));
+            const bool tail = ((nrm >> f) & 1u) == 0u;
+            if (tail) {
+              const float rc = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(aa, aa, 4.0f)) + aa);
+              xc = rec.z * rc;
+              m = __builtin_amdgcn_ballot_w64(fabsf(rec.y * rc) <= rec.w) & ((1ull << NH) - 1ull);
+            } else {
+              unsigned long long mt;
+              xc = vf + rec.x;
+              asm("v_cmp_class_f32 %0, %1, %2" : "=s"(mt) : "v"(xc), "s"(0x1C0));
+              m = mt & ((1ull << NH) - 1ull);
+            }
+            if (m == 0ull) {                                        // all four rejected: Philox rounds, candidates NH + 64 round + lane
+              const float sg = -4.0f * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o0.z), f));
+              static_assert(kTnA0 == 0.25f, "sigma above is -thr / A0");
+              TnFast tp; tp.mu = vf; tp.irt = sg; tp.a = aa; tp.live = true; tp.tail = tail;
+              tp.d = 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(aa, aa, 4.0f)) + aa); tp.ilam = __builtin_amdgcn_rcpf(aa + tp.d);
+              if (isfinite(aa) && sg < __builtin_inff())
+                for (uint32_t round = 0; m == 0ull && round < 64u; ++round) {
+                  const U4 rr = philox4x32_10(0u, (uint32_t)(k * L + f), a.it, kStreamS + 16u * ((uint32_t)NH + round * 64u + (uint32_t)lane), a.key0, a.key1);
+                  const bool acc = tn_eval_fast(tp, rr.x, rr.y, &xc);
+                  m = __builtin_amdgcn_ballot_w64(acc && isfinite(xc) && xc >= 0.0f);
+                }
+            }
+          }
+          if (m == 0ull) { xc = 0.f; m = 1ull; }                    // overflow, or 4100 rejections
+          xnew = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xc), __builtin_ctzll(m)));
+        } else {
+          xnew = fmaxf(0.f, a.min_x);
+        }
+        apply(xnew, xnew - __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), f)));
+        test();
       }
 #ifdef CHAIN_CLOCK
       { const unsigned long long tt = __builtin_amdgcn_s_memtime(); c_fix += tt - c_t0; c_t0 = tt; }

@@ -49,6 +49,14 @@ __global__ __launch_bounds__(64) void k(unsigned long long* out, float seed) {
   STAMP(t0); REP(64, "v_mov_b32 %0, %6\n\tv_mov_b32 %1, %6\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %6"); STAMP(t1); out[n++] = t1 - t0;
   // 14: 128 x (v_writelane ; v_fma)
   STAMP(t0); REP(128, "v_writelane_b32 %0, %4, 5\n\tv_fma_f32 %0, %0, %6, %1"); STAMP(t1); out[n++] = t1 - t0;
+  // 15: 64 x (s_set_gpr_idx_on ; v_mov (relative source) ; s_set_gpr_idx_off ; v_fma)
+  STAMP(t0); REP(64, "s_set_gpr_idx_on %5, gpr_idx(SRC0)\n\tv_mov_b32 %1, %2\n\ts_set_gpr_idx_off\n\tv_fma_f32 %0, %0, %6, %1"); STAMP(t1); out[n++] = t1 - t0;
+  // 16: 64 x (v_cmp -> s_and -> s_cmp -> s_cbranch (not taken) ; v_fma)
+  STAMP(t0); REP(64, "v_cmp_lt_f32 vcc, %1, %0\n\ts_and_b32 %4, vcc_lo, 0x10000\n\ts_cmp_lg_u32 %4, 0x12345\n\ts_cbranch_scc0 1f\n\tv_fma_f32 %0, %0, %6, %1\n1:"); STAMP(t1); out[n++] = t1 - t0;
+  // 17: 64 x the row chain's correction step: sub mul fma sqrt add rcp mul cmp s_and s_ff1 readlane x2 fma (13 instructions)
+  STAMP(t0); REP(64, "v_sub_f32 %1, %0, %6\n\tv_mul_f32 %2, %1, %6\n\tv_fma_f32 %3, %2, %2, 4.0\n\tv_sqrt_f32 %3, %3\n\tv_add_f32 %3, %3, %2\n\tv_rcp_f32 %3, %3\n\tv_mul_f32 %2, %3, %6\n\tv_cmp_le_f32 vcc, |%2|, %6\n\ts_and_b32 %4, vcc_lo, 0xffff\n\ts_ff1_i32_b32 %5, %4\n\tv_readlane_b32 %4, %2, %5\n\tv_readlane_b32 %5, %3, %5\n\tv_fma_f32 %0, %0, %4, %0"); STAMP(t1); out[n++] = t1 - t0;
+  // 18: 128 x (v_readlane with a constant lane ; s_nop 0)  19: 128 x v_cndmask with vcc written just before
+  STAMP(t0); REP(128, "v_cmp_eq_u32 vcc, %4, %1\n\tv_cndmask_b32 %0, %0, %2, vcc"); STAMP(t1); out[n++] = t1 - t0;
   out[n++] = (unsigned long long)(a + b + c + d) + s0 + s1;
 }
 int main() {
@@ -58,8 +66,10 @@ int main() {
   const char* names[] = {"empty", "256 dependent v_fma", "256 v_fma in 4 independent chains", "256 dependent v_rcp", "256 v_rcp 4 independent",
                          "128 x (readlane -> fma)", "64 x (cmp -> s_and -> s_ff1 -> readlane(sgpr lane) -> add)", "256 dependent s_add",
                          "128 x (v_fma ; s_add)", "64 dependent ds_read_b32 (+waitcnt, cvt)", "256 dependent v_add dpp row_shr", "128 x (v_cmp ; v_fma)",
-                         "256 dependent v_sqrt", "256 independent v_mov", "128 x (v_writelane ; v_fma)"};
-  const int cnt[] = {1, 256, 256, 256, 256, 256, 320, 256, 256, 64, 256, 256, 256, 256, 256};
-  for (int i = 0; i < 15; ++i) printf("%-64s %7llu cycles  = %.1f per instruction (of %d)\n", names[i], h[i], (double)(h[i] - h[0]) / cnt[i], cnt[i]);
+                         "256 dependent v_sqrt", "256 independent v_mov", "128 x (v_writelane ; v_fma)",
+                         "64 x (s_set_gpr_idx_on ; v_mov rel ; s_set_gpr_idx_off ; v_fma)", "64 x (v_cmp ; s_and ; s_cmp ; s_cbranch not taken ; v_fma)",
+                         "64 x (sub mul fma sqrt add rcp mul cmp s_and s_ff1 readlane readlane fma)", "128 x (v_cmp_eq ; v_cndmask vcc)"};
+  const int cnt[] = {1, 256, 256, 256, 256, 256, 320, 256, 256, 64, 256, 256, 256, 256, 256, 256, 320, 832, 256};
+  for (int i = 0; i < 19; ++i) printf("%-64s %7llu cycles  = %.1f per instruction (of %d)\n", names[i], h[i], (double)(h[i] - h[0]) / cnt[i], cnt[i]);
   return 0;
 }
