@@ -51,3 +51,29 @@ def test_hot_sweep_kernels_keep_their_register_budget():
         n, r = hits[0]
         assert r["VGPRs"] <= max_vgpr, (n, r)
         assert r["VGPRs Spill"] <= max_spill, (n, r)
+
+
+@pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason="no hipcc")
+def test_s_chain_fold_loop_keeps_two_rows_of_loads_in_flight():
+    """ssys_chain_kernel's fold waves load the rows of A for a row's deltas TWO rows ahead of their use, into two register sets
+    of twenty 16-byte loads that take turns (kernel_ssys.hip).  Whether that pipeline exists is decided by the compiler's wait
+    counts: the first use of a set has to wait for "all but the newest 39 ... 20" loads.  Three harmless-looking edits made it
+    wait for (nearly) everything instead -- a second path through the loop, a skipped item, an offset computed differently --
+    and the chain ran 30-70 us slower with every parity test green (round 5).  So: the generated code of the draw kernel must
+    hold both halves of a trip with waits 39 down to 20, and no smaller wait between the first and the last of them."""
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
+           os.path.join(CSRC, "kernel_ssys.hip"), "-o", "-"]
+    out = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    m = re.search(r"^_ZN5bnmtf17ssys_chain_kernelILi0EEEvNS_13SSysChainArgsE:(.*?)s_endpgm", out.stdout, re.S | re.M)
+    assert m, "ssys_chain_kernel<0> not found in the assembly"
+    waits = [int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", m.group(1))]
+    first = [i for i, w in enumerate(waits) if w == 39]
+    assert len(first) >= 2, waits                                   # two halves of a trip (and the peeled last row)
+    for i in first[:2]:                                             # from "all but 39" down to "all but 20" with nothing smaller in between
+        run = []
+        for w in waits[i:]:
+            run.append(w)
+            if w <= 20:
+                break
+        assert run[-1] == 20 and min(run) == 20, run
