@@ -21,23 +21,32 @@
 namespace bnmtf {
 
 // out[r][c] = sum_t X[r][t] * (transposeS ? S[c][t] : S[t][c]);  X [rows][KPin], S [K][L] row major, out [rows][KPout]
+// A block takes kSpRows rows: their X rows go through LDS (one coalesced pass), S sits there as M[t][c] (the inner index
+// first: a lane's column c is its bank), thread (row, c) sums its `inner` products from LDS -- round 5: the version that read
+// X[r][t] from global memory inside the loop was 7 us of load latency for 4 M products.
+constexpr int kSpRows = 8;
 __global__ __launch_bounds__(256) void small_product_kernel(SmallProductArgs a) {
-  __shared__ float Ss[64 * 64];
-  for (int t = threadIdx.x; t < a.K * a.L; t += 256) Ss[t] = a.S[t];
+  __shared__ float Ms[64 * 65], Xs[kSpRows][64];
+  const int inner = a.transposeS ? a.L : a.K, outw = a.transposeS ? a.K : a.L, tid = threadIdx.x;
+  for (int t = tid; t < a.K * a.L; t += 256) {
+    const int k = t / a.L, l = t % a.L;
+    if (a.transposeS) Ms[l * 65 + k] = a.S[t]; else Ms[k * 65 + l] = a.S[t];      // M[inner][out]
+  }
+  const int r0 = blockIdx.x * kSpRows;
+  for (int t = tid; t < kSpRows * a.KPin; t += 256) {
+    const int r = t / a.KPin, c = t % a.KPin;
+    Xs[r][c] = r0 + r < a.rows ? a.X[(size_t)(r0 + r) * a.KPin + c] : 0.f;
+  }
   __syncthreads();
-  const int inner = a.transposeS ? a.L : a.K, outw = a.transposeS ? a.K : a.L;
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < (size_t)a.rows * outw; e += (size_t)gridDim.x * 256) {
-    const int r = (int)(e / outw), c = (int)(e % outw);
-    const float* x = a.X + (size_t)r * a.KPin;
+  for (int e = tid; e < kSpRows * outw; e += 256) {
+    const int r = e / outw, c = e % outw;
     float s = 0.f;
-    for (int t = 0; t < inner; ++t) s = fmaf(x[t], a.transposeS ? Ss[c * a.L + t] : Ss[t * a.L + c], s);
-    a.out[(size_t)r * a.KPout + c] = s;
+    for (int t = 0; t < inner; ++t) s = fmaf(Xs[r][t], Ms[t * 65 + c], s);
+    if (r0 + r < a.rows) a.out[(size_t)(r0 + r) * a.KPout + c] = s;
   }
 }
 void launch_small_product(const SmallProductArgs& a, hipStream_t st) {
-  const int outw = a.transposeS ? a.K : a.L;
-  const int blocks = (int)std::min<size_t>(2048, ((size_t)a.rows * outw + 255) / 256);
-  hipLaunchKernelGGL(small_product_kernel, dim3(blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(small_product_kernel, dim3((a.rows + kSpRows - 1) / kSpRows), dim3(256), 0, st, a);
 }
 
 // out[j][c] = sum_t (sum_s slabs[s][j][t]) S[t][c]: the G sweep's contraction R~^T (F S) as (R~^T F) S -- R~^T F is there

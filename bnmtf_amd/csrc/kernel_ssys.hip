@@ -40,10 +40,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ void gamma_pack_body(const GammaPackArgs& a, int block);
 // (blocks behind the column Grams' pack the second moments of G's rows -- gamma_pack_body, below: the two do not depend on each
 // other, and one launch less is ~5 us of the S step)
+__device__ __forceinline__ void ssys_b_body(const SSysBArgs& a, int block);
 template <int VB>
-__global__ __launch_bounds__(256) void scol_gram_kernel(SColGramArgs a, GammaPackArgs gp) {
+__global__ __launch_bounds__(256) void scol_gram_kernel(SColGramArgs a, GammaPackArgs gp, SSysBArgs sb) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  const int gram_blocks = (a.n + 3) / 4;
+  const int gram_blocks = (a.n + 3) / 4, pack_blocks = (gp.n + 7) / 8;
+  // (... and behind those, the blocks of b = sum_j Pv_j (x) G_j: a third independent piece of the S system's build in this launch)
+  if ((int)blockIdx.x >= gram_blocks + pack_blocks) { ssys_b_body(sb, (int)blockIdx.x - gram_blocks - pack_blocks); return; }
   if ((int)blockIdx.x >= gram_blocks) { gamma_pack_body(gp, (int)blockIdx.x - gram_blocks); return; }
   const int lane = threadIdx.x & 63, half = lane >> 5, c = lane & 31;
   const int u = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -105,12 +108,13 @@ __global__ __launch_bounds__(256) void scol_gram_kernel(SColGramArgs a, GammaPac
     if (row <= c && c < a.K) w[tri_pos(tri_index(row, c, a.K))] = cf - m;    // the upper triangle, packed: what the S-system GEMM reads
   }
 }
-// gp: the packing of G's second moments rides along (gp.n == 0: none)
-void launch_scol_gram(const SColGramArgs& a, const GammaPackArgs& gp, hipStream_t st) {
+// gp: the packing of G's second moments rides along (gp.n == 0: none); sb (may be null): and the blocks of b
+void launch_scol_gram(const SColGramArgs& a, const GammaPackArgs& gp, hipStream_t st, const SSysBArgs* sb) {
   if (a.n <= 0) return;
-  const int blocks = (a.n + 3) / 4 + (gp.n + 7) / 8;
-  if (a.varF) hipLaunchKernelGGL(scol_gram_kernel<1>, dim3(blocks), dim3(256), 0, st, a, gp);
-  else        hipLaunchKernelGGL(scol_gram_kernel<0>, dim3(blocks), dim3(256), 0, st, a, gp);
+  SSysBArgs b0 = {};
+  const int blocks = (a.n + 3) / 4 + (gp.n + 7) / 8 + (sb ? ssys_b_blocks(sb->n) : 0);
+  if (a.varF) hipLaunchKernelGGL(scol_gram_kernel<1>, dim3(blocks), dim3(256), 0, st, a, gp, sb ? *sb : b0);
+  else        hipLaunchKernelGGL(scol_gram_kernel<0>, dim3(blocks), dim3(256), 0, st, a, gp, sb ? *sb : b0);
 }
 
 // Gc[j][r(l, l')] = G_jl G_jl' (l <= l'), the packed second-moment matrix of column j's row of G.  Block = 8 columns (512 blocks at 4096 columns: two per CU hide each other's load -> store latency).
@@ -240,10 +244,11 @@ void launch_ssys_reduce(const float* slabs, int nsplit, int K, int L, float* A, 
 // b[k][l] = sum_j Pv_jk G_jl over the local columns (Pv = the contraction's partial slabs, summed in slab order).
 // Block = 64 columns: Pv and G tiles through LDS, thread (k, l) sums its 64 products; the per-block partials are summed
 // in block order by ssys_reduce_kernel.
-__global__ __launch_bounds__(1024) void ssys_b_kernel(SSysBArgs a) {
+// (a body for blocks of 256 threads -- it rides in scol_gram_kernel's launch --: thread t takes the entries k = t / 32 + 8 i, l = t % 32)
+__device__ __forceinline__ void ssys_b_body(const SSysBArgs& a, int block) {
   __shared__ float pv[64][33], g[64][33];
-  const int j0 = blockIdx.x * 64;
-  for (int e = threadIdx.x; e < 64 * 32; e += 1024) {
+  const int j0 = block * 64;
+  for (int e = threadIdx.x; e < 64 * 32; e += 256) {
     const int jj = e >> 5, cc = e & 31, j = j0 + jj;
     float p = 0.f, gg = 0.f;
     if (j < a.n) {
@@ -259,14 +264,21 @@ __global__ __launch_bounds__(1024) void ssys_b_kernel(SSysBArgs a) {
     pv[jj][cc] = p; g[jj][cc] = gg;
   }
   __syncthreads();
-  const int k = threadIdx.x >> 5, l = threadIdx.x & 31;
-  float s = 0.f;
-#pragma unroll 16
-  for (int jj = 0; jj < 64; ++jj) s = fmaf(pv[jj][k], g[jj][l], s);
-  if (k < a.K && l < a.L) a.b[(size_t)blockIdx.x * a.K * a.L + k * a.L + l] = s;
+  const int k0 = threadIdx.x >> 5, l = threadIdx.x & 31;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+  for (int jj = 0; jj < 64; ++jj) {
+    const float gv = g[jj][l];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[i] = fmaf(pv[jj][k0 + 8 * i], gv, s[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (k0 + 8 * i < a.K && l < a.L) a.b[(size_t)block * a.K * a.L + (k0 + 8 * i) * a.L + l] = s[i];
 }
+__global__ __launch_bounds__(256) void ssys_b_kernel(SSysBArgs a) { ssys_b_body(a, (int)blockIdx.x); }
 void launch_ssys_b(const SSysBArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(ssys_b_kernel, dim3(ssys_b_blocks(a.n)), dim3(1024), 0, st, a);
+  hipLaunchKernelGGL(ssys_b_kernel, dim3(ssys_b_blocks(a.n)), dim3(256), 0, st, a);
 }
 
 // out = sum of the per-block partial vectors, in block order

@@ -313,7 +313,9 @@ struct SColGramArgs {       // W~_j = C~f - sum_{i in miss(j)} (F_i F_i^T + diag
   float* Wc;                           // [n + 2][tri_padded(K)]: the packed upper triangle of W~_j (pads and the two extra rows stay zero)
 };
 struct GammaPackArgs;
-void launch_scol_gram(const SColGramArgs& a, const GammaPackArgs& pack_too, hipStream_t st);   // pack_too.n > 0: the packing of G's second moments in the same launch
+struct SSysBArgs;
+// pack_too.n > 0: the packing of G's second moments in the same launch; b_too != nullptr: and the blocks of b = sum_j Pv_j (x) G_j
+void launch_scol_gram(const SColGramArgs& a, const GammaPackArgs& pack_too, hipStream_t st, const SSysBArgs* b_too = nullptr);
 struct GammaPackArgs {      // Gc[j][r(l, l')] = G_jl G_jl' (+ varG_jl when l = l': the second moment, VB) for the local columns
   int n, n0, L;
   const float* G; const float* varG;   // [J][32] (global rows n0 + j); varG null for Gibbs
