@@ -311,7 +311,7 @@ __global__ __launch_bounds__(1024) void srow_draw_kernel(SDrawArgs a) {
       for (int c = 0; c < NH; ++c) {
         const U4 r = philox4x32_10(0u, (uint32_t)(k * L + lane), a.it, kStreamS + 16u * (uint32_t)c, a.key0, a.key1);
         const TnCand cd = tn_cand_pre(r.x, r.y);
-        cands[(lane * NH + c) * 3 + 0] = cd.nl; cands[(lane * NH + c) * 3 + 1] = cd.z; cands[(lane * NH + c) * 3 + 2] = cd.u2;
+        cands[(lane * NH + c) * 3 + 0] = cd.nl; cands[(lane * NH + c) * 3 + 1] = cd.z; cands[(lane * NH + c) * 3 + 2] = cd.sw;
       }
     }
     __builtin_amdgcn_s_waitcnt(0);
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(1024) void srow_draw_kernel(SDrawArgs a) {
     for (int l = lbeg; l < lend; ++l) {
       const float row = on ? Om[l * 65 + lane] : 0.f;                  // Omega[l][lane]: off the chain
       TnCand cd0 = {0.f, 0.f, 0.f};                                     // hoisted candidate `lane` of entry l: off the chain too
-      if (lane < NH) { cd0.nl = cands[(l * NH + lane) * 3 + 0]; cd0.z = cands[(l * NH + lane) * 3 + 1]; cd0.u2 = cands[(l * NH + lane) * 3 + 2]; }
+      if (lane < NH) { cd0.nl = cands[(l * NH + lane) * 3 + 0]; cd0.z = cands[(l * NH + lane) * 3 + 1]; cd0.sw = cands[(l * NH + lane) * 3 + 2]; }
       const float numer_v = fmaf(tau, my_eta + my_s * my_oll - corr, -my_lam);
       const float numer = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, numer_v), l));
       const float oll = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_oll), l));

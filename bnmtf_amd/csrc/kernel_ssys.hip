@@ -367,12 +367,11 @@ __global__ __launch_bounds__(256) void ssys_residual_kernel(const float* A, floa
     const U4 rr = philox4x32_10(0u, (uint32_t)row, it, kStreamS + 16u * (uint32_t)lane, key0, key1);
     const TnCand cd = tn_cand_pre(rr.x, rr.y);
 #ifdef BNMTF_EXPERIMENTS
-    cands[row * 4 + lane] = make_float4(cd.nl, cd.z, cd.u2, 0.f);       // (what the entry-by-entry chain reads)
+    cands[row * 4 + lane] = make_float4(cd.nl, cd.z, u23(rr.y), 0.f);   // (what the entry-by-entry chain reads)
 #endif
     if (own8) {                                                     // the chain's records (ssys_chain_kernel): everything of a draw that needs tau_p and the random words only
       const TnPre pre = tn_fast_pre(*tau * A[(size_t)row * n2 + row]);
-      const float w2 = -1.38629436f * __builtin_amdgcn_logf(cd.u2);              // -2 ln u2 (v_log_f32 is log2)
-      const float4 rc4 = make_float4(cd.z * pre.irt, 2.0f * cd.nl - 2.0f, 2.0f * cd.nl * pre.irt, __builtin_amdgcn_sqrtf(w2));
+      const float4 rc4 = make_float4(cd.z * pre.irt, 2.0f * cd.nl - 2.0f, 2.0f * cd.nl * pre.irt, cd.sw);
       recT[row * 4 + lane] = rc4;
       if (lane == 0) {
         own8[2 * row] = pre.live ? make_float4(rc4.x, pre.rcp, -kTnA0 * pre.irt, -pre.tpirt) : make_float4(0.f, 0.f, -__builtin_inff(), 0.f);

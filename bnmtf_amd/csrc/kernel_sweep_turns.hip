@@ -251,7 +251,7 @@ __device__ __forceinline__ void sweep_turns_body(const SweepArgs& a, const FastA
       asm volatile("" : "+v"(row));                            // opaque: no partial rounds of this call are kept across columns
       const U4 r = philox4x32_10(row, (uint32_t)col, a.it, a.stream + 16u * (uint32_t)s_cand, a.key0, a.key1);
       const TnCand cd = tn_cand_pre(r.x, r.y);
-      e = f32x4{cd.nl, cd.z, cd.u2, 0.f};
+      e = f32x4{cd.nl, cd.z, cd.sw, 0.f};
     }
     *(lds_f4*)(uintptr_t)(tab_b + 16u * (uint32_t)(G * 64 + lane)) = e;
   };

@@ -86,20 +86,23 @@ __device__ __forceinline__ TnFast tn_fast_post(const TnPre& q, float numer) {
   p.a = -p.mu * q.tpirt;                         // -mu * sqrt(tau)
   p.live = q.live && isfinite(p.a);
   p.d = 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(p.a, p.a, 4.0f)) + p.a);
-  p.ilam = __builtin_amdgcn_rcpf(p.a + p.d);
+  p.ilam = p.d;                                  // Robert's rate lam = a + d satisfies lam d = 1: no second reciprocal on the samplers' chains (round 5)
   p.tail = p.a >= kTnA0;
   return p;
 }
 __device__ __forceinline__ TnFast tn_fast_params(float numer, float tau_p) { return tn_fast_post(tn_fast_pre(tau_p), numer); }
 // One candidate, in two parts: what depends on the random words only (can be issued ahead of the sequential chain) ...
-struct TnCand { float nl, z, u2; };
+// (sw = sqrt(-2 ln u2): the translated-exponential candidate e = nl / lam is accepted iff u2 <= exp(-(e - d)^2 / 2), i.e. iff
+// |e - d| <= sw -- the same event stated without an exponential on the chain that waits for it; the logarithm and the root depend on
+// the random word only and are made with the candidate's other word-only parts, ahead of the chain: round 5)
+struct TnCand { float nl, z, sw; };
 __device__ __forceinline__ TnCand tn_cand_pre(uint32_t r0, uint32_t r1) {
 #pragma clang fp contract(off)
   TnCand c;
-  const float u1 = u23(r0);
-  c.u2 = u23(r1);
+  const float u1 = u23(r0), u2 = u23(r1);
   c.nl = -0.69314718f * __builtin_amdgcn_logf(u1);                       // v_log_f32 is log2
-  c.z = __builtin_amdgcn_sqrtf(2.0f * c.nl) * __builtin_amdgcn_cosf(c.u2);   // v_cos_f32 takes revolutions
+  c.z = __builtin_amdgcn_sqrtf(2.0f * c.nl) * __builtin_amdgcn_cosf(u2);     // v_cos_f32 takes revolutions
+  c.sw = __builtin_amdgcn_sqrtf(-1.38629436f * __builtin_amdgcn_logf(u2));
   return c;
 }
 // ... and the acceptance test + value given the conditional's parameters
@@ -107,7 +110,7 @@ __device__ __forceinline__ bool tn_cand_post(const TnFast& p, const TnCand& c, f
 #pragma clang fp contract(off)
   const float e = c.nl * p.ilam;
   const float t = e - p.d;
-  const bool acc_t = c.u2 <= __builtin_amdgcn_exp2f(-0.72134752f * t * t);   // exp(-t^2/2) via v_exp_f32 (2^x)
+  const bool acc_t = fabsf(t) <= c.sw;           // u2 <= exp(-t^2 / 2)
   const bool acc_n = c.z >= p.a;
   *x = p.tail ? e * p.irt : fmaf(c.z, p.irt, p.mu);
   return p.tail ? acc_t : acc_n;
