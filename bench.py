@@ -53,6 +53,10 @@ WORKLOADS = {
                                 source="plots/time_toy/nmtf_gibbs_times.txt (2000 it in 44.37 s; experiments_toy/time/nmtf_gibbs_time.py:25-53)"),
     "cv_gdsc": dict(kind="cv", small=True, I=622, J=138, K=25, missing=0.19, values_K=[15, 20, 25, 30], folds=10, iterations=1000, burn_in=900, thinning=2,
                     source="experiments_gdsc/cross_validation/gibbs_nmf/linesearch_xval_gibbs.py:17-62 (10 folds x K in {15,20,25,30} x 1000 it, AIC, then 10 final models)"),
+    "cv_gdsc_bnmtf": dict(kind="cv3", small=True, I=622, J=138, K=8, L=8, missing=0.19, values_K=[5, 6, 7, 8, 9, 10], values_L=[5, 6, 7, 8, 9, 10], folds=10,
+                          iterations=1000, burn_in=900, thinning=2, published={"MSE": 2.402, "R^2": 0.795},
+                          source="experiments_gdsc/cross_validation/gibbs_nmtf/greedysearch_xval_gibbs.py:17-60 (10 folds, greedy search over K, L in 5..10 by AIC, "
+                                 "init S random / F, G k-means, 1000 it, burn-in 900, thinning 2; the file's own results on the real GDSC data: MSE 2.402, R^2 0.795)"),
 }
 PRI2 = dict(alpha=1.0, beta=1.0, lambdaU=0.1, lambdaV=0.1)
 PRI3 = dict(alpha=1.0, beta=1.0, lambdaF=0.1, lambdaS=0.1, lambdaG=0.1)
@@ -205,7 +209,7 @@ def build_model(w, R, M, rank, world, local_rank, comm_id):
 
 def _small_problem(w, seed=0):
     from bnmtf_amd.synthetic import generate_bnmf, generate_bnmtf
-    if w["kind"] == "bnmtf":
+    if w["kind"] in ("bnmtf", "cv3"):
         R, M, _, _, _ = generate_bnmtf(w["I"], w["J"], w["K"], w["L"], w["missing"], seed_data=seed, seed_mask=seed + 1)
     else:
         R, M, _, _ = generate_bnmf(w["I"], w["J"], w["K"], w["missing"], tau=1.0, seed_data=seed, seed_mask=seed + 1)
@@ -350,6 +354,49 @@ def main_cv(a, w):
     print(json.dumps(out)); sys.stdout.flush()
 
 
+def main_cv3(a, w):
+    """The reference's model-selection job for the tri-factorisation (greedysearch_xval_gibbs.py): per fold a greedy walk over
+    (K, L) by AIC -- every step fits the one to three neighbouring models --, then the folds' final models, through
+    GreedySearchCrossValidation on one GPU with s replica slots.  The tri-factorisation has no one-launch kernel: every model
+    runs on the multi-launch path (>= 15 launches per iteration); the slots overlap the models of a step and the final fits."""
+    import tempfile
+    import bnmtf_amd
+    from bnmtf_amd.cross_validation.greedy_search_cross_validation import GreedySearchCrossValidation
+    from bnmtf_amd.cross_validation.replicas import ReplicaPool
+    import random
+    R, M = _small_problem(w)
+    its = a.steps if a.steps_given else w["iterations"]
+    burn, thin = (w["burn_in"], w["thinning"]) if its == w["iterations"] else (its // 2, 2)
+    res = {}
+    for s in a.slots:
+        random.seed(0); np.random.seed(0)
+        pool = ReplicaPool(devices=[0] * s, shared={"R": np.asarray(R, dtype=float)})
+        fits = [0]
+        pmap = pool.map
+
+        def counted(fn, jobs, *aa, **kk):
+            jobs = list(jobs); fits[0] += len(jobs)
+            return pmap(fn, jobs, *aa, **kk)
+        pool.map = counted
+        with tempfile.NamedTemporaryFile("w", suffix=".txt") as f:
+            cv = GreedySearchCrossValidation(classifier=bnmtf_amd.bnmtf_gibbs_optimised, R=R, M=M, values_K=w["values_K"], values_L=w["values_L"], folds=w["folds"],
+                                             priors=PRI3, init_S="random", init_FG="kmeans", iterations=its, restarts=1, quality_metric="AIC",
+                                             file_performance=f.name, pool=pool, seed=1)
+            pmap(_warm, [{} for _ in range(s)])
+            t0 = time.perf_counter(); cv.run(burn_in=burn, thinning=thin); dt = time.perf_counter() - t0
+        pool.close()
+        res[str(s)] = {"slots": s, "seconds": dt, "models": fits[0], "model_iterations_per_s": fits[0] * its / dt,
+                       "heldout_MSE": cv.average_performance["MSE"], "heldout_R2": cv.average_performance["R^2"]}
+    best = max(res.values(), key=lambda r: r["model_iterations_per_s"])
+    out = {"metric": "model-iterations/sec of the GDSC-shaped 10-fold greedy-search cross-validation (BNMTF Gibbs 622x138, K, L in 5..10, %d iterations)" % its,
+           "value": best["model_iterations_per_s"], "unit": "model-iterations/s", "n_gpus": 1, "steps": its, "warmup": 0, "ms_per_step": 1e3 * best["seconds"] / its,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (GDSC's shape and observed fraction, planted K = L = %d)" % w["K"],
+           "config": {"workload": "GreedySearchCrossValidation, %d folds x greedy walk over K in %s, L in %s x %d iterations (burn-in %d, thinning %d, k-means initialisation of F and G) + %d final models; ReplicaPool slots on one GPU: %s" % (
+               w["folds"], w["values_K"], w["values_L"], its, burn, thin, w["folds"], a.slots), "source": w["source"]},
+           "published_on_the_real_data": w["published"], "by_slots": res, "roofline": None, "cpu_baseline": None}
+    print(json.dumps(out)); sys.stdout.flush()
+
+
 def _warm(job, shared):
     import bnmtf_amd
     R, M = _small_problem(dict(kind="bnmf", I=40, J=30, K=3, missing=0.1))
@@ -377,7 +424,7 @@ def main():
     if a.steps is None:
         a.steps = 100
     if WORKLOADS[a.workload].get("small"):
-        return (main_cv if WORKLOADS[a.workload]["kind"] == "cv" else main_small)(a, WORKLOADS[a.workload])
+        return {"cv": main_cv, "cv3": main_cv3}.get(WORKLOADS[a.workload]["kind"], main_small)(a, WORKLOADS[a.workload])
 
     from bnmtf_amd import comm
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:

@@ -146,12 +146,16 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
   // a wave covers 128 output columns (four 32-column tiles); when the output side is short (a shard of a multi-GPU run)
   // 64 columns, so that the chip is filled with half as many inner slices, each twice as long (BNMTF_GEMM_TW=2/4 forces)
   d.gemm_tw = (d.KP == 64 && d.n_pad <= 2048) ? 2 : 4;
+#ifdef BNMTF_EXPERIMENTS       // (A/B switches of decisions that are made: make EXPERIMENTS=1)
   if (const char* e = getenv("BNMTF_GEMM_TW")) d.gemm_tw = atoi(e) == 2 && d.KP == 64 ? 2 : 4;
+#endif
   const int tiles = d.n_pad / (32 * d.gemm_tw);
   // one block per CU: at KP = 64 the GEMM holds 332 registers per lane (one resident block), and at KP = 32 -- where two
   // would fit -- 256 blocks with twice the inner slice per wave beat 512 (4096^2, K = 32: 20.3 us against 23.2; round 3)
   int split = std::max(1, 256 / tiles);
+#ifdef BNMTF_EXPERIMENTS
   if (const char* e = getenv("BNMTF_GEMM_SPLIT")) split = std::max(1, atoi(e));
+#endif
   const int max_split = std::max(1, m / (4 * 64));
   d.split = std::min(split, max_split);
   d.ipw = round_up((m + d.split * 4 - 1) / (d.split * 4), 32);   // multiple of the GEMM's 2*U register-pipeline group
@@ -195,7 +199,11 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
   if (!sweep_fast_supported(d.KP, d.pw) && !getenv("BNMTF_NO_CHUNKS") && sweep_two_chunks_plan(d.KP, m, &d.mh, &d.pw_chunk, &d.pw1)) d.nch = 2;
   const int nch = d.nch;
   {
+#ifdef BNMTF_EXPERIMENTS
     const bool balance = !(getenv("BNMTF_BALANCE") && atoi(getenv("BNMTF_BALANCE")) == 0);
+#else
+    constexpr bool balance = true;
+#endif
     const uint32_t kNone = 0xFFFFFFFFu;
     std::vector<int> Eu(d.n, 0);
     std::vector<std::vector<uint32_t>> lanes((size_t)d.n * 32 * nch);     // per unit, per chunk, per lane: slot contents (kNone = empty), chunk-local inner indices
@@ -1330,7 +1338,11 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
       SweepArgs s = sweep_args(h, r, c, mode, kStreamRows);
       enqueue_sweep(h, r, c, s, false);
     }
+#ifdef BNMTF_EXPERIMENTS
     static const bool snap_compact = getenv("BNMTF_SNAP_COMPACT") != nullptr;      // A/B switch: the packing kernel of round 2
+#else
+    constexpr bool snap_compact = false;
+#endif
     if (!snap_compact) r.snap_dst = sink.slot_for(it, r.X);         // the sample of U goes out with the relayout (no packing kernel of its own)
     CHK(exchange_factor(h, r, &c, BNMTF_KERNEL_GEMM_COLS));        // one GPU: relayout + Gram; several: see exchange_factor
     if (snap_compact) sink.snapshot(it, r.X);

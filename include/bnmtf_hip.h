@@ -15,8 +15,10 @@
  *   - host pointers are caller-owned, C-contiguous (row-major) and only touched
  *     during the call; every call is synchronous at return.
  *   - factor matrices cross the boundary as double (what the reference's
- *     attributes hold); the device computes the O(I*J*K) contractions in fp32
- *     (f32 MFMA) and every reduction that feeds tau / metrics in fp64.
+ *     attributes hold); the device computes the O(I*J*K) contractions with
+ *     fp32-exact products on the bf16 matrix cores (every fp32 operand split
+ *     into three bf16 terms, six products per fp32 product, fp32 accumulation)
+ *     and every reduction that feeds tau / metrics in fp64.
  *   - one host thread per handle; a handle owns its device buffers and stream.
  *   - multi-GPU = one process (and one handle) per GPU, rows of R split over
  *     `world` ranks for the U/F sweep, columns for the V/G sweep, freshly drawn
