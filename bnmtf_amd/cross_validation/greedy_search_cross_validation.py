@@ -44,16 +44,26 @@ class GreedySearchCrossValidation(object):
         pool = self.pool or ReplicaPool(devices=[0], shared={"R": self.R})
         pool.shared.setdefault("R", self.R)
         try:
-            best_KL, fold_lines = [], []
-            for fi in range(self.folds):
+            def fold_search(fi):
                 search = GreedySearch(classifier=self.classifier, values_K=self.values_K, values_L=self.values_L, R=self.R, M=self.M,
                                       priors=self.priors, initS=self.init_S, initFG=self.init_FG, iterations=self.iterations, restarts=self.restarts,
                                       pool=pool, seed=None if self.seed is None else self.seed + 104729 * fi)
                 search.search(self.quality_metric, burn_in=burn_in, thinning=thinning, minimum_TN=minimum_TN)
-                best_KL.append(search.best_value(metric=self.quality_metric))
+                best = search.best_value(metric=self.quality_metric)
                 # (written below, fold by fold, each followed by its Performance line: the reference's order, greedy_search_cross_validation.py:68-100)
-                fold_lines.append("All model fits for fold %s, metric %s: %s.\n" % (fi + 1, self.quality_metric, search.all_values(metric=self.quality_metric))
-                                  + "Best K,L for fold %s: %s.\n" % (fi + 1, best_KL[-1]))
+                return best, ("All model fits for fold %s, metric %s: %s.\n" % (fi + 1, self.quality_metric, search.all_values(metric=self.quality_metric))
+                              + "Best K,L for fold %s: %s.\n" % (fi + 1, best))
+            # A fold's walk is a chain of dependent steps of one to three fits, but the folds do not depend on each other: with
+            # several replica slots and seeded candidates (every fit then draws from its own stream, whatever runs beside it) the
+            # walks advance side by side, each from a thread of its own that hands its steps to the shared pool.  Unseeded, the
+            # candidates draw from the workers' global streams in the order they run: fold by fold, as the reference.
+            if self.seed is not None and len(getattr(pool, "devices", [])) > 1 and not getattr(pool, "batched", False):
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max_workers=self.folds) as ex:
+                    done = list(ex.map(fold_search, range(self.folds)))
+            else:
+                done = [fold_search(fi) for fi in range(self.folds)]
+            best_KL, fold_lines = [d[0] for d in done], [d[1] for d in done]
             final = pool.map(fit_model, [job for fi, (train, test) in enumerate(zip(folds_training, folds_test))
                                          for job in self._final_jobs(train, test, best_KL[fi][0], best_KL[fi][1], burn_in, thinning, minimum_TN, fi)])
         finally:

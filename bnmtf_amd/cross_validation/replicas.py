@@ -8,6 +8,7 @@ The reference runs its folds in `multiprocessing.Pool(P)` on CPU cores (parallel
 here the unit of parallelism is a GPU."""
 import inspect
 import multiprocessing as mp
+import threading
 import os
 import traceback
 
@@ -64,14 +65,16 @@ class ReplicaPool(object):
         self.shared = dict(shared or {})
         self.batched = bool(batched)
         self._pool = None
+        self._lock = threading.Lock()           # (map() may be called from several threads: the folds of a greedy-search cross-validation)
 
     def _start(self):
-        if self._pool is None and len(self.devices) > 1:
-            ctx = mp.get_context("spawn")
-            q = ctx.Queue()
-            for d in self.devices:
-                q.put(d)
-            self._pool = ctx.Pool(len(self.devices), initializer=_init_worker, initargs=(q, self.shared))
+        with self._lock:
+            if self._pool is None and len(self.devices) > 1:
+                ctx = mp.get_context("spawn")
+                q = ctx.Queue()
+                for d in self.devices:
+                    q.put(d)
+                self._pool = ctx.Pool(len(self.devices), initializer=_init_worker, initargs=(q, self.shared))
 
     def map(self, fn, jobs, errors="raise"):
         """fn(job, shared) -> result for every job, results in job order; job gets a 'device' entry.  An exception in
