@@ -1134,7 +1134,7 @@ __global__ __launch_bounds__(512) void ssys_chain_kernel(SSysChainArgs a) {
   }
   for (int e = tid; e < n2; e += NT) a.S[e] = Sl[e];
 #ifdef CHAIN_CLOCK
-  if (tid == 0 && (a.it == 30u || a.it == 31u)) printf("chain it %u: prologue %llu, rows (solve) %llu, fixes %llu (%d entries, %d cold), barrier %llu cycles\n", a.it, c_begin - c_k0, c_pro, c_fix, n_fix, n_cold, c_wait);
+  if (tid == 0 && (a.it == 30u || a.it == 31u || a.it == 3000u)) printf("chain it %u: prologue %llu, rows (solve) %llu, fixes %llu (%d entries, %d cold), barrier %llu cycles\n", a.it, c_begin - c_k0, c_pro, c_fix, n_fix, n_cold, c_wait);
 #endif
 }
 void launch_ssys_chain(const SSysChainArgs& a, hipStream_t st) {
