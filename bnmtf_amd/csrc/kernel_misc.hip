@@ -57,40 +57,34 @@ void launch_gram(const GramArgs& a, hipStream_t st) {
 //   sum_Omega R Rp = sum (Pv o V)   (Pv = R~^T U only holds observed entries)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void finish_kernel(FinishArgs a) {
-  __shared__ double red[16][4];
+  __shared__ double red[16];
   const int KP = a.KP, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // four sums at once: <Cr, Cc>, and the three columns of the per-block sweep statistics
-  double v[4] = {0.0, 0.0, 0.0, 0.0};
-  {
-    double p[4] = {0.0, 0.0, 0.0, 0.0};          // 4 x 1024 entries cover K = 64: all eight loads in flight
+  // five sums, one per WAVE (round 5: every wave used to reduce four values over its lanes): waves 0-3 a quarter of <Cr, Cc> each,
+  // waves 4-6 one column of the per-block sweep statistics, wave 7 the column-sum product; the other waves have nothing to do
+  double s = 0.0;
+  if (wave < 4) {
+    const int q4 = KP * KP / 4;                                    // (KP = 32 or 64: 4 or 16 terms per lane, all loads in flight)
+    double p[16];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const int t = threadIdx.x + 1024 * u; if (t < KP * KP) p[u] = a.Cr64[t] * a.Cc64[t]; }
-    v[0] = (p[0] + p[1]) + (p[2] + p[3]);
+    for (int u = 0; u < 16; ++u) { const int t = wave * q4 + lane + 64 * u; p[u] = 64 * u < q4 ? a.Cr64[t] * a.Cc64[t] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += p[u];
+  } else if (wave < 7) {
+    for (int b = lane; b < a.nstats; b += 64) s += a.stats[(size_t)b * 4 + (wave - 4)];
+  } else if (wave == 7) {
+    s = lane < KP ? a.sr[lane] * a.sc[lane] : 0.0;
   }
-  for (int b = threadIdx.x; b < a.nstats; b += 1024)
-    for (int t = 0; t < 3; ++t) v[1 + t] += a.stats[(size_t)b * 4 + t];
+  if (wave < 8) {
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v[t] += __shfl_xor(v[t], m, 64);
-    if (lane == 0) red[wave][t] = v[t];
-  }
-  // column-sum product (KP terms) on wave 0 meanwhile
-  double sp1 = 0.0;
-  if (wave == 0) {
-    sp1 = lane < KP ? a.sr[lane] * a.sc[lane] : 0.0;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) sp1 += __shfl_xor(sp1, m, 64);
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) red[wave] = s;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     double tot[4];
-    for (int t = 0; t < 4; ++t) {
-      double s = 0.0;
-#pragma unroll
-      for (int w = 0; w < 16; ++w) s += red[w][t];
-      tot[t] = s;
-    }
+    tot[0] = (red[0] + red[1]) + (red[2] + red[3]);
+    tot[1] = red[4]; tot[2] = red[5]; tot[3] = red[6];
+    const double sp1 = red[7];
     const double dot = tot[0];
     double acc[3] = {a.acc[0] + tot[1], a.acc[1] + tot[2], a.acc[2] + tot[3]};
     const double srp = acc[0], sp = sp1 - acc[1], spp = dot - acc[2];
@@ -119,43 +113,35 @@ __global__ __launch_bounds__(1024) void finish_kernel(FinishArgs a) {
 __global__ __launch_bounds__(1024) void vb_finish_kernel(VbFinishArgs a) {
   __shared__ double red[16][16];
   const int KP = a.KP, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // 16 sums at once: <Cr, Cc>, six columns of the rows-sweep pieces, six of the cols-sweep pieces, and the three
-  // K-term sums (colsum . colsum, colsum2 . colsum2, diag(Cr) . diag(Cc))
-  double v[16];
+  // 16 sums: <Cr, Cc>, six columns of the rows-sweep pieces, six of the cols-sweep pieces, and the three K-term sums (colsum .
+  // colsum, colsum2 . colsum2, diag(Cr) . diag(Cc)).  Round 5: a sum per WAVE -- waves 0-3 a quarter of <Cr, Cc> each (and, waves
+  // 1-3, one K-term sum), waves 4-15 one column of the pieces -- so a wave reduces one or two values over its lanes, not sixteen
+  // (16 x 6 fp64 shuffles per wave were most of this kernel's 16 us).  red[w][0 / 1] = the wave's sums.
+  double s0 = 0.0, s1 = 0.0;
+  if (wave < 4) {
+    const int q4 = KP * KP / 4;
+    double p[16];
 #pragma unroll
-  for (int t = 0; t < 16; ++t) v[t] = 0.0;
-  for (int t = threadIdx.x; t < KP * KP; t += 1024) v[0] = fma(a.Cr64[t], a.Cc64[t], v[0]);
-  for (int b = threadIdx.x; b < a.nr; b += 1024)
+    for (int u = 0; u < 16; ++u) { const int t = wave * q4 + lane + 64 * u; p[u] = 64 * u < q4 ? a.Cr64[t] * a.Cc64[t] : 0.0; }
 #pragma unroll
-    for (int c = 0; c < 6; ++c) v[1 + c] += a.stats_r[(size_t)b * 8 + c];
-  for (int b = threadIdx.x; b < a.nc; b += 1024)
-#pragma unroll
-    for (int c = 0; c < 6; ++c) v[7 + c] += a.stats_c[(size_t)b * 8 + c];
-  if (threadIdx.x < KP) {
-    const int t = threadIdx.x;
-    v[13] = a.sr[t] * a.sc[t];
-    v[14] = a.s2r[t] * a.s2c[t];
-    v[15] = a.Cr64[t * KP + t] * a.Cc64[t * KP + t];
+    for (int u = 0; u < 16; ++u) s0 += p[u];
+    if (wave >= 1 && lane < KP)
+      s1 = wave == 1 ? a.sr[lane] * a.sc[lane] : wave == 2 ? a.s2r[lane] * a.s2c[lane] : a.Cr64[lane * KP + lane] * a.Cc64[lane * KP + lane];
+  } else {
+    const int c = wave - 4, col = c % 6;
+    const double* src = c < 6 ? a.stats_r : a.stats_c;
+    const int n = c < 6 ? a.nr : a.nc;
+    for (int b = lane; b < n; b += 64) s0 += src[(size_t)b * 8 + col];
   }
 #pragma unroll
-  for (int t = 0; t < 16; ++t) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v[t] += __shfl_xor(v[t], m, 64);
-    if (lane == 0) red[wave][t] = v[t];
-  }
-  __syncthreads();
-  // lane (w, t) of the first four waves sums red[w][t] over w by shuffles: tot[t] ends up in red[0][t]
-  if (threadIdx.x < 256) {
-    const int t = threadIdx.x & 15, w = threadIdx.x >> 4;
-    double sw = red[w][t];
-#pragma unroll
-    for (int m = 32; m >= 16; m >>= 1) sw += __shfl_xor(sw, m, 64);      // the four w of this wave
-    red[w][t] = sw;
-  }
+  for (int m = 32; m >= 1; m >>= 1) { s0 += __shfl_xor(s0, m, 64); s1 += __shfl_xor(s1, m, 64); }
+  if (lane == 0) { red[wave][0] = s0; red[wave][1] = s1; }
   __syncthreads();
   if (threadIdx.x == 0) {
     double tot[16];
-    for (int t = 0; t < 16; ++t) tot[t] = (red[0][t] + red[4][t]) + (red[8][t] + red[12][t]);
+    tot[0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    for (int c = 0; c < 12; ++c) tot[1 + c] = red[4 + c][0];
+    tot[13] = red[1][1]; tot[14] = red[2][1]; tot[15] = red[3][1];
     const double dot = tot[0];
     const double* su = &tot[1];
     const double* sv = &tot[7];
