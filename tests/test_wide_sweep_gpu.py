@@ -147,10 +147,15 @@ def test_a_run_split_in_two_calls_is_the_same_chain(monkeypatch, handover):
         assert np.array_equal(three.all_U, one.all_U[3:])       # without the hand-over nothing but (U, V, tau) is carried: identical
 
 
-def test_headline_shape_properties():
+@pytest.mark.parametrize("handover", [True, False])
+def test_headline_shape_properties(monkeypatch, handover):
     """8192 x 8192, K = 64, 10 % missing (the bench configuration): the observed counts are exact, the metrics from the
     Gram identities equal the direct fp64 metric kernel on the same sample, the chain reaches the noise floor, and the
-    draws are non-negative and finite."""
+    draws are non-negative and finite.  handover = False (BNMTF_HANDOVER=0: q rebuilt from the factors in every half sweep,
+    the path of rounds 1-2 and of every multi-GPU run): the identity metrics then meet the direct ones to 1e-4, the bound
+    that held before q was handed over between the half sweeps; with the hand-over (the default on one GPU) the stated 3e-4."""
+    if not handover:
+        monkeypatch.setenv("BNMTF_HANDOVER", "0")
     I = J = 8192; K = 64
     R, M, _, _ = generate_bnmf(I, J, K, 0.1, tau=1.0, seed_data=0, seed_mask=1)
     b = bnmf_gibbs_optimised(R, M, K, PRI, verbose=False, seed=0)
@@ -185,7 +190,7 @@ def test_headline_shape_properties():
     # the STATED tolerance of the per-iteration metrics at this size: 3e-4 relative to the fp64
     # metric of the same (U, V) -- the Gram identity takes sum q^2 from fp32 q that is handed back and forth between the half sweeps
     # (measured: 1.0 / 1.4 / 1.5e-4 after 16 / 200 / 1 000 iterations, tools/handover_drift.py)
-    assert abs(p["MSE"] - mse[-1]) < 3e-4 * mse[-1]
+    assert abs(p["MSE"] - mse[-1]) < (3e-4 if handover else 1e-4) * mse[-1]
     assert abs(p["Rp"] - b.all_performances["Rp"][-1]) < 1e-5
     assert np.isfinite(b.U).all() and np.isfinite(b.V).all() and b.U.min() >= 0 and b.V.min() >= 0
 
