@@ -56,6 +56,7 @@ _SIGS = {
     "bnmtf_is_small": ([_P, C.POINTER(C.c_int)], C.c_int),
     "bnmtf_set_state": ([_P, _P, _P, _P, C.c_double], C.c_int),
     "bnmtf_get_state": ([_P, _P, _P, _P, C.POINTER(C.c_double)], C.c_int),
+    "bnmtf_gibbs_run_many": ([_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
     "bnmtf_cond_params": ([_P, C.c_int, C.c_int, C.c_int, _P, _P], C.c_int),
     "bnmtf_gibbs_run": ([_P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P], C.c_int),
     "bnmf_vb_set_state": ([_P] + [_P] * 8 + [C.c_double], C.c_int),

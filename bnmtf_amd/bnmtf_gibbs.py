@@ -66,26 +66,48 @@ class bnmtf_gibbs_optimised(DeviceModel):
         self.tau = self.alpha_s() / self.beta_s()
 
     def _push(self):
+        tau = float(getattr(self, "tau", 1.0))
+        # the state the device holds already (nothing touched F, S, G, tau since the last run() pulled them): no upload -- and the
+        # device keeps what it carries between its half sweeps, so run(a); run(b) is the chain of run(a + b)
+        held = getattr(self, "_device_state", None)
+        if (held is not None and held[0] is self._h and tau == held[4] and np.array_equal(self.F, held[1])
+                and np.array_equal(self.S, held[2]) and np.array_equal(self.G, held[3])):
+            return
+        self._device_state = None
         _lib.check(_lib.lib().bnmtf_set_state(self._handle(), _lib.ptr(_lib.f64(self.F)), _lib.ptr(_lib.f64(self.S)),
-                                              _lib.ptr(_lib.f64(self.G)), float(getattr(self, "tau", 1.0))))
+                                              _lib.ptr(_lib.f64(self.G)), tau))
 
     def _pull(self):
         F = np.zeros((self.I, self.K)); S = np.zeros((self.K, self.L)); G = np.zeros((self.J, self.L)); tau = C.c_double()
         _lib.check(_lib.lib().bnmtf_get_state(self._handle(), _lib.ptr(F), _lib.ptr(S), _lib.ptr(G), C.byref(tau)))
         self.F, self.S, self.G, self.tau = F, S, G, tau.value
+        self._device_state = (self._h, F.copy(), S.copy(), G.copy(), tau.value)
 
     def run(self, iterations, update='draw', store_samples=True, expectation=None):
         """:138-180.  expectation=(burn_in, thinning): posterior means accumulated on the device (see bnmf_gibbs_optimised.run)."""
+        bufs = self._run_prepare(iterations, store_samples, expectation)
+        it, F_out, S_out, G_out, taus, perf, times = bufs
+        _lib.check(_lib.lib().bnmtf_gibbs_run(self._handle(), it, _lib.UPDATE_MODE if update == 'mode' else _lib.UPDATE_DRAW,
+                                              _lib.ptr(F_out), _lib.ptr(S_out), _lib.ptr(G_out), _lib.ptr(taus), _lib.ptr(perf), _lib.ptr(times)))
+        return self._run_finish(bufs, store_samples)
+
+    # run() in two halves, so that bnmtf_amd.run_many can put many models' device part into one call
+    def _run_prepare(self, iterations, store_samples, expectation):
         it = int(iterations)
         self._push()
         self._set_expectation(expectation, it)
         F_out = _lib.sample_buffer((it, self.I, self.K)) if store_samples else None
         S_out = _lib.sample_buffer((it, self.K, self.L)) if store_samples else None
         G_out = _lib.sample_buffer((it, self.J, self.L)) if store_samples else None
-        taus = np.zeros(it); perf = np.zeros((it, 3)); times = np.zeros(it)
-        _lib.check(_lib.lib().bnmtf_gibbs_run(self._handle(), it, _lib.UPDATE_MODE if update == 'mode' else _lib.UPDATE_DRAW,
-                                              _lib.ptr(F_out), _lib.ptr(S_out), _lib.ptr(G_out), _lib.ptr(taus), _lib.ptr(perf), _lib.ptr(times)))
-        self._pull()
+        return (it, F_out, S_out, G_out, np.zeros(it), np.zeros((it, 3)), np.zeros(it))
+
+    def _run_finish(self, bufs, store_samples, state=None):
+        it, F_out, S_out, G_out, taus, perf, times = bufs
+        if state is None:
+            self._pull()
+        else:                       # (run_many fetched the final states of the whole batch with one synchronisation)
+            self.F, self.S, self.G, self.tau = state[0], state[1], state[2], float(state[3][0])
+            self._device_state = (self._h, self.F.copy(), self.S.copy(), self.G.copy(), self.tau)
         self.all_F = F_out if store_samples else np.zeros((0, self.I, self.K))
         self.all_S = S_out if store_samples else np.zeros((0, self.K, self.L))
         self.all_G = G_out if store_samples else np.zeros((0, self.J, self.L))

@@ -1000,7 +1000,8 @@ int bnmtf_create(const bnmtf_problem* p, bnmtf_handle* out) {
   // BNMTF_SMALL=0: never.
   h->lam_rows.assign(p->lambda_rows, p->lambda_rows + (size_t)I * Wr);
   h->lam_cols.assign(p->lambda_cols, p->lambda_cols + (size_t)J * Wc);
-  if (p->L == 0 && p->world == 1 && !getenv("BNMTF_FORCE_COMM")) {
+  if (p->L > 0) h->lam_S.assign(p->lambda_S, p->lambda_S + (size_t)p->K * p->L);
+  if (p->world == 1 && !getenv("BNMTF_FORCE_COMM")) {
     if ((rcode = small_build(h, R, M))) return fail(rcode);
   }
   if (!h->one_arena) {   // the full matrix and the training mask (predict / validation; the layout passes read them on the device); small scalars -- one allocation
@@ -1454,17 +1455,20 @@ int bnmtf_metric_sums(bnmtf_handle h, const uint8_t* Mp, const double* A, const 
   if (!A) {
     if (!h->have_state) { set_error("no state set"); return BNMTF_ESTATE; }
     a_own.resize((size_t)I * h->rows.W); b_own.resize((size_t)J * h->cols.W);
-    if (h->small && h->small_cur) CHK(small_download_state(h, a_own.data(), b_own.data()));
+    const bool from_small = h->small && h->small_cur;
+    if (h->L > 0) as.resize((size_t)h->K * h->L);
+    if (from_small) CHK(small_download_state(h, a_own.data(), b_own.data(), h->L > 0 ? as.data() : nullptr));
     else {
       CHK(download_matrix(h, h->rows.X, I, h->rows.W, h->rows.KP, a_own.data()));
       CHK(download_matrix(h, h->cols.X, J, h->cols.W, h->cols.KP, b_own.data()));
     }
     A = a_own.data(); B = b_own.data();
     if (h->L > 0) {
-      as.resize((size_t)h->K * h->L);
-      std::vector<float> sf((size_t)h->K * h->L);
-      HIPCHK(hipMemcpy(sf.data(), h->S, sf.size() * sizeof(float), hipMemcpyDeviceToHost));
-      for (size_t t = 0; t < sf.size(); ++t) as[t] = sf[t];
+      if (!from_small) {
+        std::vector<float> sf((size_t)h->K * h->L);
+        HIPCHK(hipMemcpy(sf.data(), h->S, sf.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t t = 0; t < sf.size(); ++t) as[t] = sf[t];
+      }
       S = as.data();
     }
   }

@@ -80,9 +80,11 @@ template <int NT> struct Misc {
   static_assert(red % 2 == 0 && c64 % 2 == 0 && part % 2 == 0, "doubles are 8-byte aligned");
 };
 
-__host__ __device__ inline int small_misc_offset(int I, int J) { return ((I + 1) * kS + (J + 1) * kS + 2 * 32 * kS + 3) & ~3; }
-size_t small_lds_bytes(int I, int J, int nt) {
-  return sizeof(float) * (size_t)(small_misc_offset(I, J) + (nt <= 256 ? Misc<256>::floats : (nt <= 512 ? Misc<512>::floats : Misc<1024>::floats)));
+// (tri-factorisation, L > 0: behind the two Gram copies the Gram of F [K rows], the Gram of G [L rows], S [K rows] and S^T [L rows])
+__host__ __device__ inline int small_tri_floats(int K, int L) { return L > 0 ? (2 * K + 2 * L) * kS : 0; }
+__host__ __device__ inline int small_misc_offset(int I, int J, int K = 0, int L = 0) { return ((I + 1) * kS + (J + 1) * kS + 2 * 32 * kS + small_tri_floats(K, L) + 3) & ~3; }
+size_t small_lds_bytes(int I, int J, int nt, int K, int L) {
+  return sizeof(float) * (size_t)(small_misc_offset(I, J, K, L) + (nt <= 256 ? Misc<256>::floats : (nt <= 512 ? Misc<512>::floats : Misc<1024>::floats)));
 }
 
 // sum of four doubles over the block, in a fixed order (wave: xor butterfly; block: wave 0 .. 15); every thread gets the sums
@@ -116,7 +118,8 @@ __device__ __forceinline__ void block_sum4(double v[4], double* red, int tid) {
 // factor) or <C_other, C> (c64_dot: the cols factor, at the end of the iteration; returned by thread 0, zero elsewhere).
 // Columns >= K of the region are zero.
 template <int NT>
-__device__ __forceinline__ double small_gram(const float* reg, int n, int K, float* scratch, float* Cs, double* colsum, double* c64_out, const double* c64_dot, int tid) {
+__device__ __forceinline__ double small_gram(const float* reg, int n, int K, float* scratch, float* Cs, double* colsum, double* c64_out, const double* c64_dot, int tid,
+                                             int rows_out = 32) {
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   constexpr int GW = Misc<NT>::gram_waves;
@@ -174,12 +177,12 @@ __device__ __forceinline__ double small_gram(const float* reg, int n, int K, flo
     else if constexpr (GW == 2) s = scr[tile * 256 + e] + scr[(3 + tile) * 256 + e];
     else s = scr[tile * 256 + e];
     const int a = (ln >> 4) + 4 * r + (tile == 2 ? 16 : 0), b = (ln & 15) + (tile >= 1 ? 16 : 0);    // C/D of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 reg
-    Cs[a * kS + b] = (float)s;
+    if (a < rows_out) Cs[a * kS + b] = (float)s;          // (rows_out < 32: a Gram copy that holds the factor's own width only -- the rest is zero)
     if (c64_out) c64_out[a * 32 + b] = s;
     double pr = 0.0;
     if (c64_dot) pr = c64_dot[a * 32 + b] * s;
     if (tile == 1) {
-      Cs[b * kS + a] = (float)s;
+      if (b < rows_out) Cs[b * kS + a] = (float)s;
       if (c64_out) c64_out[b * 32 + a] = s;
       if (c64_dot) pr += c64_dot[b * 32 + a] * s;
     }
@@ -217,6 +220,7 @@ struct ContractArgs {
   const float* big; const float* XT; const float* lambda; float* PT;
   int n, m, ldb, ldn, K; float tau;
   uint32_t regO_b, CsO_b, regOwn_b;       // LDS byte addresses of the other factor, its Gram, and the own factor's region
+  bool raw = false;                       // the bare product sum_r big[r][u] Xo[r][k] into PT, nothing else (the S step's R~ G)
 };
 template <int UW, int NT>
 __device__ __forceinline__ void small_contract(const ContractArgs& d, int tid) {
@@ -236,7 +240,7 @@ __device__ __forceinline__ void small_contract(const ContractArgs& d, int tid) {
   const int kt = (K + 15) >> 4, ub = (d.n + 16 * UW - 1) / (16 * UW), items = ub * kt;
   // batches of NB inner steps (4 rows each): nb_big of R~ (its rows behind m are zero), then the K x K term's: A = X^T (rows
   // behind K zero), B = -C
-  const int nb_big = ((d.m + 31) & ~31) / (4 * NB), nb = nb_big + (K + 4 * NB - 1) / (4 * NB);
+  const int nb_big = ((d.m + 31) & ~31) / (4 * NB), nb = d.raw ? nb_big : nb_big + (K + 4 * NB - 1) / (4 * NB);
   for (int item = wave; item < items; item += NT / 64) {
     const int u0 = (item / kt) * 16 * UW, k0 = (item % kt) * 16;
     f32x4 acc[UW], pacc[UW];
@@ -311,6 +315,16 @@ __device__ __forceinline__ void small_contract(const ContractArgs& d, int tid) {
 #endif
     // C/D of the 16x16 f32 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg
     const int k = k0 + li;
+    if (d.raw) {
+#pragma unroll
+      for (int t = 0; t < UW; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int u = u0 + UW * (4 * lk + r) + t;
+          if (u < d.n && k < K) *G(PT + (size_t)k * d.ldn + u) = acc[t][r];
+        }
+      continue;
+    }
     float lam[UW][4];                      // the prior rates: all loads first (one after the other they were 16 L2 round trips per item)
 #pragma unroll
     for (int t = 0; t < UW; ++t)
@@ -335,17 +349,49 @@ __device__ __forceinline__ void small_contract(const ContractArgs& d, int tid) {
   }
 }
 
-template <int EM, int NT>
+// The in-place products of the tri-factorisation: row u of `reg` (Win values) becomes its product with S (TR = false:
+// out_c = sum_w x_w S[w][c], S as Sm = S) or with S^T (the caller passes Sm = S^T), Wout values and zeros up to 32.  One thread per
+// row, the row in registers (WB = Win rounded up to 8; the rows of Sm are zero behind Win).
+template <int WB, int NT>
+__device__ __forceinline__ void small_row_product(float* reg, int n, int Wout, const float* SmT, int tid) {
+  for (int u = tid; u < n; u += NT) {
+    float x[WB];
+#pragma unroll
+    for (int w = 0; w < WB; ++w) x[w] = reg[u * kS + w];
+    for (int c = 0; c < 32; ++c) {
+      float acc = 0.f;
+      if (c < Wout) {
+#pragma unroll
+        for (int w = 0; w < WB; ++w) acc = fmaf(x[w], SmT[c * kS + w], acc);      // SmT[c][w] = Sm[w][c]: out_c = sum_w x_w Sm[w][c]
+      }
+      reg[u * kS + c] = acc;
+    }
+  }
+}
+template <int NT>
+__device__ __forceinline__ void small_times_S(float* reg, int n, int Win, int Wout, const float* SmT, int tid) {
+  if (Win <= 8) small_row_product<8, NT>(reg, n, Wout, SmT, tid);
+  else if (Win <= 16) small_row_product<16, NT>(reg, n, Wout, SmT, tid);
+  else small_row_product<32, NT>(reg, n, Wout, SmT, tid);
+}
+
+template <int EM, int NT, bool TRI>
 __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __restrict__ all) {
   extern __shared__ float lds[];
   const SmallLaunch& L = all[blockIdx.x];
   const int tid = threadIdx.x;
   const int I = L.rows.n, J = L.cols.n, K = L.K;
+  const int Lc = TRI ? L.L : K;            // width of the cols factor (tri-factorisation: G is J x L)
   float* regR = lds;
   float* regC = regR + (I + 1) * kS;
   float* CsR = regC + (J + 1) * kS;
   float* CsC = CsR + 32 * kS;
-  float* misc = lds + small_misc_offset(I, J);
+  // tri-factorisation: Gram of F [K rows], Gram of G [L rows], S [K rows], S^T [L rows] (rows of 33, zero behind the widths)
+  float* CfT = CsC + 32 * kS;
+  float* CgT = CfT + (TRI ? K : 0) * kS;
+  float* Ss = CgT + (TRI ? Lc : 0) * kS;
+  float* SsT = Ss + (TRI ? K : 0) * kS;
+  float* misc = lds + small_misc_offset(I, J, K, TRI ? Lc : 0);
   typedef Misc<NT> MS;
   float2* part = reinterpret_cast<float2*>(misc + MS::part);
   float* numer_s = misc + MS::numer; float* taup_s = misc + MS::taup; float* xk_s = misc + MS::xk;
@@ -360,15 +406,20 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
 
   // ---- the state into LDS: both factors (zero pads, zero row behind the last), the transposed copies the column loop reads
   for (int t = tid; t < (I + 1) * kS; t += NT) { const int u = t / kS, k = t - u * kS; regR[t] = (u < I && k < K) ? L.rows.X[u * 32 + k] : 0.f; }
-  for (int t = tid; t < (J + 1) * kS; t += NT) { const int u = t / kS, k = t - u * kS; regC[t] = (u < J && k < K) ? L.cols.X[u * 32 + k] : 0.f; }
-  for (int t = tid; t < 2 * 32 * kS; t += NT) CsR[t] = 0.f;
+  for (int t = tid; t < (J + 1) * kS; t += NT) { const int u = t / kS, k = t - u * kS; regC[t] = (u < J && k < Lc) ? L.cols.X[u * 32 + k] : 0.f; }
+  for (int t = tid; t < 2 * 32 * kS + (TRI ? small_tri_floats(K, Lc) : 0); t += NT) CsR[t] = 0.f;
   for (int t = tid; t < I * K; t += NT) { const int u = t % I, k = t / I; L.rows.XT[(size_t)k * L.rows.ldn + u] = L.rows.X[u * 32 + k]; }
-  for (int t = tid; t < J * K; t += NT) { const int u = t % J, k = t / J; L.cols.XT[(size_t)k * L.cols.ldn + u] = L.cols.X[u * 32 + k]; }
+  for (int t = tid; t < J * Lc; t += NT) { const int u = t % J, k = t / J; L.cols.XT[(size_t)k * L.cols.ldn + u] = L.cols.X[u * 32 + k]; }
   if (tid < 4) cnt[tid] = 0;
   if (tid == 0) { *tau_s = *L.tau_f; L.clock[0] = wall_clock64(); }
   bar_all();
-  small_gram<NT>(regR, I, K, gscr, CsR, csum, c64R, nullptr, tid);
-  small_gram<NT>(regC, J, K, gscr, CsC, csum + 32, nullptr, nullptr, tid);
+  if constexpr (TRI) {
+    for (int t = tid; t < K * Lc; t += NT) { const int k = t / Lc, l = t - k * Lc; const float v = L.S[t]; Ss[k * kS + l] = v; SsT[l * kS + k] = v; }
+    small_gram<NT>(regC, J, Lc, gscr, CgT, csum + 32, nullptr, nullptr, tid, Lc);      // (the Grams of the effective factors are formed ahead of each half sweep)
+  } else {
+    small_gram<NT>(regR, I, K, gscr, CsR, csum, c64R, nullptr, tid);
+    small_gram<NT>(regC, J, K, gscr, CsC, csum + 32, nullptr, nullptr, tid);
+  }
 
   int rr = 0;                                // running retry-round number: list rr % 3 is the one being filled / read
   const bool draw = L.update == BNMTF_UPDATE_DRAW;
@@ -398,13 +449,22 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
       const float tau = *tau_s;
       const int n = d.n, m = d.m, em = d.em;
       const bool entry = tq < d.nthreads, unit = tq < n;
+      const int Kd = dir == 0 ? K : Lc;         // columns of this half sweep (= width of the own factor and of the other, effective, one)
+      if constexpr (TRI) {
+        // the other factor of this half sweep in place: G S^T (J x K) for the F sweep, F S (I x L) for the G sweep, and its Gram
+        small_times_S<NT>(dir == 0 ? regC : regR, m, dir == 0 ? Lc : K, Kd, dir == 0 ? Ss : SsT, tq);
+        if (Kd < 32)                               // (the own region held the other sweep's effective factor: nothing behind this sweep's width)
+          for (int t = tq; t < n * (32 - Kd); t += NT) { const int u = t / (32 - Kd), k = Kd + t - u * (32 - Kd); regOwn[u * kS + k] = 0.f; }
+        // (+ the fp64 Gram and the column sums of F S: the end of the iteration)
+        small_gram<NT>(dir == 0 ? regC : regR, m, Kd, gscr, dir == 0 ? CsC : CsR, dir == 0 ? csum + 32 : csum, dir == 0 ? nullptr : c64R, nullptr, tq);
+      }
 
       // ---- the Philox words of the first nc0 candidates of every (unit, column) of this half sweep, by all threads at once
       // (they depend on the counters only; inside the column loop a Philox call is ~800 cycles of a wave on the critical path)
       constexpr int nc0 = 1;
       u32x2n* tab = reinterpret_cast<u32x2n*>(d.tab);
       if (draw)
-        for (int e = tq; e < K * nc0 * d.ldn; e += NT) {
+        for (int e = tq; e < Kd * nc0 * d.ldn; e += NT) {
           const int u = e % d.ldn, kc = e / d.ldn;
           if (u < n) {
             const U4 r = philox4x32_10((uint32_t)u, (uint32_t)(kc / nc0), it32, stream + 16u * (uint32_t)(kc % nc0), L.key0, L.key1);
@@ -414,13 +474,13 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
       STAMP(0);
       // ---- contraction: regOwn = G (nothing of the sweep's per-thread state is live yet: the operand pipeline has the registers)
       {
-        const int kt = (K + 15) >> 4;
+        const int kt = (Kd + 15) >> 4;
         ContractArgs ca;
 #ifdef BNMTF_SMALL_TIMING
         ca.cph = cph + 3 * dir;
 #endif
         ca.big = d.big; ca.XT = d.XT; ca.lambda = d.lambda; ca.PT = dir == 1 ? L.PT : nullptr;
-        ca.n = n; ca.m = m; ca.ldb = d.ldb; ca.ldn = d.ldn; ca.K = K; ca.tau = tau;
+        ca.n = n; ca.m = m; ca.ldb = d.ldb; ca.ldn = d.ldn; ca.K = Kd; ca.tau = tau;
         ca.regO_b = (uint32_t)(uintptr_t)(lds_fp)regO; ca.CsO_b = (uint32_t)(uintptr_t)(lds_fp)CsO; ca.regOwn_b = (uint32_t)(uintptr_t)(lds_fp)regOwn;
         if (((n + 63) / 64) * kt >= NT / 64) small_contract<4, NT>(ca, tq);
         else if (((n + 31) / 32) * kt >= NT / 128) small_contract<2, NT>(ca, tq);
@@ -448,7 +508,7 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
       const bool prepass = dir == 0 && (it_abs % L.refresh == 0 || (it == 0 && !L.q_valid));
       if (prepass) {
         if (entry)
-          for (int k = 0; k < K; ++k) {
+          for (int k = 0; k < Kd; ++k) {
             const float xv = *G(d.XT + (size_t)k * d.ldn + myunit);
 #pragma unroll
             for (int h = 0; h < EM / 2; ++h)
@@ -482,7 +542,7 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
       }
       if (cand_on) cw_n = *G(tab + (size_t)cc * T + cu);
 #pragma unroll 1
-      for (int k = 0; k < K; ++k) {
+      for (int k = 0; k < Kd; ++k) {
         if (entry) {
           const float dlt = k > 0 ? dl[myunit] : 0.f;
           float qv = 0.f, vv = 0.f;
@@ -511,7 +571,7 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
         float gk = 0.f, ckk = 0.f;
         TnCand cand = {0.f, 0.f, 0.f};
         if (cand_on) cand = tn_cand_pre(cw_n.x, cw_n.y);
-        if (k + 1 < K) {
+        if (k + 1 < Kd) {
           if (unit) {
             xk_n = *G(d.XT + (size_t)(k + 1) * T + tq);
             if (dir == 1) pv_n = *G(L.PT + (size_t)(k + 1) * T + tq);
@@ -599,12 +659,12 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
           regOwn[tq * kS + k] = xnew;
           if (dir == 1) st_px += (double)pv * (double)xnew;
           const float t = tau * delta;
-          for (int k2 = k + 1; k2 < K; k2 += 8) {
+          for (int k2 = k + 1; k2 < Kd; k2 += 8) {
             float g8[8], c8[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const int kk = min(k2 + j, 31); g8[j] = regOwn[tq * kS + kk]; c8[j] = CsO[k * kS + kk]; }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) if (k2 + j < K) regOwn[tq * kS + k2 + j] = fmaf(-t, c8[j], g8[j]);
+            for (int j = 0; j < 8; ++j) if (k2 + j < Kd) regOwn[tq * kS + k2 + j] = fmaf(-t, c8[j], g8[j]);
           }
         }
         STAMP(9);
@@ -617,7 +677,7 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
           if (e < em) {
             float vlast;
             if constexpr (KEEPV) vlast = vp[e];
-            else vlast = regO[((jj[e >> 1] >> (16 * (e & 1))) & 0xFFFFu) + (K - 1)];
+            else vlast = regO[((jj[e >> 1] >> (16 * (e & 1))) & 0xFFFFu) + (Kd - 1)];
             q[e] = fmaf(dlt, vlast, q[e]);
             *G(d.q + e * kSmallThreads + tq) = q[e];
             if (dir == 1) { st_q += (double)q[e]; st_q2 += (double)q[e] * (double)q[e]; }
@@ -626,24 +686,203 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
       bar_all();                               // q and the transposed factor: read by other threads in the next half sweeps
       STAMP(10);
       // ---- Gram of the new factor; state, sample, posterior sums
-      if (dir == 0) small_gram<NT>(regOwn, n, K, gscr, CsR, csum, c64R, nullptr, tq);
-      else st_dot = small_gram<NT>(regOwn, n, K, gscr, CsC, csum + 32, nullptr, c64R, tq);
+      if constexpr (TRI) {       // the factors' own Grams are the S step's; the sweeps read the effective factors' (formed ahead of them)
+        st_dot = small_gram<NT>(regOwn, n, Kd, gscr, dir == 0 ? CfT : CgT, dir == 0 ? csum : csum + 32, nullptr, dir == 0 ? nullptr : c64R, tq, Kd);
+      } else {
+        if (dir == 0) small_gram<NT>(regOwn, n, K, gscr, CsR, csum, c64R, nullptr, tq);
+        else st_dot = small_gram<NT>(regOwn, n, K, gscr, CsC, csum + 32, nullptr, c64R, tq);
+      }
       if (tq < 4) cnt[tq] = 0;                 // (no list is in flight here; rr keeps counting)
       STAMP(11);
       {
         float* smp = dir == 0 ? L.U_s : L.V_s;
         double* ex = dir == 0 ? L.expR : L.expC;
         const bool add = ex && L.exp_burn >= 0 && it >= L.exp_burn && (it - L.exp_burn) % L.exp_thin == 0;
-        for (int t = tq; t < n * K; t += NT) {
-          const int u = t / K, k = t - u * K;
+        for (int t = tq; t < n * Kd; t += NT) {
+          const int u = t / Kd, k = t - u * Kd;
           const float v = regOwn[u * kS + k];
           *G(d.X + u * 32 + k) = v;
-          if (smp) *G(smp + ((size_t)it * n + u) * K + k) = v;
+          if (smp) *G(smp + ((size_t)it * n + u) * Kd + k) = v;
           if (add) *G(ex + u * 32 + k) += (double)v;
         }
       }
       bar_lds();
       STAMP(12);
+
+      // ================================================= the S step of the tri-factorisation (bnmtf_gibbs_optimised.py:157-160, 201-205)
+      // The conditional of S_kl needs sums over the OBSERVED entries of w_ij = F_ik G_jl; in the exact Gram + sparse-complement form
+      //   tau_p = tau (Cf_kk Cg_ll - sum_miss w^2),   numer = -lambda + tau (r_kl + sum_miss q w + S_kl (Cf_kk Cg_ll - sum_miss w^2)),
+      //   r = F^T R~ G - Cf S Cg (kept current: r -= delta Cf[:, k] (x) Cg[l, :]),   q_ij = (F S G^T)_ij on the missing entries,
+      // q in the registers of the F sweep's entry threads (a thread's entries share i: one F_ik per thread and row of S), the two
+      // sums over the missing entries = the column loop's gather of G's column l, reduced over the whole block by wave 0, which draws.
+      if constexpr (TRI) if (dir == 0) {
+        const int n2 = K * Lc;
+        float* rS = reinterpret_cast<float*>(c64R);          // [K L] (the fp64 Gram's area is free until the G sweep's effective factor is formed)
+        float* tmpS = rS + 1024;
+        for (int t = tq; t < J * kS; t += NT) { const int u = t / kS, k = t - u * kS; regC[t] = k < Lc ? *G(L.cols.X + u * 32 + k) : 0.f; }     // G back into its region
+        if (draw)
+          for (int e = tq; e < n2 * 4; e += NT) {
+            const U4 r = philox4x32_10(0u, (uint32_t)(e >> 2), it32, kStreamS + 16u * (uint32_t)(e & 3), L.key0, L.key1);
+            *G(reinterpret_cast<u32x2n*>(L.stab) + e) = u32x2n{r.x, r.y};
+          }
+        for (int pp = tq; pp < n2; pp += NT) {               // T = S Cg
+          const int kk = pp / Lc, ll = pp - kk * Lc;
+          float a = 0.f;
+          for (int l2 = 0; l2 < Lc; ++l2) a = fmaf(Ss[kk * kS + l2], CgT[l2 * kS + ll], a);
+          tmpS[pp] = a;
+        }
+        bar_lds();
+        {
+          const int kt = (Lc + 15) >> 4;
+          ContractArgs ca;
+#ifdef BNMTF_SMALL_TIMING
+          ca.cph = cph;
+#endif
+          ca.big = d.big; ca.XT = d.XT; ca.lambda = d.lambda; ca.PT = L.ZT;
+          ca.n = n; ca.m = m; ca.ldb = d.ldb; ca.ldn = d.ldn; ca.K = Lc; ca.tau = tau; ca.raw = true;
+          ca.regO_b = (uint32_t)(uintptr_t)(lds_fp)regC; ca.CsO_b = (uint32_t)(uintptr_t)(lds_fp)CsC; ca.regOwn_b = (uint32_t)(uintptr_t)(lds_fp)regR;
+          (void)kt;
+          small_contract<2, NT>(ca, tq);           // (one shape for this product: a third of the sweep's)
+        }
+        for (int pp = tq; pp < n2; pp += NT) {               // Cf T
+          const int kk = pp / Lc, ll = pp - kk * Lc;
+          float a = 0.f;
+          for (int k2 = 0; k2 < K; ++k2) a = fmaf(CfT[kk * kS + k2], tmpS[k2 * Lc + ll], a);
+          rS[pp] = a;
+        }
+        bar_all();                               // (Z is read by other threads than the ones that stored it)
+        for (int p0 = 0; p0 < n2; p0 += NT / 8) {                // r = F^T Z - Cf S Cg: eight threads per entry, fp64 sums
+          const int pp = p0 + (tq >> 3), s8 = tq & 7;
+          double a = 0.0;
+          if (pp < n2) {
+            const int kk = pp / Lc, ll = pp - kk * Lc;
+            for (int i = s8; i < I; i += 8) a += (double)regR[i * kS + kk] * (double)*G(L.ZT + (size_t)ll * d.ldn + i);
+          }
+          a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
+          if (pp < n2 && s8 == 0) rS[pp] = (float)(a - (double)rS[pp]);
+        }
+        // this thread's slots and q again (the sweep's registers are gone; q as the sweep stored it)
+        uint32_t sj[EM / 2];
+        float sq[EM], sv[KEEPV ? EM : 2];
+#pragma unroll
+        for (int h = 0; h < EM / 2; ++h) {
+          uint32_t j0 = (uint32_t)(m * kS), j1 = (uint32_t)(m * kS);
+          if (entry && 2 * h < em) { j0 = *G(d.idx + (2 * h) * kSmallThreads + tq); j1 = *G(d.idx + (2 * h + 1) * kSmallThreads + tq); }
+          sj[h] = j0 | (j1 << 16);
+          sq[2 * h] = sq[2 * h + 1] = 0.f;
+          if constexpr (KEEPV) sv[2 * h] = sv[2 * h + 1] = 0.f;
+          if (entry && 2 * h < em) { sq[2 * h] = *G(d.q + (2 * h) * kSmallThreads + tq); sq[2 * h + 1] = *G(d.q + (2 * h + 1) * kSmallThreads + tq); }
+        }
+        float dprev = 0.f;                       // delta of the step before x this thread's F value of that step's row
+        int lprev = 0;
+        u32x2n scw = {0u, 0u};
+        const u32x2n* stab = reinterpret_cast<const u32x2n*>(L.stab);
+        bar_all();                               // (rS, the candidate words)
+        if (draw && tq < 4) scw = *G(stab + tq);
+        float lam_n = tq < 64 ? *G(L.lambdaS) : 0.f;
+#pragma unroll 1
+        for (int k = 0; k < K; ++k) {
+          const float f = entry ? regR[myunit * kS + k] : 0.f;
+#pragma unroll 1
+          for (int l = 0; l < Lc; ++l) {
+            const int pp = k * Lc + l;
+            if (entry) {
+              float qg = 0.f, gg = 0.f;
+              const float* col = regC + l;
+#pragma unroll
+              for (int h = 0; h < EM / 2; ++h)
+                if (2 * h < em) {
+                  asm volatile("" : "+v"(sj[h]));
+                  const float g0 = col[sj[h] & 0xFFFFu], g1 = col[sj[h] >> 16];
+                  if constexpr (KEEPV) {
+                    sq[2 * h] = fmaf(dprev, sv[2 * h], sq[2 * h]);
+                    sq[2 * h + 1] = fmaf(dprev, sv[2 * h + 1], sq[2 * h + 1]);
+                    sv[2 * h] = g0; sv[2 * h + 1] = g1;
+                  } else if (pp > 0) {
+                    sq[2 * h] = fmaf(dprev, regC[(sj[h] & 0xFFFFu) + lprev], sq[2 * h]);
+                    sq[2 * h + 1] = fmaf(dprev, regC[(sj[h] >> 16) + lprev], sq[2 * h + 1]);
+                  }
+                  qg = fmaf(sq[2 * h], g0, qg); gg = fmaf(g0, g0, gg);
+                  qg = fmaf(sq[2 * h + 1], g1, qg); gg = fmaf(g1, g1, gg);
+                }
+              part[tq] = float2{f * qg, f * f * gg};
+            }
+            // wave 0 draws: its candidates' word-only halves and the next step's words ahead of the barrier
+            TnCand cand = {0.f, 0.f, 0.f};
+            const float lamS = lam_n;
+            if (tq < 64) {
+              if (draw && tq < 4) cand = tn_cand_pre(scw.x, scw.y);
+              if (pp + 1 < n2) {
+                if (draw && tq < 4) scw = *G(stab + (size_t)(pp + 1) * 4 + tq);
+                lam_n = *G(L.lambdaS + pp + 1);
+              }
+            }
+            bar_lds();
+            if (tq < 64) {
+              float sx = 0.f, sy = 0.f;
+              for (int t = tq; t < d.nthreads; t += 64) { const float2 pt = part[t]; sx += pt.x; sy += pt.y; }
+#pragma unroll
+              for (int mk = 32; mk >= 1; mk >>= 1) { sx += __shfl_xor(sx, mk, 64); sy += __shfl_xor(sy, mk, 64); }
+              const float sold = Ss[k * kS + l];
+              const float adiag = CfT[k * kS + k] * CgT[l * kS + l] - sy;
+              const float tau_p = tau * adiag;
+              const float numer = fmaf(tau, rS[pp] + sx + sold * adiag, -lamS);
+              float xnew = 0.f;
+              if (draw) {
+                const TnFast tf = tn_fast_params(numer, tau_p);
+                float xc = 0.f;
+                const bool acc = tq < 4 && tn_cand_post(tf, cand, &xc);
+                unsigned long long mask = __ballot(acc);
+                if (tf.live) {
+                  if (mask) xnew = tn_guard(__shfl(xc, __ffsll((long long)mask) - 1, 64));
+                  else
+                    for (uint32_t c0 = 4u; c0 < 4096u; c0 += 64u) {        // (one draw in ~250 rejects its first four candidates)
+                      const uint32_t c = c0 + (uint32_t)tq;
+                      const U4 r = philox4x32_10(0u, (uint32_t)pp, it32, kStreamS + 16u * c, L.key0, L.key1);
+                      const bool a2 = tn_eval_fast(tf, r.x, r.y, &xc) && c < 4096u;
+                      mask = __ballot(a2);
+                      if (mask) { xnew = tn_guard(__shfl(xc, __ffsll((long long)mask) - 1, 64)); break; }
+                    }
+                }
+              } else {
+                const float mu = numer / tau_p;
+                xnew = fmaxf((tau_p > 0.f && mu > 0.f) ? mu : 0.f, L.min_x);
+              }
+              if (tq == 0) { dl[0] = xnew - sold; Ss[k * kS + l] = xnew; SsT[l * kS + k] = xnew; }
+            }
+            bar_lds();
+            const float delta = dl[0];
+            for (int p2 = tq; p2 < n2; p2 += NT) {
+              const int kk = p2 / Lc, ll = p2 - kk * Lc;
+              rS[p2] = fmaf(-delta * CfT[kk * kS + k], CgT[l * kS + ll], rS[p2]);
+            }
+            dprev = delta * f; lprev = l;
+          }
+        }
+        // the last step's update of q; q goes where the G sweep finds it; S: state, sample, posterior sum
+        if (entry) {
+#pragma unroll
+          for (int e = 0; e < EM; ++e)
+            if (e < em) {
+              float vlast;
+              if constexpr (KEEPV) vlast = sv[e];
+              else vlast = regC[((sj[e >> 1] >> (16 * (e & 1))) & 0xFFFFu) + lprev];
+              *G(d.q + e * kSmallThreads + tq) = fmaf(dprev, vlast, sq[e]);
+            }
+        }
+        {
+          const bool add = L.expS && L.exp_burn >= 0 && it >= L.exp_burn && (it - L.exp_burn) % L.exp_thin == 0;
+          for (int t = tq; t < n2; t += NT) {
+            const int kk = t / Lc, ll = t - kk * Lc;
+            const float v = Ss[kk * kS + ll];
+            *G(L.S + t) = v;
+            if (L.S_s) *G(L.S_s + (size_t)it * n2 + t) = v;
+            if (add) *G(L.expS + t) += (double)v;
+          }
+        }
+        bar_all();
+        STAMP(12);
+      }
     }
 
     // ---- end of the iteration (kernel_misc.hip finish_kernel): SSE from the Gram identities, tau, the three metrics
@@ -654,7 +893,7 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
       block_sum4<NT>(v, red, tf_);
       if (tf_ == 0) {
         double sp1 = 0.0;
-        for (int k = 0; k < K; ++k) sp1 += csum[k] * csum[32 + k];
+        for (int k = 0; k < Lc; ++k) sp1 += csum[k] * csum[32 + k];
         const double srp = v[1], sp = sp1 - v[2], spp = v[0] - v[3];
         const double nobs = L.n_obs;
         const double sse = L.sumR2 - 2.0 * srp + spp;
@@ -691,28 +930,34 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
 #endif
 }
 
-template <int EM, int NT>
+template <int EM, int NT, bool TRI>
 static void launch_small_inst(const SmallLaunch* dev_launches, int n_models, size_t lds_bytes, hipStream_t st) {
   static std::atomic<uint64_t> ok{0};
-  if (allow_full_lds((const void*)small_gibbs_kernel<EM, NT>, ok)) hipLaunchKernelGGL((small_gibbs_kernel<EM, NT>), dim3(n_models), dim3(NT), lds_bytes, st, dev_launches);
+  if (allow_full_lds((const void*)small_gibbs_kernel<EM, NT, TRI>, ok)) hipLaunchKernelGGL((small_gibbs_kernel<EM, NT, TRI>), dim3(n_models), dim3(NT), lds_bytes, st, dev_launches);
 }
-template <int EM>
+template <int EM, bool TRI>
 static void launch_small_em(const SmallLaunch* dev_launches, int n_models, int nt, size_t lds_bytes, hipStream_t st) {
-  if (nt <= 256) launch_small_inst<EM, 256>(dev_launches, n_models, lds_bytes, st);
-  else if (nt <= 512) launch_small_inst<EM, 512>(dev_launches, n_models, lds_bytes, st);
-  else launch_small_inst<EM, 1024>(dev_launches, n_models, lds_bytes, st);
+  if (nt <= 256) launch_small_inst<EM, 256, TRI>(dev_launches, n_models, lds_bytes, st);
+  else if (nt <= 512) launch_small_inst<EM, 512, TRI>(dev_launches, n_models, lds_bytes, st);
+  else launch_small_inst<EM, 1024, TRI>(dev_launches, n_models, lds_bytes, st);
 }
 // em: slots per entry thread (8 / 16 / 32), nt: threads per block (256 / 512 / 1024) -- the largest any model of the batch needs
-void launch_small_gibbs(const SmallLaunch* dev_launches, int n_models, int em, int nt, size_t lds_bytes, hipStream_t st) {
-  if (n_models <= 0) return;
-  if (em <= 8) launch_small_em<8>(dev_launches, n_models, nt, lds_bytes, st);
-  else if (em <= 16) launch_small_em<16>(dev_launches, n_models, nt, lds_bytes, st);
-  else if (em <= 32) launch_small_em<32>(dev_launches, n_models, nt, lds_bytes, st);
+template <bool TRI>
+static void launch_small_kind(const SmallLaunch* dev_launches, int n_models, int em, int nt, size_t lds_bytes, hipStream_t st) {
+  if (em <= 8) launch_small_em<8, TRI>(dev_launches, n_models, nt, lds_bytes, st);
+  else if (em <= 16) launch_small_em<16, TRI>(dev_launches, n_models, nt, lds_bytes, st);
+  else if (em <= 32) launch_small_em<32, TRI>(dev_launches, n_models, nt, lds_bytes, st);
   // (the classes above 32 slots only exist where the 32-slot one needs more than 1024 threads; they gather the previous column's
   // values again instead of keeping them: 40 and 48 slots still fit a 16-wave block's 128 registers per lane, 64 spill)
-  else if (em <= 40) launch_small_inst<40, 1024>(dev_launches, n_models, lds_bytes, st);
-  else if (em <= 48) launch_small_inst<48, 1024>(dev_launches, n_models, lds_bytes, st);
-  else launch_small_inst<64, 1024>(dev_launches, n_models, lds_bytes, st);
+  else if (em <= 40) launch_small_inst<40, 1024, TRI>(dev_launches, n_models, lds_bytes, st);
+  else if (em <= 48) launch_small_inst<48, 1024, TRI>(dev_launches, n_models, lds_bytes, st);
+  else launch_small_inst<64, 1024, TRI>(dev_launches, n_models, lds_bytes, st);
+}
+// tri: every model of the batch is a tri-factorisation (SmallLaunch::L > 0); a batch is of one kind
+void launch_small_gibbs(const SmallLaunch* dev_launches, int n_models, int em, int nt, size_t lds_bytes, hipStream_t st, bool tri) {
+  if (n_models <= 0) return;
+  if (tri) launch_small_kind<true>(dev_launches, n_models, em, nt, lds_bytes, st);
+  else launch_small_kind<false>(dev_launches, n_models, em, nt, lds_bytes, st);
 }
 
 }  // namespace bnmtf

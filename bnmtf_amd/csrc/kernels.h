@@ -420,9 +420,19 @@ struct SmallLaunch {
   unsigned long long* clock;   // [n_iter + 1] wall_clock64 at the start and after every iteration
   float* U_s; float* V_s;      // samples [n_iter][n][K], or null
   double* expR; double* expC; double* exp_tau; int exp_burn, exp_thin;   // posterior sums (bnmtf_set_expectation), or null / -1
+  // tri-factorisation (L > 0; bnmtf_gibbs_optimised.py:138-180): rows = F (I x K), cols = G (J x L), S (K x L) between them.  The F
+  // sweep sees G S^T as its other factor, the G sweep F S (formed in place in LDS), the K L entries of S are updated one after the
+  // other between the two by the whole block (kernel_small.hip, "S step")
+  int L;
+  float* S;                    // [K][L] state
+  const float* lambdaS;        // [K][L] prior rates
+  float* ZT;                   // [32][rows.ldn] R~ G: b = F^T (R~ G) of the S step
+  uint2* stab;                 // [K L][4] Philox words of the first four candidates of every S draw of an iteration
+  float* S_s;                  // samples [n_iter][K][L], or null
+  double* expS;                // posterior sum [K][L], or null
 };
-size_t small_lds_bytes(int I, int J, int nt);  // LDS a block of nt threads needs for an I x J model
-void launch_small_gibbs(const SmallLaunch* dev_launches, int n_models, int em, int nt, size_t lds_bytes, hipStream_t st);
+size_t small_lds_bytes(int I, int J, int nt, int K = 0, int L = 0);  // LDS a block of nt threads needs for an I x J model (K, L: the tri-factorisation's ranks)
+void launch_small_gibbs(const SmallLaunch* dev_launches, int n_models, int em, int nt, size_t lds_bytes, hipStream_t st, bool tri = false);
 
 // small helpers
 void launch_sum_stats(const double* stats, int nblocks, double* acc, hipStream_t st);   // acc[0..2] += column sums of stats

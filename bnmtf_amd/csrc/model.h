@@ -147,7 +147,7 @@ struct bnmtf_model {
   bool std_built = true, small_cur = false, std_cur = false;
   bool pool_stream = false;    // the stream goes back to the per-process pool at destroy (small models)
   bool one_arena = false;      // Rfull, Mtrain, the scalars, the posterior sums and Ad / Bd live in the small model's arena (one allocation per model)
-  std::vector<double> lam_rows, lam_cols;          // prior rates as given (build_standard may run after bnmtf_create has returned)
+  std::vector<double> lam_rows, lam_cols, lam_S;   // prior rates as given (build_standard may run after bnmtf_create has returned)
   // BNMTF extras
   float* S = nullptr;            // [K][L] on device (row major, unpadded)
   bnmtf::Dir reff, ceff;         // effective factors U_eff = F S (I x L), V_eff = G S^T (J x K): factor storage only

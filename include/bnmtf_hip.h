@@ -157,6 +157,18 @@ BNMTF_API int bnmtf_cond_params(bnmtf_handle h, int which, int k, int l, double*
 BNMTF_API int bnmtf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* F_out, float* S_out, float* G_out,
                     double* tau_out, double* perf_out, double* times_out);
 
+/* bnmtf_gibbs_run for n_models independent tri-factorisations at once: the folds and the (K, L) neighbours a greedy model search
+ * fits one after the other (code/cross_validation/greedy_search_cross_validation.py:60-130,
+ * experiments/experiments_gdsc/cross_validation/gibbs_nmtf/greedysearch_xval_gibbs.py:17-60).  Models of the one-launch path
+ * (K, L <= 32, I, J <= 1024, factors within one CU's LDS: kernel_small.hip) that share a device go down in ONE grid, a block per
+ * model -- F sweep, the K L entries of S, G sweep, tau, the metrics of every iteration inside the launch; any other handle is run
+ * by bnmtf_gibbs_run in turn.  Every model draws the chain its own bnmtf_gibbs_run call would draw.  Arrays of n_models pointers
+ * (or NULL), each as in bnmtf_gibbs_run; F_final [I][K], S_final [K][L], G_final [J][L], tau_final [1] (doubles): the state each
+ * model ends with, fetched for the whole batch with one synchronisation. */
+BNMTF_API int bnmtf_gibbs_run_many(const bnmtf_handle* hs, int n_models, int n_iter, int update, float* const* F_outs, float* const* S_outs,
+                         float* const* G_outs, double* const* tau_outs, double* const* perf_outs, double* const* times_outs,
+                         double* const* F_final, double* const* S_final, double* const* G_final, double* const* tau_final);
+
 /* ---- BNMF VB (bnmf_vb_optimised.py) ------------------------------------ */
 /* all eight q-parameter matrices + exptau; any pointer may be NULL (left as is) */
 BNMTF_API int bnmf_vb_set_state(bnmtf_handle h, const double* muU, const double* tauU, const double* expU, const double* varU,
