@@ -424,7 +424,7 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
   int rr = 0;                                // running retry-round number: list rr % 3 is the one being filled / read
   const bool draw = L.update == BNMTF_UPDATE_DRAW;
 #ifdef BNMTF_SMALL_TIMING
-  unsigned long long ph[16] = {0}, cph[6] = {0}, tlast = __builtin_readcyclecounter();
+  unsigned long long ph[20] = {0}, cph[6] = {0}, tlast = __builtin_readcyclecounter();
   int nretry = 0;
 #endif
 
@@ -457,6 +457,7 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
           for (int t = tq; t < n * (32 - Kd); t += NT) { const int u = t / (32 - Kd), k = Kd + t - u * (32 - Kd); regOwn[u * kS + k] = 0.f; }
         // (+ the fp64 Gram and the column sums of F S: the end of the iteration)
         small_gram<NT>(dir == 0 ? regC : regR, m, Kd, gscr, dir == 0 ? CsC : CsR, dir == 0 ? csum + 32 : csum, dir == 0 ? nullptr : c64R, nullptr, tq);
+        STAMP(16);
       }
 
       // ---- the Philox words of the first nc0 candidates of every (unit, column) of this half sweep, by all threads at once
@@ -672,6 +673,7 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
       // ---- the last column's update of q; q goes where the other direction finds it
       if (entry) {
         const float dlt = dl[myunit];
+        double lq = 0.0, lq2 = 0.0;            // (summed here and added once: the iteration's accumulators live through every phase)
 #pragma unroll
         for (int e = 0; e < EM; ++e)
           if (e < em) {
@@ -680,8 +682,9 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
             else vlast = regO[((jj[e >> 1] >> (16 * (e & 1))) & 0xFFFFu) + (Kd - 1)];
             q[e] = fmaf(dlt, vlast, q[e]);
             *G(d.q + e * kSmallThreads + tq) = q[e];
-            if (dir == 1) { st_q += (double)q[e]; st_q2 += (double)q[e] * (double)q[e]; }
+            lq += (double)q[e]; lq2 += (double)q[e] * (double)q[e];
           }
+        if (dir == 1) { st_q += lq; st_q2 += lq2; }
       }
       bar_all();                               // q and the transposed factor: read by other threads in the next half sweeps
       STAMP(10);
@@ -762,17 +765,19 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
           if (pp < n2 && s8 == 0) rS[pp] = (float)(a - (double)rS[pp]);
         }
         // this thread's slots and q again (the sweep's registers are gone; q as the sweep stored it)
+        // (the previous step's G values are gathered again for the deferred update of q, not kept: the registers go to q)
         uint32_t sj[EM / 2];
-        float sq[EM], sv[KEEPV ? EM : 2];
+        float sq[EM];
 #pragma unroll
         for (int h = 0; h < EM / 2; ++h) {
           uint32_t j0 = (uint32_t)(m * kS), j1 = (uint32_t)(m * kS);
           if (entry && 2 * h < em) { j0 = *G(d.idx + (2 * h) * kSmallThreads + tq); j1 = *G(d.idx + (2 * h + 1) * kSmallThreads + tq); }
           sj[h] = j0 | (j1 << 16);
           sq[2 * h] = sq[2 * h + 1] = 0.f;
-          if constexpr (KEEPV) sv[2 * h] = sv[2 * h + 1] = 0.f;
           if (entry && 2 * h < em) { sq[2 * h] = *G(d.q + (2 * h) * kSmallThreads + tq); sq[2 * h + 1] = *G(d.q + (2 * h + 1) * kSmallThreads + tq); }
         }
+        const int kkA = tq / Lc, llA = tq - kkA * Lc;        // the entry of r this thread keeps current
+        STAMP(14);
         float dprev = 0.f;                       // delta of the step before x this thread's F value of that step's row
         int lprev = 0;
         u32x2n scw = {0u, 0u};
@@ -786,26 +791,25 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
 #pragma unroll 1
           for (int l = 0; l < Lc; ++l) {
             const int pp = k * Lc + l;
-            if (entry) {
+            {
               float qg = 0.f, gg = 0.f;
               const float* col = regC + l;
+              const float* colp = regC + lprev;
+              if (entry) {
 #pragma unroll
-              for (int h = 0; h < EM / 2; ++h)
-                if (2 * h < em) {
-                  asm volatile("" : "+v"(sj[h]));
-                  const float g0 = col[sj[h] & 0xFFFFu], g1 = col[sj[h] >> 16];
-                  if constexpr (KEEPV) {
-                    sq[2 * h] = fmaf(dprev, sv[2 * h], sq[2 * h]);
-                    sq[2 * h + 1] = fmaf(dprev, sv[2 * h + 1], sq[2 * h + 1]);
-                    sv[2 * h] = g0; sv[2 * h + 1] = g1;
-                  } else if (pp > 0) {
-                    sq[2 * h] = fmaf(dprev, regC[(sj[h] & 0xFFFFu) + lprev], sq[2 * h]);
-                    sq[2 * h + 1] = fmaf(dprev, regC[(sj[h] >> 16) + lprev], sq[2 * h + 1]);
+                for (int h = 0; h < EM / 2; ++h)
+                  if (2 * h < em) {
+                    asm volatile("" : "+v"(sj[h]));
+                    const float g0 = col[sj[h] & 0xFFFFu], g1 = col[sj[h] >> 16];
+                    sq[2 * h] = fmaf(dprev, colp[sj[h] & 0xFFFFu], sq[2 * h]);          // (dprev = 0 ahead of the first step)
+                    sq[2 * h + 1] = fmaf(dprev, colp[sj[h] >> 16], sq[2 * h + 1]);
+                    qg = fmaf(sq[2 * h], g0, qg); gg = fmaf(g0, g0, gg);
+                    qg = fmaf(sq[2 * h + 1], g1, qg); gg = fmaf(g1, g1, gg);
                   }
-                  qg = fmaf(sq[2 * h], g0, qg); gg = fmaf(g0, g0, gg);
-                  qg = fmaf(sq[2 * h + 1], g1, qg); gg = fmaf(g1, g1, gg);
-                }
-              part[tq] = float2{f * qg, f * f * gg};
+              }
+              // the wave's two sums by DPP (every wave: the ones without entries add zeros), one pair per wave to LDS
+              const float wx = half_swap_sum(half_sum(f * qg)), wy = half_swap_sum(half_sum(f * f * gg));
+              if ((tq & 63) == 0) part[tq >> 6] = float2{wx, wy};
             }
             // wave 0 draws: its candidates' word-only halves and the next step's words ahead of the barrier
             TnCand cand = {0.f, 0.f, 0.f};
@@ -819,10 +823,10 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
             }
             bar_lds();
             if (tq < 64) {
-              float sx = 0.f, sy = 0.f;
-              for (int t = tq; t < d.nthreads; t += 64) { const float2 pt = part[t]; sx += pt.x; sy += pt.y; }
-#pragma unroll
-              for (int mk = 32; mk >= 1; mk >>= 1) { sx += __shfl_xor(sx, mk, 64); sy += __shfl_xor(sy, mk, 64); }
+              // the (at most 16) waves' sums: one 16-lane row, added by DPP in an order that does not depend on the block size
+              const float2 pt = tq < NT / 64 ? part[tq] : float2{0.f, 0.f};
+              const float sx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, dpp_xor_row_sum(pt.x))));
+              const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, dpp_xor_row_sum(pt.y))));
               const float sold = Ss[k * kS + l];
               const float adiag = CfT[k * kS + k] * CgT[l * kS + l] - sy;
               const float tau_p = tau * adiag;
@@ -852,21 +856,21 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
             }
             bar_lds();
             const float delta = dl[0];
-            for (int p2 = tq; p2 < n2; p2 += NT) {
+            if (tq < n2) rS[tq] = fmaf(-delta * CfT[kkA * kS + k], CgT[l * kS + llA], rS[tq]);
+            for (int p2 = tq + NT; p2 < n2; p2 += NT) {          // (more entries than threads: the small blocks with wide factors)
               const int kk = p2 / Lc, ll = p2 - kk * Lc;
               rS[p2] = fmaf(-delta * CfT[kk * kS + k], CgT[l * kS + ll], rS[p2]);
             }
             dprev = delta * f; lprev = l;
           }
         }
+        STAMP(15);
         // the last step's update of q; q goes where the G sweep finds it; S: state, sample, posterior sum
         if (entry) {
 #pragma unroll
           for (int e = 0; e < EM; ++e)
             if (e < em) {
-              float vlast;
-              if constexpr (KEEPV) vlast = sv[e];
-              else vlast = regC[((sj[e >> 1] >> (16 * (e & 1))) & 0xFFFFu) + lprev];
+              const float vlast = regC[((sj[e >> 1] >> (16 * (e & 1))) & 0xFFFFu) + lprev];
               *G(d.q + e * kSmallThreads + tq) = fmaf(dprev, vlast, sq[e]);
             }
         }
@@ -881,7 +885,7 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
           }
         }
         bar_all();
-        STAMP(12);
+        STAMP(17);
       }
     }
 
@@ -921,9 +925,10 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
   }
 #ifdef BNMTF_SMALL_TIMING
   if (blockIdx.x == 0 && (tid == 0 || tid == NT - 64))
-    printf("small kernel thread %d, %d iterations, cycles per iteration: table %llu contract %llu qinit %llu | columns: entry+prefetch %llu bar %llu unit %llu cand %llu pick %llu retry %llu (%d rounds) fixup %llu | qstore %llu gram %llu copy %llu finish %llu\n",
+    printf("small kernel thread %d, %d iterations, cycles per iteration: table %llu contract %llu qinit %llu | columns: entry+prefetch %llu bar %llu unit %llu cand %llu pick %llu retry %llu (%d rounds) fixup %llu | qstore %llu gram %llu copy %llu finish %llu | tri: effective factor + Gram %llu S setup %llu S steps %llu S tail %llu\n",
            tid, L.n_iter, ph[0] / L.n_iter, ph[1] / L.n_iter, ph[2] / L.n_iter, ph[3] / L.n_iter, ph[4] / L.n_iter, ph[5] / L.n_iter, ph[6] / L.n_iter, ph[7] / L.n_iter,
-           ph[8] / L.n_iter, nretry, ph[9] / L.n_iter, ph[10] / L.n_iter, ph[11] / L.n_iter, ph[12] / L.n_iter, ph[13] / L.n_iter);
+           ph[8] / L.n_iter, nretry, ph[9] / L.n_iter, ph[10] / L.n_iter, ph[11] / L.n_iter, ph[12] / L.n_iter, ph[13] / L.n_iter,
+           ph[16] / L.n_iter, ph[14] / L.n_iter, ph[15] / L.n_iter, ph[17] / L.n_iter);
   if (blockIdx.x == 0 && (tid & 63) == 0)
     printf("   wave %2d contraction per iteration: rows loop %llu epilogue %llu (%llu items) | cols loop %llu epilogue %llu (%llu items)\n", tid >> 6,
            cph[0] / L.n_iter, cph[1] / L.n_iter, cph[2] / L.n_iter, cph[3] / L.n_iter, cph[4] / L.n_iter, cph[5] / L.n_iter);
