@@ -357,8 +357,8 @@ def main_cv(a, w):
 def main_cv3(a, w):
     """The reference's model-selection job for the tri-factorisation (greedysearch_xval_gibbs.py): per fold a greedy walk over
     (K, L) by AIC -- every step fits the one to three neighbouring models --, then the folds' final models, through
-    GreedySearchCrossValidation on one GPU with s replica slots.  The tri-factorisation has no one-launch kernel: every model
-    runs on the multi-launch path (>= 15 launches per iteration); the slots overlap the models of a step and the final fits."""
+    GreedySearchCrossValidation on one GPU: with s replica slots (processes; each model a call of its own), and with one batched
+    slot ("1b": the steps the ten folds have open at the same time are ONE device call, a block per model -- kernel_small.hip)."""
     import tempfile
     import bnmtf_amd
     from bnmtf_amd.cross_validation.greedy_search_cross_validation import GreedySearchCrossValidation
@@ -368,9 +368,9 @@ def main_cv3(a, w):
     its = a.steps if a.steps_given else w["iterations"]
     burn, thin = (w["burn_in"], w["thinning"]) if its == w["iterations"] else (its // 2, 2)
     res = {}
-    for s in a.slots:
+    for s, batched in [(s, False) for s in a.slots] + [(1, True)] + [(s, True) for s in a.slots if s > 1]:
         random.seed(0); np.random.seed(0)
-        pool = ReplicaPool(devices=[0] * s, shared={"R": np.asarray(R, dtype=float)})
+        pool = ReplicaPool(devices=[0] * s, shared={"R": np.asarray(R, dtype=float)}, batched=batched)
         fits = [0]
         pmap = pool.map
 
@@ -385,13 +385,13 @@ def main_cv3(a, w):
             pmap(_warm, [{} for _ in range(s)])
             t0 = time.perf_counter(); cv.run(burn_in=burn, thinning=thin); dt = time.perf_counter() - t0
         pool.close()
-        res[str(s)] = {"slots": s, "seconds": dt, "models": fits[0], "model_iterations_per_s": fits[0] * its / dt,
-                       "heldout_MSE": cv.average_performance["MSE"], "heldout_R2": cv.average_performance["R^2"]}
+        res[str(s) + ("b" if batched else "")] = {"slots": s, "batched": batched, "seconds": dt, "models": fits[0], "model_iterations_per_s": fits[0] * its / dt,
+                                                  "heldout_MSE": cv.average_performance["MSE"], "heldout_R2": cv.average_performance["R^2"]}
     best = max(res.values(), key=lambda r: r["model_iterations_per_s"])
     out = {"metric": "model-iterations/sec of the GDSC-shaped 10-fold greedy-search cross-validation (BNMTF Gibbs 622x138, K, L in 5..10, %d iterations)" % its,
            "value": best["model_iterations_per_s"], "unit": "model-iterations/s", "n_gpus": 1, "steps": its, "warmup": 0, "ms_per_step": 1e3 * best["seconds"] / its,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (GDSC's shape and observed fraction, planted K = L = %d)" % w["K"],
-           "config": {"workload": "GreedySearchCrossValidation, %d folds x greedy walk over K in %s, L in %s x %d iterations (burn-in %d, thinning %d, k-means initialisation of F and G) + %d final models; ReplicaPool slots on one GPU: %s" % (
+           "config": {"workload": "GreedySearchCrossValidation, %d folds x greedy walk over K in %s, L in %s x %d iterations (burn-in %d, thinning %d, k-means initialisation of F and G) + %d final models; ReplicaPool slots on one GPU: %s, and one batched slot (\"1b\")" % (
                w["folds"], w["values_K"], w["values_L"], its, burn, thin, w["folds"], a.slots), "source": w["source"]},
            "published_on_the_real_data": w["published"], "by_slots": res, "roofline": None, "cpu_baseline": None}
     print(json.dumps(out)); sys.stdout.flush()

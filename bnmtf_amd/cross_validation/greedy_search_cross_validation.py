@@ -44,11 +44,19 @@ class GreedySearchCrossValidation(object):
         pool = self.pool or ReplicaPool(devices=[0], shared={"R": self.R})
         pool.shared.setdefault("R", self.R)
         try:
+            side_by_side = self.seed is not None and (len(getattr(pool, "devices", [])) > 1 or getattr(pool, "batched", False))
+            # (a batched pool: the steps the folds have open at the same time go to the device as one call, a block per model)
+            walk_pool = pool.joint(self.folds) if side_by_side and getattr(pool, "batched", False) else pool
+
             def fold_search(fi):
-                search = GreedySearch(classifier=self.classifier, values_K=self.values_K, values_L=self.values_L, R=self.R, M=self.M,
-                                      priors=self.priors, initS=self.init_S, initFG=self.init_FG, iterations=self.iterations, restarts=self.restarts,
-                                      pool=pool, seed=None if self.seed is None else self.seed + 104729 * fi)
-                search.search(self.quality_metric, burn_in=burn_in, thinning=thinning, minimum_TN=minimum_TN)
+                try:
+                    search = GreedySearch(classifier=self.classifier, values_K=self.values_K, values_L=self.values_L, R=self.R, M=self.M,
+                                          priors=self.priors, initS=self.init_S, initFG=self.init_FG, iterations=self.iterations, restarts=self.restarts,
+                                          pool=walk_pool, seed=None if self.seed is None else self.seed + 104729 * fi)
+                    search.search(self.quality_metric, burn_in=burn_in, thinning=thinning, minimum_TN=minimum_TN)
+                finally:
+                    if walk_pool is not pool:
+                        walk_pool.leave()
                 best = search.best_value(metric=self.quality_metric)
                 # (written below, fold by fold, each followed by its Performance line: the reference's order, greedy_search_cross_validation.py:68-100)
                 return best, ("All model fits for fold %s, metric %s: %s.\n" % (fi + 1, self.quality_metric, search.all_values(metric=self.quality_metric))
@@ -57,7 +65,7 @@ class GreedySearchCrossValidation(object):
             # several replica slots and seeded candidates (every fit then draws from its own stream, whatever runs beside it) the
             # walks advance side by side, each from a thread of its own that hands its steps to the shared pool.  Unseeded, the
             # candidates draw from the workers' global streams in the order they run: fold by fold, as the reference.
-            if self.seed is not None and len(getattr(pool, "devices", [])) > 1 and not getattr(pool, "batched", False):
+            if side_by_side:
                 from concurrent.futures import ThreadPoolExecutor
                 with ThreadPoolExecutor(max_workers=self.folds) as ex:
                     done = list(ex.map(fold_search, range(self.folds)))

@@ -112,6 +112,13 @@ class ReplicaPool(object):
                 out[i] = r
         return out
 
+    def joint(self, participants):
+        """A view of this pool for `participants` threads that each walk a chain of dependent map() calls (the folds of a
+        greedy-search cross-validation): the calls the threads have open at the same time are run as ONE map() of this pool --
+        on a batched pool one device call, a block per model -- and every thread gets its own jobs' results.  A thread that has
+        no further call says so with .leave()."""
+        return _Joint(self, participants)
+
     def close(self):
         if self._pool is not None:
             self._pool.close(); self._pool.join()
@@ -122,6 +129,57 @@ class ReplicaPool(object):
 
     def __exit__(self, *a):
         self.close()
+
+
+class _Joint(object):
+    def __init__(self, pool, participants):
+        self.pool, self.active = pool, int(participants)
+        self.shared, self.devices, self.batched = pool.shared, pool.devices, pool.batched
+        self._cv = threading.Condition()
+        self._open = []                     # [fn, jobs, results] of the calls waiting for the others
+
+    def map(self, fn, jobs, errors="raise"):
+        call = [fn, list(jobs), None]
+        with self._cv:
+            self._open.append(call)
+            if len(self._open) >= self.active:
+                self._run()
+            while call[2] is None:
+                self._cv.wait()
+        out = call[2]
+        if isinstance(out, BaseException):
+            raise out
+        errs = [r for r in out if isinstance(r, ReplicaError)]
+        if errs and errors == "raise":
+            raise RuntimeError("%d of %d replica jobs failed; first:\n%s" % (len(errs), len(out), errs[0]))
+        return out
+
+    def leave(self):
+        with self._cv:
+            self.active -= 1
+            if self._open and len(self._open) >= self.active:
+                self._run()
+
+    def _run(self):
+        """(called with the lock held: everybody else is waiting for this very call)"""
+        calls, self._open = self._open, []
+        try:
+            by_fn = {}
+            for c in calls:
+                by_fn.setdefault(c[0], []).append(c)
+            for fn, cs in by_fn.items():
+                res = self.pool.map(fn, [j for c in cs for j in c[1]], errors="return")
+                at = 0
+                for c in cs:
+                    c[2] = res[at:at + len(c[1])]; at += len(c[1])
+        except BaseException as e:          # noqa: BLE001 -- handed to every waiting caller
+            for c in calls:
+                if c[2] is None:
+                    c[2] = e
+        self._cv.notify_all()
+
+    def close(self):
+        pass
 
 
 def _call_batch(jobs):

@@ -237,3 +237,48 @@ def test_run_many_takes_gibbs_models_only():
     with pytest.raises(TypeError):
         run_many([nmf_icm(R, M, 2, pri)], 3)
     assert run_many([], 3) == []
+
+
+def test_joint_map_merges_the_calls_the_threads_have_open():
+    """ReplicaPool.joint: the map() calls of the participating threads that are open at the same time reach the pool as ONE map();
+    a thread that is done leaves; results go back to their callers in their own order."""
+    import threading
+    from bnmtf_amd.cross_validation.replicas import ReplicaPool, _Joint
+
+    class Recorder(object):
+        shared, devices, batched = {}, [0], True
+        def __init__(self):
+            self.calls = []
+        def map(self, fn, jobs, errors="raise"):
+            self.calls.append(len(jobs))
+            return [fn(j, None) for j in jobs]
+
+    rec = Recorder()
+    joint = _Joint(rec, 3)
+    out = {}
+    def walker(name, steps):
+        try:
+            res = []
+            for s in range(steps):
+                res.append(joint.map(lambda j, _: (name, j), [10 * s + i for i in range(name + 1)]))
+            out[name] = res
+        finally:
+            joint.leave()
+    ts = [threading.Thread(target=walker, args=(n, st)) for n, st in ((0, 1), (1, 3), (2, 2))]
+    for t in ts: t.start()
+    for t in ts: t.join(timeout=30)
+    assert not any(t.is_alive() for t in ts)
+    # (the one lambda per call is its own fn: the recorder sees one map per fn and round -- 3 + 2 + 1 calls of 1..3 jobs)
+    assert sorted(rec.calls) == sorted([1, 2, 3, 2, 3, 2])
+    assert out[1] == [[(1, 0), (1, 1)], [(1, 10), (1, 11)], [(1, 20), (1, 21)]] and out[0] == [[(0, 0)]]
+    # with one shared fn the open calls are one map
+    rec2 = Recorder(); joint2 = _Joint(rec2, 2)
+    f = lambda j, _: j * 2
+    got = {}
+    def w2(name):
+        got[name] = joint2.map(f, [name, name + 1]); joint2.leave()
+    ts = [threading.Thread(target=w2, args=(n,)) for n in (1, 5)]
+    for t in ts: t.start()
+    for t in ts: t.join(timeout=30)
+    assert rec2.calls == [4] and got == {1: [2, 4], 5: [10, 12]}
+    assert isinstance(ReplicaPool(devices=[0]).joint(2), _Joint)

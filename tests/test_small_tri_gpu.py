@@ -177,3 +177,28 @@ def test_switching_paths_mid_chain_keeps_the_state():
     assert np.isfinite(b.all_performances['MSE']).all() and b.all_performances['MSE'][-1] < 2.0 * np.var(R)
     p = b.predict_while_running()
     assert abs(p["MSE"] - b.all_performances['MSE'][-1]) < 1e-4 * p["MSE"]
+
+
+def test_batched_greedy_search_cross_validation_gives_the_unbatched_results(tmp_path):
+    """The folds' walks side by side on a batched pool: the steps they have open together are one device call (a block per model),
+    and every model is the chain its own run() draws -- the same held-out performances, to the bit."""
+    from bnmtf_amd.cross_validation.greedy_search_cross_validation import GreedySearchCrossValidation
+    from bnmtf_amd.cross_validation.replicas import ReplicaPool
+    import random
+    R, M, _, _, _ = generate_bnmtf(40, 30, 3, 2, 0.1, seed_data=3, seed_mask=4)
+    perf = []
+    for batched in (False, True):
+        random.seed(0); np.random.seed(0)
+        pool = ReplicaPool(devices=[0], shared={"R": R}, batched=batched)
+        calls = []
+        pmap = pool.map
+        pool.map = lambda fn, jobs, *a, **k: (calls.append(len(list(jobs))), pmap(fn, jobs, *a, **k))[1]
+        cv = GreedySearchCrossValidation(classifier=bnmtf_gibbs_optimised, R=R, M=M, values_K=[2, 3, 4], values_L=[2, 3], folds=3, priors=PRI,
+                                         init_S="random", init_FG="kmeans", iterations=40, restarts=1, quality_metric="AIC",
+                                         file_performance=str(tmp_path / ("perf%d.txt" % batched)), pool=pool, seed=7)
+        cv.run(burn_in=20, thinning=2)
+        pool.close()
+        perf.append(cv.performances)
+        if batched:
+            assert calls[0] == 3 and max(calls) >= 6, calls        # the three folds' first models in one call, their steps of up to three models together
+    assert perf[0] == perf[1]
