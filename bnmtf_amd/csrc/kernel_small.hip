@@ -29,6 +29,7 @@
 //  * Gram matrices in fp64 on v_mfma_f64_16x16x4_f64 from the LDS copy; masked SSE / MSE / R^2 / Rp from the Gram
 //    identities (kernel_misc.hip finish_kernel: same formulas), tau from the host-staged Gamma variate.
 #include <algorithm>
+#include <type_traits>
 
 #include "../../include/bnmtf_hip.h"
 #include "kernels.h"
@@ -78,13 +79,30 @@ template <int NT> struct Misc {
   static constexpr int gram_waves = NT / 256;
   static_assert(gram_waves * 3 * 256 * 2 + 8 * 32 * 2 <= floats - part, "the Gram scratch re-uses the sweep's exchange area");
   static_assert(red % 2 == 0 && c64 % 2 == 0 && part % 2 == 0, "doubles are 8-byte aligned");
+  static_assert(8 * NT <= floats - part, "the tri-factorisation's packed second moments go through the exchange area eight at a time");
 };
 
 // (tri-factorisation, L > 0: behind the two Gram copies the Gram of F [K rows], the Gram of G [L rows], S [K rows] and S^T [L rows])
 __host__ __device__ inline int small_tri_floats(int K, int L) { return L > 0 ? (2 * K + 2 * L) * kS : 0; }
+// The S step's dense form (the K L x K L system in LDS, the chain on one wave) for the ranks the reference searches (K, L <= 10:
+// 55 packed second moments per unit fit a thread's registers, the system is <= 100 x 100).  Its system and the packed products
+// take the F region's place while the chain runs (F comes back from global memory) -- or, when that region is too small, space
+// of their own behind the exchange arrays.
+constexpr int kTriDenseK = 10, kTriPairs = kTriDenseK * (kTriDenseK + 1) / 2;
+__host__ __device__ inline bool small_tri_dense(int K, int L) { return L > 0 && K <= kTriDenseK && L <= kTriDenseK; }
+__host__ __device__ inline int small_tri_dense_floats(int K, int L) { return ((K * L * K * L + 3) & ~3) + 64 * 64; }
+__host__ __device__ inline bool small_tri_dense_overlays(int I, int K, int L) { return (I + 1) * kS >= small_tri_dense_floats(K, L); }
+__host__ __device__ inline int tri_pair_index(int a, int b) { return a * kTriDenseK - a * (a - 1) / 2 + (b - a); }      // a <= b < 10
+__device__ __forceinline__ void tri_pair(int p, int& a, int& b) {
+  int k = 0, st = 0;
+#pragma unroll
+  for (int t = 0; t < kTriDenseK - 1; ++t) { const int nxt = st + (kTriDenseK - k); if (p >= nxt) { st = nxt; ++k; } }
+  a = k; b = k + (p - st);
+}
 __host__ __device__ inline int small_misc_offset(int I, int J, int K = 0, int L = 0) { return ((I + 1) * kS + (J + 1) * kS + 2 * 32 * kS + small_tri_floats(K, L) + 3) & ~3; }
 size_t small_lds_bytes(int I, int J, int nt, int K, int L) {
-  return sizeof(float) * (size_t)(small_misc_offset(I, J, K, L) + (nt <= 256 ? Misc<256>::floats : (nt <= 512 ? Misc<512>::floats : Misc<1024>::floats)));
+  const int extra = (small_tri_dense(K, L) && !small_tri_dense_overlays(I, K, L)) ? small_tri_dense_floats(K, L) : 0;
+  return sizeof(float) * (size_t)(small_misc_offset(I, J, K, L) + (nt <= 256 ? Misc<256>::floats : (nt <= 512 ? Misc<512>::floats : Misc<1024>::floats)) + extra);
 }
 
 // sum of four doubles over the block, in a fixed order (wave: xor butterfly; block: wave 0 .. 15); every thread gets the sums
@@ -382,6 +400,7 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
   const int tid = threadIdx.x;
   const int I = L.rows.n, J = L.cols.n, K = L.K;
   const int Lc = TRI ? L.L : K;            // width of the cols factor (tri-factorisation: G is J x L)
+  const bool tri_dense = TRI && small_tri_dense(K, Lc);
   float* regR = lds;
   float* regC = regR + (I + 1) * kS;
   float* CsR = regC + (J + 1) * kS;
@@ -424,7 +443,7 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
   int rr = 0;                                // running retry-round number: list rr % 3 is the one being filled / read
   const bool draw = L.update == BNMTF_UPDATE_DRAW;
 #ifdef BNMTF_SMALL_TIMING
-  unsigned long long ph[20] = {0}, cph[6] = {0}, tlast = __builtin_readcyclecounter();
+  unsigned long long ph[24] = {0}, cph[6] = {0}, tlast = __builtin_readcyclecounter();
   int nretry = 0;
 #endif
 
@@ -483,7 +502,19 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
         ca.big = d.big; ca.XT = d.XT; ca.lambda = d.lambda; ca.PT = dir == 1 ? L.PT : nullptr;
         ca.n = n; ca.m = m; ca.ldb = d.ldb; ca.ldn = d.ldn; ca.K = Kd; ca.tau = tau;
         ca.regO_b = (uint32_t)(uintptr_t)(lds_fp)regO; ca.CsO_b = (uint32_t)(uintptr_t)(lds_fp)CsO; ca.regOwn_b = (uint32_t)(uintptr_t)(lds_fp)regOwn;
-        if (((n + 63) / 64) * kt >= NT / 64) small_contract<4, NT>(ca, tq);
+        if (TRI && dir == 1) {
+          // the tri-factorisation's G sweep: R~^T (F S) = (R~^T F) S from the S step's pass over R~ (Pv: L.ZT [K][ldn]); the own
+          // factor's old values from its transposed copy (this loop overwrites the region)
+          for (int o = tq; o < n * Kd; o += NT) {
+            const int j = o / Kd, l = o - j * Kd;
+            float pv = 0.f, kk = 0.f;
+            for (int k2 = 0; k2 < K; ++k2) pv = fmaf(*G(L.ZT + (size_t)k2 * d.ldn + j), SsT[l * kS + k2], pv);
+            for (int l2 = 0; l2 < Kd; ++l2) kk = fmaf(*G(d.XT + (size_t)l2 * d.ldn + j), CsO[l2 * kS + l], kk);
+            regOwn[j * kS + l] = fmaf(tau, pv - kk, -*G(d.lambda + j * 32 + l));
+            *G(L.PT + (size_t)l * d.ldn + j) = pv;
+          }
+        }
+        else if (((n + 63) / 64) * kt >= NT / 64) small_contract<4, NT>(ca, tq);
         else if (((n + 31) / 32) * kt >= NT / 128) small_contract<2, NT>(ca, tq);
         else small_contract<1, NT>(ca, tq);
       }
@@ -506,7 +537,8 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
         q[2 * h] = q[2 * h + 1] = 0.f;
         if constexpr (KEEPV) vp[2 * h] = vp[2 * h + 1] = 0.f;
       }
-      const bool prepass = dir == 0 && (it_abs % L.refresh == 0 || (it == 0 && !L.q_valid));
+      // (the dense S step does not carry q: the G sweep behind it forms q from F S and G)
+      const bool prepass = (dir == 0 && (it_abs % L.refresh == 0 || (it == 0 && !L.q_valid))) || (dir == 1 && tri_dense);
       if (prepass) {
         if (entry)
           for (int k = 0; k < Kd; ++k) {
@@ -723,12 +755,12 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
         float* rS = reinterpret_cast<float*>(c64R);          // [K L] (the fp64 Gram's area is free until the G sweep's effective factor is formed)
         float* tmpS = rS + 1024;
         for (int t = tq; t < J * kS; t += NT) { const int u = t / kS, k = t - u * kS; regC[t] = k < Lc ? *G(L.cols.X + u * 32 + k) : 0.f; }     // G back into its region
-        if (draw)
+        if (draw && !tri_dense)                    // (the dense form keeps its candidates in LDS)
           for (int e = tq; e < n2 * 4; e += NT) {
             const U4 r = philox4x32_10(0u, (uint32_t)(e >> 2), it32, kStreamS + 16u * (uint32_t)(e & 3), L.key0, L.key1);
             *G(reinterpret_cast<u32x2n*>(L.stab) + e) = u32x2n{r.x, r.y};
           }
-        for (int pp = tq; pp < n2; pp += NT) {               // T = S Cg
+        for (int pp = tq; pp < n2 && !tri_dense; pp += NT) {               // T = S Cg
           const int kk = pp / Lc, ll = pp - kk * Lc;
           float a = 0.f;
           for (int l2 = 0; l2 < Lc; ++l2) a = fmaf(Ss[kk * kS + l2], CgT[l2 * kS + ll], a);
@@ -736,143 +768,352 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
         }
         bar_lds();
         {
-          const int kt = (Lc + 15) >> 4;
+          const int kt = (K + 15) >> 4;
           ContractArgs ca;
 #ifdef BNMTF_SMALL_TIMING
           ca.cph = cph;
 #endif
-          ca.big = d.big; ca.XT = d.XT; ca.lambda = d.lambda; ca.PT = L.ZT;
-          ca.n = n; ca.m = m; ca.ldb = d.ldb; ca.ldn = d.ldn; ca.K = Lc; ca.tau = tau; ca.raw = true;
-          ca.regO_b = (uint32_t)(uintptr_t)(lds_fp)regC; ca.CsO_b = (uint32_t)(uintptr_t)(lds_fp)CsC; ca.regOwn_b = (uint32_t)(uintptr_t)(lds_fp)regR;
+          // Pv = R~^T F (J x K): b = Pv^T G here, and R~^T (F S) = Pv S for the G sweep -- its pass over R~ is this one
+          const SmallDirDev& dc = L.cols;
+          ca.big = dc.big; ca.XT = dc.XT; ca.lambda = dc.lambda; ca.PT = L.ZT;
+          ca.n = dc.n; ca.m = dc.m; ca.ldb = dc.ldb; ca.ldn = dc.ldn; ca.K = K; ca.tau = tau; ca.raw = true;
+          ca.regO_b = (uint32_t)(uintptr_t)(lds_fp)regR; ca.CsO_b = (uint32_t)(uintptr_t)(lds_fp)CsC; ca.regOwn_b = (uint32_t)(uintptr_t)(lds_fp)regC;
           (void)kt;
           small_contract<2, NT>(ca, tq);           // (one shape for this product: a third of the sweep's)
         }
         for (int pp = tq; pp < n2; pp += NT) {               // Cf T
           const int kk = pp / Lc, ll = pp - kk * Lc;
           float a = 0.f;
-          for (int k2 = 0; k2 < K; ++k2) a = fmaf(CfT[kk * kS + k2], tmpS[k2 * Lc + ll], a);
-          rS[pp] = a;
+          for (int k2 = 0; k2 < K && !tri_dense; ++k2) a = fmaf(CfT[kk * kS + k2], tmpS[k2 * Lc + ll], a);
+          rS[pp] = a;                            // (dense: 0 -- r = b - A S follows when A is there)
         }
         bar_all();                               // (Z is read by other threads than the ones that stored it)
-        for (int p0 = 0; p0 < n2; p0 += NT / 8) {                // r = F^T Z - Cf S Cg: eight threads per entry, fp64 sums
+        for (int p0 = 0; p0 < n2; p0 += NT / 8) {                // r = Pv^T G - Cf S Cg: eight threads per entry, fp64 sums
           const int pp = p0 + (tq >> 3), s8 = tq & 7;
           double a = 0.0;
           if (pp < n2) {
             const int kk = pp / Lc, ll = pp - kk * Lc;
-            for (int i = s8; i < I; i += 8) a += (double)regR[i * kS + kk] * (double)*G(L.ZT + (size_t)ll * d.ldn + i);
+            const int ldc = L.cols.ldn;
+            for (int j0 = s8; j0 < J; j0 += 64) {          // (eight of Pv's values on their way from L2 at a time)
+              float zv[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) zv[u] = *G(L.ZT + (size_t)kk * ldc + min(j0 + 8 * u, J - 1));
+#pragma unroll
+              for (int u = 0; u < 8; ++u) if (j0 + 8 * u < J) a += (double)regC[(j0 + 8 * u) * kS + ll] * (double)zv[u];
+            }
           }
           a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
           if (pp < n2 && s8 == 0) rS[pp] = (float)(a - (double)rS[pp]);
         }
-        // this thread's slots and q again (the sweep's registers are gone; q as the sweep stored it)
-        // (the previous step's G values are gathered again for the deferred update of q, not kept: the registers go to q)
-        uint32_t sj[EM / 2];
-        float sq[EM];
+        STAMP(18);
+        if (!tri_dense) {
+          // this thread's slots and q again (the sweep's registers are gone; q as the sweep stored it)
+          // (the previous step's G values are gathered again for the deferred update of q, not kept: the registers go to q)
+          uint32_t sj[EM / 2];
+          float sq[EM];
 #pragma unroll
-        for (int h = 0; h < EM / 2; ++h) {
-          uint32_t j0 = (uint32_t)(m * kS), j1 = (uint32_t)(m * kS);
-          if (entry && 2 * h < em) { j0 = *G(d.idx + (2 * h) * kSmallThreads + tq); j1 = *G(d.idx + (2 * h + 1) * kSmallThreads + tq); }
-          sj[h] = j0 | (j1 << 16);
-          sq[2 * h] = sq[2 * h + 1] = 0.f;
-          if (entry && 2 * h < em) { sq[2 * h] = *G(d.q + (2 * h) * kSmallThreads + tq); sq[2 * h + 1] = *G(d.q + (2 * h + 1) * kSmallThreads + tq); }
-        }
-        const int kkA = tq / Lc, llA = tq - kkA * Lc;        // the entry of r this thread keeps current
-        STAMP(14);
-        float dprev = 0.f;                       // delta of the step before x this thread's F value of that step's row
-        int lprev = 0;
-        u32x2n scw = {0u, 0u};
-        const u32x2n* stab = reinterpret_cast<const u32x2n*>(L.stab);
-        bar_all();                               // (rS, the candidate words)
-        if (draw && tq < 4) scw = *G(stab + tq);
-        float lam_n = tq < 64 ? *G(L.lambdaS) : 0.f;
+          for (int h = 0; h < EM / 2; ++h) {
+            uint32_t j0 = (uint32_t)(m * kS), j1 = (uint32_t)(m * kS);
+            if (entry && 2 * h < em) { j0 = *G(d.idx + (2 * h) * kSmallThreads + tq); j1 = *G(d.idx + (2 * h + 1) * kSmallThreads + tq); }
+            sj[h] = j0 | (j1 << 16);
+            sq[2 * h] = sq[2 * h + 1] = 0.f;
+            if (entry && 2 * h < em) { sq[2 * h] = *G(d.q + (2 * h) * kSmallThreads + tq); sq[2 * h + 1] = *G(d.q + (2 * h + 1) * kSmallThreads + tq); }
+          }
+          const int kkA = tq / Lc, llA = tq - kkA * Lc;        // the entry of r this thread keeps current
+          STAMP(14);
+          float dprev = 0.f;                       // delta of the step before x this thread's F value of that step's row
+          int lprev = 0;
+          u32x2n scw = {0u, 0u};
+          const u32x2n* stab = reinterpret_cast<const u32x2n*>(L.stab);
+          bar_all();                               // (rS, the candidate words)
+          if (draw && tq < 4) scw = *G(stab + tq);
+          float lam_n = tq < 64 ? *G(L.lambdaS) : 0.f;
 #pragma unroll 1
-        for (int k = 0; k < K; ++k) {
-          const float f = entry ? regR[myunit * kS + k] : 0.f;
+          for (int k = 0; k < K; ++k) {
+            const float f = entry ? regR[myunit * kS + k] : 0.f;
 #pragma unroll 1
-          for (int l = 0; l < Lc; ++l) {
-            const int pp = k * Lc + l;
-            {
-              float qg = 0.f, gg = 0.f;
-              const float* col = regC + l;
-              const float* colp = regC + lprev;
-              if (entry) {
+            for (int l = 0; l < Lc; ++l) {
+              const int pp = k * Lc + l;
+              {
+                float qg = 0.f, gg = 0.f;
+                const float* col = regC + l;
+                const float* colp = regC + lprev;
+                if (entry) {
 #pragma unroll
-                for (int h = 0; h < EM / 2; ++h)
-                  if (2 * h < em) {
-                    asm volatile("" : "+v"(sj[h]));
-                    const float g0 = col[sj[h] & 0xFFFFu], g1 = col[sj[h] >> 16];
-                    sq[2 * h] = fmaf(dprev, colp[sj[h] & 0xFFFFu], sq[2 * h]);          // (dprev = 0 ahead of the first step)
-                    sq[2 * h + 1] = fmaf(dprev, colp[sj[h] >> 16], sq[2 * h + 1]);
-                    qg = fmaf(sq[2 * h], g0, qg); gg = fmaf(g0, g0, gg);
-                    qg = fmaf(sq[2 * h + 1], g1, qg); gg = fmaf(g1, g1, gg);
-                  }
-              }
-              // the wave's two sums by DPP (every wave: the ones without entries add zeros), one pair per wave to LDS
-              const float wx = half_swap_sum(half_sum(f * qg)), wy = half_swap_sum(half_sum(f * f * gg));
-              if ((tq & 63) == 0) part[tq >> 6] = float2{wx, wy};
-            }
-            // wave 0 draws: its candidates' word-only halves and the next step's words ahead of the barrier
-            TnCand cand = {0.f, 0.f, 0.f};
-            const float lamS = lam_n;
-            if (tq < 64) {
-              if (draw && tq < 4) cand = tn_cand_pre(scw.x, scw.y);
-              if (pp + 1 < n2) {
-                if (draw && tq < 4) scw = *G(stab + (size_t)(pp + 1) * 4 + tq);
-                lam_n = *G(L.lambdaS + pp + 1);
-              }
-            }
-            bar_lds();
-            if (tq < 64) {
-              // the (at most 16) waves' sums: one 16-lane row, added by DPP in an order that does not depend on the block size
-              const float2 pt = tq < NT / 64 ? part[tq] : float2{0.f, 0.f};
-              const float sx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, dpp_xor_row_sum(pt.x))));
-              const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, dpp_xor_row_sum(pt.y))));
-              const float sold = Ss[k * kS + l];
-              const float adiag = CfT[k * kS + k] * CgT[l * kS + l] - sy;
-              const float tau_p = tau * adiag;
-              const float numer = fmaf(tau, rS[pp] + sx + sold * adiag, -lamS);
-              float xnew = 0.f;
-              if (draw) {
-                const TnFast tf = tn_fast_params(numer, tau_p);
-                float xc = 0.f;
-                const bool acc = tq < 4 && tn_cand_post(tf, cand, &xc);
-                unsigned long long mask = __ballot(acc);
-                if (tf.live) {
-                  if (mask) xnew = tn_guard(__shfl(xc, __ffsll((long long)mask) - 1, 64));
-                  else
-                    for (uint32_t c0 = 4u; c0 < 4096u; c0 += 64u) {        // (one draw in ~250 rejects its first four candidates)
-                      const uint32_t c = c0 + (uint32_t)tq;
-                      const U4 r = philox4x32_10(0u, (uint32_t)pp, it32, kStreamS + 16u * c, L.key0, L.key1);
-                      const bool a2 = tn_eval_fast(tf, r.x, r.y, &xc) && c < 4096u;
-                      mask = __ballot(a2);
-                      if (mask) { xnew = tn_guard(__shfl(xc, __ffsll((long long)mask) - 1, 64)); break; }
+                  for (int h = 0; h < EM / 2; ++h)
+                    if (2 * h < em) {
+                      asm volatile("" : "+v"(sj[h]));
+                      const float g0 = col[sj[h] & 0xFFFFu], g1 = col[sj[h] >> 16];
+                      sq[2 * h] = fmaf(dprev, colp[sj[h] & 0xFFFFu], sq[2 * h]);          // (dprev = 0 ahead of the first step)
+                      sq[2 * h + 1] = fmaf(dprev, colp[sj[h] >> 16], sq[2 * h + 1]);
+                      qg = fmaf(sq[2 * h], g0, qg); gg = fmaf(g0, g0, gg);
+                      qg = fmaf(sq[2 * h + 1], g1, qg); gg = fmaf(g1, g1, gg);
                     }
                 }
+                // the wave's two sums by DPP (every wave: the ones without entries add zeros), one pair per wave to LDS
+                const float wx = half_swap_sum(half_sum(f * qg)), wy = half_swap_sum(half_sum(f * f * gg));
+                if ((tq & 63) == 0) part[tq >> 6] = float2{wx, wy};
+              }
+              // wave 0 draws: its candidates' word-only halves and the next step's words ahead of the barrier
+              TnCand cand = {0.f, 0.f, 0.f};
+              const float lamS = lam_n;
+              if (tq < 64) {
+                if (draw && tq < 4) cand = tn_cand_pre(scw.x, scw.y);
+                if (pp + 1 < n2) {
+                  if (draw && tq < 4) scw = *G(stab + (size_t)(pp + 1) * 4 + tq);
+                  lam_n = *G(L.lambdaS + pp + 1);
+                }
+              }
+              bar_lds();
+              if (tq < 64) {
+                // the (at most 16) waves' sums: one 16-lane row, added by DPP in an order that does not depend on the block size
+                const float2 pt = tq < NT / 64 ? part[tq] : float2{0.f, 0.f};
+                const float sx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, dpp_xor_row_sum(pt.x))));
+                const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, dpp_xor_row_sum(pt.y))));
+                const float sold = Ss[k * kS + l];
+                const float adiag = CfT[k * kS + k] * CgT[l * kS + l] - sy;
+                const float tau_p = tau * adiag;
+                const float numer = fmaf(tau, rS[pp] + sx + sold * adiag, -lamS);
+                float xnew = 0.f;
+                if (draw) {
+                  const TnFast tf = tn_fast_params(numer, tau_p);
+                  float xc = 0.f;
+                  const bool acc = tq < 4 && tn_cand_post(tf, cand, &xc);
+                  unsigned long long mask = __ballot(acc);
+                  if (tf.live) {
+                    if (mask) xnew = tn_guard(__shfl(xc, __ffsll((long long)mask) - 1, 64));
+                    else
+                      for (uint32_t c0 = 4u; c0 < 4096u; c0 += 64u) {        // (one draw in ~250 rejects its first four candidates)
+                        const uint32_t c = c0 + (uint32_t)tq;
+                        const U4 r = philox4x32_10(0u, (uint32_t)pp, it32, kStreamS + 16u * c, L.key0, L.key1);
+                        const bool a2 = tn_eval_fast(tf, r.x, r.y, &xc) && c < 4096u;
+                        mask = __ballot(a2);
+                        if (mask) { xnew = tn_guard(__shfl(xc, __ffsll((long long)mask) - 1, 64)); break; }
+                      }
+                  }
+                } else {
+                  const float mu = numer / tau_p;
+                  xnew = fmaxf((tau_p > 0.f && mu > 0.f) ? mu : 0.f, L.min_x);
+                }
+                if (tq == 0) { dl[0] = xnew - sold; Ss[k * kS + l] = xnew; SsT[l * kS + k] = xnew; }
+              }
+              bar_lds();
+              const float delta = dl[0];
+              if (tq < n2) rS[tq] = fmaf(-delta * CfT[kkA * kS + k], CgT[l * kS + llA], rS[tq]);
+              for (int p2 = tq + NT; p2 < n2; p2 += NT) {          // (more entries than threads: the small blocks with wide factors)
+                const int kk = p2 / Lc, ll = p2 - kk * Lc;
+                rS[p2] = fmaf(-delta * CfT[kk * kS + k], CgT[l * kS + ll], rS[p2]);
+              }
+              dprev = delta * f; lprev = l;
+            }
+          }
+          STAMP(15);
+          // the last step's update of q; q goes where the G sweep finds it; S: state, sample, posterior sum
+          if (entry) {
+#pragma unroll
+            for (int e = 0; e < EM; ++e)
+              if (e < em) {
+                const float vlast = regC[((sj[e >> 1] >> (16 * (e & 1))) & 0xFFFFu) + lprev];
+                *G(d.q + e * kSmallThreads + tq) = fmaf(dprev, vlast, sq[e]);
+              }
+          }
+        } else {
+          // ---------------- the dense form: A = Cf (x) Cg - sum_miss (f f^T) (x) (g g^T) in LDS, the K L steps on ONE wave
+          constexpr int KD = kTriDenseK, PD = kTriPairs;
+          const int lane = tq & 63, wave = tq >> 6;
+          const SmallDirDev& dc = L.cols;
+          float* buf = gscr;                       // [8][NT]: eight packed second moments of every entry thread at a time
+          // (1) W'_j = sum_{i in miss(j)} f_i f_i^T (packed upper triangle of the 10-wide index: columns >= K of F are zero) per
+          // entry thread of the G sweep's layout, then per unit: the unit's threads in thread order
+          {
+            float acc[PD];
+#pragma unroll
+            for (int pi = 0; pi < PD; ++pi) acc[pi] = 0.f;
+            const bool ce = tq < dc.nthreads;
+            if (ce) {
+              uint32_t off = *G(dc.idx + tq);
+              for (int e = 0; e < dc.em; ++e) {
+                const uint32_t off_n = e + 1 < dc.em ? (uint32_t)*G(dc.idx + (e + 1) * kSmallThreads + tq) : 0u;
+                float fv[KD];
+#pragma unroll
+                for (int k2 = 0; k2 < KD; ++k2) fv[k2] = regR[off + k2];
+                int pi = 0;
+#pragma unroll
+                for (int k2 = 0; k2 < KD; ++k2)
+#pragma unroll
+                  for (int k3 = k2; k3 < KD; ++k3) { acc[pi] = fmaf(fv[k2], fv[k3], acc[pi]); ++pi; }
+                off = off_n;
+              }
+            }
+            STAMP(19);
+            uint16_t* segL = reinterpret_cast<uint16_t*>(tmpS);          // [J][2] the units' entry threads, read seven times: in LDS
+            for (int t = tq; t < 2 * J; t += NT) segL[t] = *G(dc.seg + t);
+#pragma unroll
+            for (int ch = 0; ch < (PD + 7) / 8; ++ch) {
+              bar_lds();
+              if (ce) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) buf[c * NT + tq] = ch * 8 + c < PD ? acc[ch * 8 + c < PD ? ch * 8 + c : 0] : 0.f;
+              }
+              bar_lds();
+              for (int o = tq; o < J * 8; o += NT) {
+                const int j = o >> 3, c = o & 7;
+                const int s0 = segL[2 * j], sn = segL[2 * j + 1];
+                float sm = 0.f;
+                for (int t = s0; t < s0 + sn; ++t) sm += buf[c * NT + t];
+                *G(L.Wg + (size_t)j * 56 + ch * 8 + c) = sm;
+              }
+            }
+          }
+          bar_all();                               // (W' is read by other threads; F's region is free from here on)
+          STAMP(20);
+          float* Ad = small_tri_dense_overlays(I, K, Lc) ? regR : misc + MS::floats;        // [n2][n2] the system, then [64][64] the packed products
+          float* Am = Ad + ((n2 * n2 + 3) & ~3);
+          // (2) Am[(k <= k')][(l <= l')] = sum_j W'_j[(k k')] G_jl G_jl' on the f32 matrix cores: 4 x 4 tiles of 16 x 16, inner index j
+          for (int tile = wave; tile < 16; tile += NT / 64) {
+            const int ti = tile >> 2, tj = tile & 3;
+            const int pk = 16 * ti + (lane & 15), pl = 16 * tj + (lane & 15), jq = lane >> 4;
+            int la = 0, lb = 0;
+            tri_pair(pl < PD ? pl : 0, la, lb);
+            f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+            const int pkc = min(pk, 55);
+            for (int j0 = 0; j0 < J; j0 += 16) {           // four inner steps' operands first (W' comes from L2), then their products
+              float av[4], bv[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const int j = j0 + 4 * u + jq, jc = min(j, J - 1);
+                av[u] = *G(L.Wg + (size_t)jc * 56 + pkc);
+                bv[u] = regC[jc * kS + la] * regC[jc * kS + lb];
+                if (!(j < J && pk < 56)) av[u] = 0.f;
+                if (!(j < J && pl < PD)) bv[u] = 0.f;
+              }
+#pragma unroll
+              for (int u = 0; u < 4; ++u) acc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc4, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Am[(16 * ti + 4 * jq + r) * 64 + 16 * tj + (lane & 15)] = acc4[r];      // C/D: col = lane & 15, row = 4 (lane >> 4) + reg
+          }
+          bar_lds();
+          STAMP(21);
+          // (3) the system: A[(k l)][(k' l')] = Cf_kk' Cg_ll' - Am[(k k')][(l l')]; a thread keeps one column p' and walks the rows
+          {
+            const int pc = tq & 127, rg = tq >> 7;
+            if (pc < n2) {
+              const int k2 = pc / Lc, l2 = pc - k2 * Lc;
+              constexpr int RS = NT / 128;
+              const int dk = RS / Lc, dl2 = RS - dk * Lc;
+              int k1 = rg / Lc, l1 = rg - k1 * Lc;
+              for (int pr = rg; pr < n2; pr += RS, k1 += dk, l1 += dl2) {
+                if (l1 >= Lc) { l1 -= Lc; ++k1; }
+                const int pk = tri_pair_index(min(k1, k2), max(k1, k2)), pl = tri_pair_index(min(l1, l2), max(l1, l2));
+                Ad[pr * n2 + pc] = fmaf(CfT[k1 * kS + k2], CgT[l1 * kS + l2], -Am[pk * 64 + pl]);
+              }
+            }
+          }
+          bar_lds();
+          STAMP(22);
+          // (4) r = b - A S
+          for (int p0 = 0; p0 < n2; p0 += NT / 8) {          // eight threads per row, each every eighth column
+            const int pr = p0 + (tq >> 3), s8 = tq & 7;
+            float a = 0.f;
+            if (pr < n2) {
+              int k2 = s8 / Lc, l2 = s8 - k2 * Lc;
+              const int dk = 8 / Lc, dl2 = 8 - dk * Lc;
+              for (int pc = s8; pc < n2; pc += 8, k2 += dk, l2 += dl2) {
+                if (l2 >= Lc) { l2 -= Lc; ++k2; }
+                a = fmaf(Ad[pr * n2 + pc], Ss[k2 * kS + l2], a);
+              }
+            }
+            a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
+            if (pr < n2 && s8 == 0) rS[pr] -= a;
+          }
+          // the chain's first four candidates per entry (their halves that need the random words only) and the prior rates into LDS,
+          // where the packed products were: a step of the chain is shorter than a round trip to L2
+          float4* candL = reinterpret_cast<float4*>(Am);           // [n2][4]
+          float* lamL = Am + 4 * 4 * 128;                           // [n2]
+          for (int e = tq; e < n2 * 4; e += NT) {
+            TnCand cd = {0.f, 0.f, 0.f};
+            if (draw) {
+              const U4 r = philox4x32_10(0u, (uint32_t)(e >> 2), it32, kStreamS + 16u * (uint32_t)(e & 3), L.key0, L.key1);
+              cd = tn_cand_pre(r.x, r.y);
+            }
+            candL[e] = float4{cd.nl, cd.z, cd.sw, 0.f};
+          }
+          for (int e = tq; e < n2; e += NT) lamL[e] = *G(L.lambdaS + e);
+          STAMP(14);
+          bar_lds();
+          // (5) the chain: lane p keeps r_p and S_p (and those of p + 64); a step reads its entry's row of A (one step ahead), forms
+          // the conditional from registers, tests the four candidates in lanes 0-3, and folds delta into r.  What a lone wave pays
+          // for is dependent instructions and, most of all, branches on vector conditions (tools/micro/lone_wave.hip): the parts
+          // that need tau_p only are made a step ahead, S is selected by lane (no LDS round trip, no masked store), one branch per
+          // step (the draw whose first four candidates were all rejected).
+          if (tq < 64) {
+            float r0 = lane < n2 ? rS[lane] : 0.f, r1 = lane + 64 < n2 ? rS[lane + 64] : 0.f;
+            float s0 = 0.f, s1 = 0.f;
+            { const int ka = lane / Lc, kb = (lane + 64) / Lc;
+              if (lane < n2) s0 = Ss[ka * kS + lane - ka * Lc];
+              if (lane + 64 < n2) s1 = Ss[kb * kS + lane + 64 - kb * Lc]; }
+            float4 cn = candL[lane & 3];
+            float lam_n = lamL[0];
+            float a0 = lane < n2 ? Ad[lane] : 0.f, a1 = lane + 64 < n2 ? Ad[lane + 64] : 0.f, ad = Ad[0];
+            TnPre pre_n = tn_fast_pre(tau * ad);
+            auto chain = [&](auto draws) {             // (two copies of the loop: the update rule is not a branch of every step)
+            constexpr bool DRAW = decltype(draws)::value;
+#pragma unroll 1
+            for (int sidx = 0; sidx < n2; ++sidx) {
+              const TnCand cand = {cn.x, cn.y, cn.z};
+              const float lamS = lam_n;
+              const float c0 = a0, c1 = a1, adiag = ad;
+              const TnPre pre = pre_n;
+              if (sidx + 1 < n2) {                   // the next step's row, candidates, rate and tau_p parts on their way
+                cn = candL[(sidx + 1) * 4 + (lane & 3)];
+                lam_n = lamL[sidx + 1];
+                const float* row = Ad + (sidx + 1) * n2;
+                a0 = lane < n2 ? row[lane] : 0.f; a1 = lane + 64 < n2 ? row[lane + 64] : 0.f; ad = row[sidx + 1];
+                pre_n = tn_fast_pre(tau * ad);
+              }
+              const int sl = sidx & 63;
+              const float rs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sidx < 64 ? r0 : r1), sl));
+              const float sold = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sidx < 64 ? s0 : s1), sl));
+              const float tau_p = tau * adiag;
+              const float numer = fmaf(tau, fmaf(sold, adiag, rs), -lamS);
+              float xnew;
+              if constexpr (DRAW) {
+                const TnFast tf = tn_fast_post(pre, numer);
+                float xc = 0.f;
+                const bool acc = tn_cand_post(tf, cand, &xc);          // (every lane holds candidate lane & 3: no masked section)
+                unsigned long long mask = __ballot(acc) & 0xFull;
+                const int src = mask ? __ffsll((long long)mask) - 1 : 0;
+                const float xsel = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tn_guard(xc)), src));
+                xnew = (tf.live && mask) ? xsel : 0.f;
+                if (__builtin_expect(tf.live && !mask, 0))
+                  for (uint32_t cb = 4u; cb < 4096u; cb += 64u) {          // (one draw in ~250 rejects its first four candidates)
+                    const uint32_t c = cb + (uint32_t)lane;
+                    const U4 r = philox4x32_10(0u, (uint32_t)sidx, it32, kStreamS + 16u * c, L.key0, L.key1);
+                    const bool a2 = tn_eval_fast(tf, r.x, r.y, &xc) && c < 4096u;
+                    mask = __ballot(a2);
+                    if (mask) { xnew = tn_guard(__shfl(xc, __ffsll((long long)mask) - 1, 64)); break; }
+                  }
               } else {
                 const float mu = numer / tau_p;
                 xnew = fmaxf((tau_p > 0.f && mu > 0.f) ? mu : 0.f, L.min_x);
               }
-              if (tq == 0) { dl[0] = xnew - sold; Ss[k * kS + l] = xnew; SsT[l * kS + k] = xnew; }
+              const float delta = xnew - sold;
+              r0 = fmaf(-delta, c0, r0); r1 = fmaf(-delta, c1, r1);
+              const bool mine = lane == sl;
+              s0 = (mine && sidx < 64) ? xnew : s0;
+              s1 = (mine && sidx >= 64) ? xnew : s1;
             }
-            bar_lds();
-            const float delta = dl[0];
-            if (tq < n2) rS[tq] = fmaf(-delta * CfT[kkA * kS + k], CgT[l * kS + llA], rS[tq]);
-            for (int p2 = tq + NT; p2 < n2; p2 += NT) {          // (more entries than threads: the small blocks with wide factors)
-              const int kk = p2 / Lc, ll = p2 - kk * Lc;
-              rS[p2] = fmaf(-delta * CfT[kk * kS + k], CgT[l * kS + ll], rS[p2]);
-            }
-            dprev = delta * f; lprev = l;
+            };
+            if (draw) chain(std::true_type{}); else chain(std::false_type{});
+            { const int ka = lane / Lc, kb = (lane + 64) / Lc;
+              if (lane < n2) { Ss[ka * kS + lane - ka * Lc] = s0; SsT[(lane - ka * Lc) * kS + ka] = s0; }
+              if (lane + 64 < n2) { Ss[kb * kS + lane + 64 - kb * Lc] = s1; SsT[(lane + 64 - kb * Lc) * kS + kb] = s1; } }
           }
-        }
-        STAMP(15);
-        // the last step's update of q; q goes where the G sweep finds it; S: state, sample, posterior sum
-        if (entry) {
-#pragma unroll
-          for (int e = 0; e < EM; ++e)
-            if (e < em) {
-              const float vlast = regC[((sj[e >> 1] >> (16 * (e & 1))) & 0xFFFFu) + lprev];
-              *G(d.q + e * kSmallThreads + tq) = fmaf(dprev, vlast, sq[e]);
-            }
+          STAMP(15);
+          bar_lds();
+          if (small_tri_dense_overlays(I, K, Lc))        // F back into its region (and its zero row)
+            for (int t = tq; t < (I + 1) * kS; t += NT) { const int u = t / kS, k2 = t - u * kS; regR[t] = (u < I && k2 < K) ? *G(L.rows.X + u * 32 + k2) : 0.f; }
         }
         {
           const bool add = L.expS && L.exp_burn >= 0 && it >= L.exp_burn && (it - L.exp_burn) % L.exp_thin == 0;
@@ -928,7 +1169,10 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
     printf("small kernel thread %d, %d iterations, cycles per iteration: table %llu contract %llu qinit %llu | columns: entry+prefetch %llu bar %llu unit %llu cand %llu pick %llu retry %llu (%d rounds) fixup %llu | qstore %llu gram %llu copy %llu finish %llu | tri: effective factor + Gram %llu S setup %llu S steps %llu S tail %llu\n",
            tid, L.n_iter, ph[0] / L.n_iter, ph[1] / L.n_iter, ph[2] / L.n_iter, ph[3] / L.n_iter, ph[4] / L.n_iter, ph[5] / L.n_iter, ph[6] / L.n_iter, ph[7] / L.n_iter,
            ph[8] / L.n_iter, nretry, ph[9] / L.n_iter, ph[10] / L.n_iter, ph[11] / L.n_iter, ph[12] / L.n_iter, ph[13] / L.n_iter,
-           ph[16] / L.n_iter, ph[14] / L.n_iter, ph[15] / L.n_iter, ph[17] / L.n_iter);
+           ph[16] / L.n_iter, (ph[14] + ph[18] + ph[19] + ph[20] + ph[21] + ph[22]) / L.n_iter, ph[15] / L.n_iter, ph[17] / L.n_iter);
+  if (TRI && blockIdx.x == 0 && tid == 0)
+    printf("   S setup: G back, R~ G, b %llu | packed second moments %llu per-unit sums %llu | products (MFMA) %llu system %llu r, candidates %llu\n",
+           ph[18] / L.n_iter, ph[19] / L.n_iter, ph[20] / L.n_iter, ph[21] / L.n_iter, ph[22] / L.n_iter, ph[14] / L.n_iter);
   if (blockIdx.x == 0 && (tid & 63) == 0)
     printf("   wave %2d contraction per iteration: rows loop %llu epilogue %llu (%llu items) | cols loop %llu epilogue %llu (%llu items)\n", tid >> 6,
            cph[0] / L.n_iter, cph[1] / L.n_iter, cph[2] / L.n_iter, cph[3] / L.n_iter, cph[4] / L.n_iter, cph[5] / L.n_iter);

@@ -426,8 +426,9 @@ struct SmallLaunch {
   int L;
   float* S;                    // [K][L] state
   const float* lambdaS;        // [K][L] prior rates
-  float* ZT;                   // [32][rows.ldn] R~ G: b = F^T (R~ G) of the S step
+  float* ZT;                   // [32][cols.ldn] Pv = R~^T F (k-major): b = Pv^T G of the S step, and (R~^T F) S is the G sweep's contraction
   uint2* stab;                 // [K L][4] Philox words of the first four candidates of every S draw of an iteration
+  float* Wg;                   // [cols.n][56] packed second moments of F's rows over a column's missing entries (the dense S step, K, L <= 10)
   float* S_s;                  // samples [n_iter][K][L], or null
   double* expS;                // posterior sum [K][L], or null
 };
