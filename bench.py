@@ -51,6 +51,8 @@ WORKLOADS = {
                                   source="plots/time_Sanger/nmf_gibbs_times.txt (500 it in 201.0 s; experiments_gdsc/time/nmf_gibbs_time.py:22-47, 81 % observed)"),
     "bnmtf_toy_100x80_k5": dict(kind="bnmtf", small=True, I=100, J=80, K=5, L=5, missing=0.0, steps=1000, published=45.1,
                                 source="plots/time_toy/nmtf_gibbs_times.txt (2000 it in 44.37 s; experiments_toy/time/nmtf_gibbs_time.py:25-53)"),
+    "bnmtf_gdsc_622x138_k5": dict(kind="bnmtf", small=True, I=622, J=138, K=5, L=5, missing=0.19, steps=1000, published=9.02,
+                                  source="plots/time_Sanger/nmtf_gibbs_times.txt (1000 it in 110.8 s; experiments_gdsc/time/nmtf_gibbs_time.py, K = L = 5, 81 % observed)"),
     "cv_gdsc": dict(kind="cv", small=True, I=622, J=138, K=25, missing=0.19, values_K=[15, 20, 25, 30], folds=10, iterations=1000, burn_in=900, thinning=2,
                     source="experiments_gdsc/cross_validation/gibbs_nmf/linesearch_xval_gibbs.py:17-62 (10 folds x K in {15,20,25,30} x 1000 it, AIC, then 10 final models)"),
     "cv_gdsc_bnmtf": dict(kind="cv3", small=True, I=622, J=138, K=8, L=8, missing=0.19, values_K=[5, 6, 7, 8, 9, 10], values_L=[5, 6, 7, 8, 9, 10], folds=10,
@@ -291,7 +293,7 @@ def main_small(a, w):
     m.close()
     # a batch of independent models (different masks / seeds, same shape) in ONE call: what a model search runs
     batch = None
-    if w["kind"] == "bnmf":                  # (run_many takes BNMF Gibbs models; the tri-factorisation has no one-launch kernel)
+    if w["kind"] in ("bnmf", "bnmtf"):       # (run_many: the models of the one-launch path share a launch, a block each)
         batch = {}
         for nb in a.batch:
             ms = []

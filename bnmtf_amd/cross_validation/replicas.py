@@ -63,6 +63,10 @@ class ReplicaPool(object):
             devices = list(range(max(n, 1)))
         self.devices = list(devices)
         self.shared = dict(shared or {})
+        # several slots on one GPU: their models run side by side, each of the one-launch kind on a CU of its own -- the rule that
+        # sends a lone CU-filling model down the multi-launch path (it has the chip to itself there) does not describe them
+        if len(set(self.devices)) < len(self.devices):
+            self.shared.setdefault("_small_path", "always")
         self.batched = bool(batched)
         self._pool = None
         self._lock = threading.Lock()           # (map() may be called from several threads: the folds of a greedy-search cross-validation)
@@ -212,6 +216,8 @@ def _build(job, shared):
         if _accepts(cls.__init__, "seed"):
             kw["seed"] = job["seed"]
     model = cls(R, np.asarray(job["M"], dtype=float), *job["args"], **kw)
+    if shared.get("_small_path") is not None and hasattr(model, "set_small_path"):
+        model.set_small_path(shared["_small_path"])
     model.initialise(**job["init"])
     return model
 

@@ -121,6 +121,7 @@ def test_run_many_is_every_models_own_run():
             np.random.seed(seed)
             m = bnmtf_gibbs_optimised(R, M, K, L, PRI, seed=seed, verbose=False)
             m.initialise('random', 'random')
+            m.set_small_path('always')          # (alone, the models that fill a CU would take the multi-launch path: another summation order)
             ms.append(m)
         R, M, _, _ = generate_bnmf(80, 60, 5, 0.1, seed_data=9, seed_mask=10)
         np.random.seed(9)
@@ -202,3 +203,29 @@ def test_batched_greedy_search_cross_validation_gives_the_unbatched_results(tmp_
         if batched:
             assert calls[0] == 3 and max(calls) >= 6, calls        # the three folds' first models in one call, their steps of up to three models together
     assert perf[0] == perf[1]
+
+
+def test_the_path_is_chosen_by_what_the_call_runs():
+    """A tri-factorisation that fills a CU (1024-thread block) runs faster alone on the multi-launch path, and on a CU of its own as
+    soon as a call runs two of them; the small ones always take the one launch.  (std_built: were the multi-launch structures built?)"""
+    R, M, _, _, _ = generate_bnmtf(622, 138, 6, 6, 0.19, seed_data=1, seed_mask=2)
+    def model(seed):
+        np.random.seed(seed)
+        b = bnmtf_gibbs_optimised(R, M, 6, 6, PRI, seed=seed, verbose=False)
+        b.initialise('random', 'random')
+        return b
+    lone = model(1)
+    assert not lone.is_small()
+    lone.run(3)
+    assert "std_built=1" in lone.describe()
+    pair = [model(2), model(3)]
+    bnmtf_amd.run_many(pair, 3)
+    assert all("std_built=0" in m.describe() and "block=1024" in m.describe() for m in pair)
+    assert all(np.isfinite(m.all_performances['MSE']).all() for m in pair + [lone])
+    Rs, Ms, _, _, _ = generate_bnmtf(100, 80, 5, 5, 0.1, seed_data=1, seed_mask=2)
+    np.random.seed(4)
+    small = bnmtf_gibbs_optimised(Rs, Ms, 5, 5, PRI, seed=4, verbose=False)
+    small.initialise('random', 'random')
+    assert small.is_small()
+    small.run(3)
+    assert "std_built=0" in small.describe()
