@@ -63,10 +63,11 @@ class ReplicaPool(object):
             devices = list(range(max(n, 1)))
         self.devices = list(devices)
         self.shared = dict(shared or {})
-        # several slots on one GPU: their models run side by side, each of the one-launch kind on a CU of its own -- the rule that
-        # sends a lone CU-filling model down the multi-launch path (it has the chip to itself there) does not describe them
+        # several slots on one GPU: their models run side by side.  A tri-factorisation that fills a CU is 1.3-1.6 x slower on the
+        # one-launch path than alone on the multi-launch path -- four of them side by side are ahead there (measured: the greedy
+        # search's job 9.4 -> 7.5 s with four slots); a two-factor model is 2.5 x slower and is not (1.6 -> 4.2 s): tri models only
         if len(set(self.devices)) < len(self.devices):
-            self.shared.setdefault("_small_path", "always")
+            self.shared.setdefault("_small_path_tri", "always")
         self.batched = bool(batched)
         self._pool = None
         self._lock = threading.Lock()           # (map() may be called from several threads: the folds of a greedy-search cross-validation)
@@ -216,8 +217,8 @@ def _build(job, shared):
         if _accepts(cls.__init__, "seed"):
             kw["seed"] = job["seed"]
     model = cls(R, np.asarray(job["M"], dtype=float), *job["args"], **kw)
-    if shared.get("_small_path") is not None and hasattr(model, "set_small_path"):
-        model.set_small_path(shared["_small_path"])
+    if shared.get("_small_path_tri") is not None and getattr(model, "L", 0) and hasattr(model, "set_small_path"):
+        model.set_small_path(shared["_small_path_tri"])
     model.initialise(**job["init"])
     return model
 
