@@ -3,6 +3,7 @@
 tag=$1
 mkdir -p gpurun_out/bench_$tag
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > gpurun_out/bench_$tag/gpu_suite.txt
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" >> gpurun_out/bench_$tag/gpu_suite.txt 2>&1
 bash tools/profile_round.sh $tag bnmf_8192_k64 bnmf_4096_k32 bnmtf_4096_k32 vb_8192_k64 > gpurun_out/bench_$tag/profile.log 2>&1
 python bench.py > gpurun_out/bench_$tag/${tag}_bnmf_8192_k64.json 2> gpurun_out/bench_$tag/err.txt
 python bench.py --workload bnmf_4096_k32 --steps 50 > gpurun_out/bench_$tag/${tag}_bnmf_4096_k32.json 2>> gpurun_out/bench_$tag/err.txt
@@ -12,7 +13,8 @@ for w in bnmtf_toy_100x80_k5 bnmtf_gdsc_622x138_k5 bnmf_toy_100x80_k10 bnmf_gdsc
   python bench.py --workload $w > gpurun_out/bench_$tag/${tag}_$w.json 2>> gpurun_out/bench_$tag/err.txt
 done
 python bench.py --workload cv_gdsc_bnmtf --slots 1 4 8 > gpurun_out/bench_$tag/${tag}_cv_gdsc_bnmtf.json 2>> gpurun_out/bench_$tag/err.txt
-python bench.py --workload cv_gdsc > gpurun_out/bench_$tag/${tag}_cv_gdsc.json 2>> gpurun_out/bench_$tag/err.txt
+python bench.py --workload cv_gdsc > gpurun_out/bench_$tag/${tag}_cv_gdsc_slots.json 2>> gpurun_out/bench_$tag/err.txt
+python bench.py --workload cv_gdsc --cv-batched --slots 1 > gpurun_out/bench_$tag/${tag}_cv_gdsc_batched.json 2>> gpurun_out/bench_$tag/err.txt
 rocm-smi --showpower --showclocks 2>/dev/null | grep -E "sclk|Power" | head -4 > gpurun_out/bench_$tag/smi.txt
 cat gpurun_out/bench_$tag/gpu_suite.txt
 for f in gpurun_out/bench_$tag/*.json; do python - "$f" <<'PY'
