@@ -1,4 +1,4 @@
-# same-box A/B of two library builds at the shard shapes and the lone GDSC-size models (multi-launch path)
+# same-box A/B of two library builds (the shipped one against tools/lib_prev.so) at the shard shapes (rows x 8192, under rocprofv3) and for lone GDSC-size models on the multi-launch path
 mkdir -p gpurun_out/abs; repo=$PWD
 cd /tmp && export TMPDIR=/tmp
 for v in new prev new prev; do
