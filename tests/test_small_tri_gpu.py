@@ -229,3 +229,45 @@ def test_the_path_is_chosen_by_what_the_call_runs():
     assert small.is_small()
     small.run(3)
     assert "std_built=0" in small.describe()
+
+
+def test_random_shapes_ranks_and_masks_agree_with_the_multi_launch_path():
+    """tools/fuzz_small_tri.py in short: edge shapes (one row, one column, rank one, nothing missing, 45 % missing), both forms of the
+    S step, every block size -- first iteration against the multi-launch path, draws and mode updates."""
+    rng = np.random.RandomState(5)
+    done = 0
+    for case in range(60):
+        I = int(rng.choice([1, 2, 7, 33, 65, 100, 257, 400, 622])); J = int(rng.choice([1, 3, 16, 31, 80, 138, 300]))
+        if I + J > 900: J = max(1, 900 - I)
+        K = int(rng.choice([1, 2, 5, 10, 11, 32])); L = int(rng.choice([1, 3, 10, 12, 32]))
+        miss = float(rng.choice([0.0, 0.05, 0.2, 0.45]))
+        try:
+            R, M, _, _, _ = generate_bnmtf(I, J, K, L, miss, seed_data=case, seed_mask=case + 1)
+        except RuntimeError:                     # (no mask without an empty row or column at this shape and density)
+            continue
+        for upd in ("draw", "mode"):
+            runs = []
+            for small in (True, False):
+                np.random.seed(case)
+                b = bnmtf_gibbs_optimised(R, M, K, L, PRI, seed=case + 5, verbose=False)
+                b.initialise('random', 'random')
+                b.set_small_path('always' if small else False)
+                if small and not b.is_small():
+                    break
+                b.run(2, update=upd)
+                runs.append(b)
+            if len(runs) < 2:
+                break
+            a, c = runs
+            for nm in ("all_F", "all_S", "all_G"):
+                x, y = getattr(a, nm)[0], getattr(c, nm)[0]
+                d = np.abs(x - y) / (1e-3 + np.abs(y))
+                assert np.isfinite(x).all() and np.mean(d < 5e-3) >= (0.9 if upd == "draw" else 0.999), (case, I, J, K, L, miss, upd, nm, np.mean(d < 5e-3), d.max())
+            np.testing.assert_allclose(a.all_performances['MSE'][0], c.all_performances['MSE'][0], rtol=2e-2 if upd == "draw" else 1e-3)
+            for m in runs:
+                m.close()
+        else:
+            done += 1
+        if done >= 16:
+            break
+    assert done >= 16
