@@ -238,7 +238,7 @@ struct ContractArgs {
   const float* big; const float* XT; const float* lambda; float* PT;
   int n, m, ldb, ldn, K; float tau;
   uint32_t regO_b, CsO_b, regOwn_b;       // LDS byte addresses of the other factor, its Gram, and the own factor's region
-  bool raw = false;                       // the bare product sum_r big[r][u] Xo[r][k] into PT, nothing else (the S step's R~ G)
+  bool raw = false;                       // the bare product sum_r big[r][u] Xo[r][k] into PT, nothing else (the tri-factorisation's Pv = R~^T F)
 };
 template <int UW, int NT>
 __device__ __forceinline__ void small_contract(const ContractArgs& d, int tid) {
@@ -747,9 +747,11 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
       // ================================================= the S step of the tri-factorisation (bnmtf_gibbs_optimised.py:157-160, 201-205)
       // The conditional of S_kl needs sums over the OBSERVED entries of w_ij = F_ik G_jl; in the exact Gram + sparse-complement form
       //   tau_p = tau (Cf_kk Cg_ll - sum_miss w^2),   numer = -lambda + tau (r_kl + sum_miss q w + S_kl (Cf_kk Cg_ll - sum_miss w^2)),
-      //   r = F^T R~ G - Cf S Cg (kept current: r -= delta Cf[:, k] (x) Cg[l, :]),   q_ij = (F S G^T)_ij on the missing entries,
-      // q in the registers of the F sweep's entry threads (a thread's entries share i: one F_ik per thread and row of S), the two
-      // sums over the missing entries = the column loop's gather of G's column l, reduced over the whole block by wave 0, which draws.
+      //   r = F^T R~ G - Cf S Cg (kept current: r -= delta Cf[:, k] (x) Cg[l, :]),   q_ij = (F S G^T)_ij on the missing entries.
+      // Two forms.  Sequential: q in the registers of the F sweep's entry threads (a thread's entries share i: one F_ik
+      // per thread and row of S), the two sums over the missing entries = the column loop's gather of G's column l, reduced over the
+      // whole block by wave 0, which draws.  Dense (K, L <= 10): the whole system A = Cf (x) Cg - sum_miss (f f^T) (x) (g g^T) in LDS,
+      // the K L steps on one wave.
       if constexpr (TRI) if (dir == 0) {
         const int n2 = K * Lc;
         float* rS = reinterpret_cast<float*>(c64R);          // [K L] (the fp64 Gram's area is free until the G sweep's effective factor is formed)
@@ -768,7 +770,6 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
         }
         bar_lds();
         {
-          const int kt = (K + 15) >> 4;
           ContractArgs ca;
 #ifdef BNMTF_SMALL_TIMING
           ca.cph = cph;
@@ -778,7 +779,6 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
           ca.big = dc.big; ca.XT = dc.XT; ca.lambda = dc.lambda; ca.PT = L.ZT;
           ca.n = dc.n; ca.m = dc.m; ca.ldb = dc.ldb; ca.ldn = dc.ldn; ca.K = K; ca.tau = tau; ca.raw = true;
           ca.regO_b = (uint32_t)(uintptr_t)(lds_fp)regR; ca.CsO_b = (uint32_t)(uintptr_t)(lds_fp)CsC; ca.regOwn_b = (uint32_t)(uintptr_t)(lds_fp)regC;
-          (void)kt;
           small_contract<2, NT>(ca, tq);           // (one shape for this product: a third of the sweep's)
         }
         for (int pp = tq; pp < n2; pp += NT) {               // Cf T
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
           for (int k2 = 0; k2 < K && !tri_dense; ++k2) a = fmaf(CfT[kk * kS + k2], tmpS[k2 * Lc + ll], a);
           rS[pp] = a;                            // (dense: 0 -- r = b - A S follows when A is there)
         }
-        bar_all();                               // (Z is read by other threads than the ones that stored it)
+        bar_all();                               // (Pv is read by other threads than the ones that stored it)
         for (int p0 = 0; p0 < n2; p0 += NT / 8) {                // r = Pv^T G - Cf S Cg: eight threads per entry, fp64 sums
           const int pp = p0 + (tq >> 3), s8 = tq & 7;
           double a = 0.0;
