@@ -282,3 +282,52 @@ def test_joint_map_merges_the_calls_the_threads_have_open():
     for t in ts: t.join(timeout=30)
     assert rec2.calls == [4] and got == {1: [2, 4], 5: [10, 12]}
     assert isinstance(ReplicaPool(devices=[0]).joint(2), _Joint)
+
+
+def test_joint_map_survives_a_walk_that_fails():
+    """A thread that raises between its map() calls leaves (the caller's `finally`): the others are not left waiting for it; an
+    exception inside the merged call reaches every caller of that call."""
+    import threading
+    from bnmtf_amd.cross_validation.replicas import _Joint
+
+    class Pool(object):
+        shared, devices, batched = {}, [0], True
+        def map(self, fn, jobs, errors="raise"):
+            if any(j == "boom" for j in jobs):
+                raise ValueError("the device call failed")
+            return [fn(j, None) for j in jobs]
+
+    f = lambda j, _: j
+    joint = _Joint(Pool(), 3)
+    out = {}
+    def good(name):
+        try:
+            out[name] = [joint.map(f, [name]), joint.map(f, [name + 10])]
+        finally:
+            joint.leave()
+    def bad():
+        try:
+            joint.map(f, [0])
+            raise RuntimeError("this walk stops here")
+        except RuntimeError:
+            out["bad"] = "stopped"
+        finally:
+            joint.leave()
+    ts = [threading.Thread(target=good, args=(1,)), threading.Thread(target=good, args=(2,)), threading.Thread(target=bad)]
+    for t in ts: t.start()
+    for t in ts: t.join(timeout=30)
+    assert not any(t.is_alive() for t in ts)
+    assert out == {1: [[1], [11]], 2: [[2], [12]], "bad": "stopped"}
+    joint = _Joint(Pool(), 2)
+    errs = []
+    def failing(job):
+        try:
+            joint.map(f, [job])
+        except ValueError as e:
+            errs.append(str(e))
+        finally:
+            joint.leave()
+    ts = [threading.Thread(target=failing, args=(j,)) for j in ("boom", "fine")]
+    for t in ts: t.start()
+    for t in ts: t.join(timeout=30)
+    assert not any(t.is_alive() for t in ts) and errs == ["the device call failed"] * 2
