@@ -88,8 +88,7 @@ __host__ __device__ inline int small_tri_floats(int K, int L) { return L > 0 ? (
 // 55 packed second moments per unit fit a thread's registers, the system is <= 100 x 100).  Its system and the packed products
 // take the F region's place while the chain runs (F comes back from global memory) -- or, when that region is too small, space
 // of their own behind the exchange arrays.
-constexpr int kTriDenseK = 10, kTriPairs = kTriDenseK * (kTriDenseK + 1) / 2;
-__host__ __device__ inline bool small_tri_dense(int K, int L) { return L > 0 && K <= kTriDenseK && L <= kTriDenseK; }
+constexpr int kTriPairs = kTriDenseK * (kTriDenseK + 1) / 2;            // (kTriDenseK, small_tri_dense: kernels.h -- the path rule asks, too)
 __host__ __device__ inline int small_tri_dense_floats(int K, int L) { return ((K * L * K * L + 3) & ~3) + 64 * 64; }
 __host__ __device__ inline bool small_tri_dense_overlays(int I, int K, int L) { return (I + 1) * kS >= small_tri_dense_floats(K, L); }
 __host__ __device__ inline int tri_pair_index(int a, int b) { return a * kTriDenseK - a * (a - 1) / 2 + (b - a); }      // a <= b < 10
@@ -923,6 +922,8 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
           const int lane = tq & 63, wave = tq >> 6;
           const SmallDirDev& dc = L.cols;
           float* buf = gscr;                       // [8][NT]: eight packed second moments of every entry thread at a time
+          // (the packed index is the 10-wide triangle's whatever K and L are: pairs behind the last one of the model's ranks are zero and skipped)
+          const int pmaxK = tri_pair_index(K - 1, K - 1) + 1, pmaxL = tri_pair_index(Lc - 1, Lc - 1) + 1;
           // (1) W'_j = sum_{i in miss(j)} f_i f_i^T (packed upper triangle of the 10-wide index: columns >= K of F are zero) per
           // entry thread of the G sweep's layout, then per unit: the unit's threads in thread order
           {
@@ -950,6 +951,7 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
             for (int t = tq; t < 2 * J; t += NT) segL[t] = *G(dc.seg + t);
 #pragma unroll
             for (int ch = 0; ch < (PD + 7) / 8; ++ch) {
+              if (ch * 8 >= pmaxK) break;
               bar_lds();
               if (ce) {
 #pragma unroll
@@ -972,6 +974,7 @@ __global__ __launch_bounds__(NT) void small_gibbs_kernel(const SmallLaunch* __re
           // (2) Am[(k <= k')][(l <= l')] = sum_j W'_j[(k k')] G_jl G_jl' on the f32 matrix cores: 4 x 4 tiles of 16 x 16, inner index j
           for (int tile = wave; tile < 16; tile += NT / 64) {
             const int ti = tile >> 2, tj = tile & 3;
+            if (16 * ti >= pmaxK || 16 * tj >= pmaxL) continue;
             const int pk = 16 * ti + (lane & 15), pl = 16 * tj + (lane & 15), jq = lane >> 4;
             int la = 0, lb = 0;
             tri_pair(pl < PD ? pl : 0, la, lb);

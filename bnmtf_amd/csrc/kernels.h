@@ -432,6 +432,9 @@ struct SmallLaunch {
   float* S_s;                  // samples [n_iter][K][L], or null
   double* expS;                // posterior sum [K][L], or null
 };
+// the S step's dense form (the K L x K L system in LDS, the chain on one wave: kernel_small.hip) takes the ranks the reference searches
+constexpr int kTriDenseK = 10;
+__host__ __device__ inline bool small_tri_dense(int K, int L) { return L > 0 && K <= kTriDenseK && L <= kTriDenseK; }
 size_t small_lds_bytes(int I, int J, int nt, int K = 0, int L = 0);  // LDS a block of nt threads needs for an I x J model (K, L: the tri-factorisation's ranks)
 void launch_small_gibbs(const SmallLaunch* dev_launches, int n_models, int em, int nt, size_t lds_bytes, hipStream_t st, bool tri = false);
 

@@ -229,6 +229,19 @@ def test_the_path_is_chosen_by_what_the_call_runs():
     assert small.is_small()
     small.run(3)
     assert "std_built=0" in small.describe()
+    # ranks above 10: the S step's sequential form (~2 us per entry of S) -- alone the multi-launch path's chain is several times faster,
+    # a batch that is worth the K L = 256 entries takes the one launch
+    wide = []
+    for seed in range(5):
+        np.random.seed(seed)
+        w = bnmtf_gibbs_optimised(Rs, Ms, 16, 16, PRI, seed=seed, verbose=False)
+        w.initialise('random', 'random')
+        wide.append(w)
+    assert not wide[0].is_small()
+    wide[0].run(2)
+    assert "std_built=1" in wide[0].describe()
+    bnmtf_amd.run_many(wide[1:], 2)
+    assert all("std_built=0" in w.describe() for w in wide[1:])
 
 
 def test_random_shapes_ranks_and_masks_agree_with_the_multi_launch_path():
