@@ -270,7 +270,8 @@ BNMTF_API int bnmtf_set_sweep_path(bnmtf_handle h, int fast);
 /* the one-launch path for small models, two- and three-factor (K, L <= 32, I, J <= 1024, factors within one CU's LDS; run() = one
  * launch, one block per model).  mode 1 (default): taken when it is the faster way to run the call -- always for the models of
  * 256- and 512-thread blocks, for the ones that fill a CU (1024-thread blocks) from three models per bnmf_gibbs_run_many call on
- * (two per bnmtf_gibbs_run_many call); 0: never (the multi-launch path); 2: always.  Same chain either way up to fp32 summation order.
+ * (two per bnmtf_gibbs_run_many call; a tri-factorisation with a rank above 10 -- the sequential form of its S step -- only in a batch of at
+ * least (K L + 50) / 80 models); 0: never (the multi-launch path); 2: always.  Same chain either way up to fp32 summation order.
  * bnmtf_is_small: would a bnmf_gibbs_run / bnmtf_gibbs_run of this handle alone take it? */
 BNMTF_API int bnmtf_set_small_path(bnmtf_handle h, int mode);
 /* the handle's communicator as it reports itself: kind 0 none (one GPU), 1 RCCL (ranks = ncclCommCount), 2 the in-process test
