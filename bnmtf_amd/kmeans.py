@@ -24,8 +24,9 @@ max_iterations = 200
 
 
 class KMeans(object):
-    def __init__(self, X, M, K, resolve_empty='singleton', *, device=0):
+    def __init__(self, X, M, K, resolve_empty='singleton', *, device=0, rng=None):
         self._device = 0 if device is None else int(device)
+        self._random = random if rng is None else rng           # the module's global stream (the reference's), or a `random.Random` of the caller's
         self._dh = None
         self.X = np.array(X, dtype=float)
         self.M = np.array(M, dtype=float)
@@ -44,11 +45,11 @@ class KMeans(object):
 
     def initialise(self, seed=None):
         if seed is not None:
-            random.seed(seed)
+            self._random.seed(seed)
         big = np.where(self.M > 0, self.X, np.inf); small = np.where(self.M > 0, self.X, -np.inf)
         self.mins, self.maxs = big.min(axis=0), small.max(axis=0)
         # a list, as in the reference: an entry may become a view of a row of X (see the header)
-        self.centroids = [np.array([random.uniform(self.mins[j], self.maxs[j]) for j in range(self.no_coordinates)]) for _ in range(self.K)]
+        self.centroids = [np.array([self._random.uniform(self.mins[j], self.maxs[j]) for j in range(self.no_coordinates)]) for _ in range(self.K)]
         self.cluster_assignments = -np.ones(self.no_points, dtype=int)
         self.mask_centroids = np.ones((self.K, self.no_coordinates))
         self._alias = [None] * self.K                    # centroid c is the row _alias[c] of X
@@ -110,7 +111,7 @@ class KMeans(object):
                     self._device_sums()                   # memberships changed: the sums of the clusters still to come
                     self._update_cluster(old)
                 else:
-                    self.centroids[c] = np.array([random.uniform(self.mins[j], self.maxs[j]) for j in range(self.no_coordinates)])
+                    self.centroids[c] = np.array([self._random.uniform(self.mins[j], self.maxs[j]) for j in range(self.no_coordinates)])
                     self._alias[c] = None
                     self.mask_centroids[c] = np.ones(self.no_coordinates)
             return
