@@ -97,11 +97,7 @@ class DeviceModel(object):
     def _rng(self):
         """Source of the initialisation draws: numpy.random's global stream for a single-GPU model (what the reference
         consumes, so numpy.random.seed() reproduces its initial factors); a RandomState seeded with the shared key for a
-        sharded model, so that every rank holds the same replicated U, V.  (`_rng_np`: a stream of this model's own -- the replica
-        pool builds the models of a batch side by side in threads, each from its job's seed: the same draws as under a global
-        `numpy.random.seed(seed)`.)"""
-        if getattr(self, "_rng_np", None) is not None:
-            return self._rng_np
+        sharded model, so that every rank holds the same replicated U, V."""
         if self._world == 1:
             return np.random
         if self._init_rs is None:

@@ -54,12 +54,12 @@ class bnmtf_gibbs_optimised(DeviceModel):
             self.G = self._rng().exponential(scale=1.0 / self.lambdaG)
         elif init_FG == 'kmeans':
             if self.verbose: print("Initialising F using KMeans.")
-            kmeans_F = KMeans(self.R, self.M, self.K, device=self._device, rng=getattr(self, "_rng_py", None))
+            kmeans_F = KMeans(self.R, self.M, self.K, device=self._device)
             kmeans_F.initialise()
             kmeans_F.cluster()
             self.F = kmeans_F.clustering_results + 0.2
             if self.verbose: print("Initialising G using KMeans.")
-            kmeans_G = KMeans(self.R.T, self.M.T, self.L, device=self._device, rng=getattr(self, "_rng_py", None))
+            kmeans_G = KMeans(self.R.T, self.M.T, self.L, device=self._device)
             kmeans_G.initialise()
             kmeans_G.cluster()
             self.G = kmeans_G.clustering_results + 0.2

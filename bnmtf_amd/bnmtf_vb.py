@@ -83,12 +83,12 @@ class bnmtf_vb_optimised(DeviceModel):
             self.muG = self._rng().exponential(scale=1.0 / self.lambdaG)
         elif init_FG == 'kmeans':
             if self.verbose: print("Initialising F using KMeans.")
-            kmeans_F = KMeans(self.R, self.M, self.K, device=self._device, rng=getattr(self, "_rng_py", None))
+            kmeans_F = KMeans(self.R, self.M, self.K, device=self._device)
             kmeans_F.initialise()
             kmeans_F.cluster()
             self.muF = kmeans_F.clustering_results
             if self.verbose: print("Initialising G using KMeans.")
-            kmeans_G = KMeans(self.R.T, self.M.T, self.L, device=self._device, rng=getattr(self, "_rng_py", None))
+            kmeans_G = KMeans(self.R.T, self.M.T, self.L, device=self._device)
             kmeans_G.initialise()
             kmeans_G.cluster()
             self.muG = kmeans_G.clustering_results

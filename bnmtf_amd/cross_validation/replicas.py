@@ -202,9 +202,8 @@ def _accepts(fn, name):
         return False
 
 
-def _build(job, shared, own_streams=False):
-    """The model of one job: constructed and initialised (the job's seeds set first).  own_streams: the job's seed goes into a NumPy
-    and a `random` stream of the model's own instead of the global ones -- the same draws, and several models can be built at once."""
+def _build(job, shared):
+    """The model of one job: constructed and initialised (the job's seeds set first)."""
     import random
     R = job["R"] if job.get("R") is not None else shared["R"]
     cls = job["classifier"]
@@ -214,13 +213,10 @@ def _build(job, shared, own_streams=False):
     if _accepts(cls.__init__, "verbose"):
         kw["verbose"] = False
     if job.get("seed") is not None:
-        if not own_streams:
-            np.random.seed(job["seed"] % (2 ** 32)); random.seed(job["seed"])
+        np.random.seed(job["seed"] % (2 ** 32)); random.seed(job["seed"])
         if _accepts(cls.__init__, "seed"):
             kw["seed"] = job["seed"]
     model = cls(R, np.asarray(job["M"], dtype=float), *job["args"], **kw)
-    if own_streams:
-        model._rng_np = np.random.RandomState(job["seed"] % (2 ** 32)); model._rng_py = random.Random(job["seed"])
     if shared.get("_small_path_tri") is not None and getattr(model, "L", 0) and hasattr(model, "set_small_path"):
         model.set_small_path(shared["_small_path_tri"])
     model.initialise(**job["init"])
@@ -267,15 +263,7 @@ def fit_models(jobs, shared):
     that ask for the same run (iterations, expectation) go to the device as ONE call -- small models share a launch, one
     block each --, then every model is scored.  Results in job order, each what fit_model(job) returns."""
     from ..batch import run_many, takes
-    # seeded jobs of the library's own classes: built side by side (construction and initialisation are device round trips --
-    # k-means, bnmtf_create, beta_s -- between short pieces of NumPy; every model draws from streams of its own, seeded as the
-    # global ones would have been)
-    if len(jobs) > 1 and all(j.get("seed") is not None and getattr(j["classifier"], "__module__", "").startswith("bnmtf_amd.") for j in jobs):
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
-            models = list(ex.map(lambda j: _build(j, shared, own_streams=True), jobs))
-    else:
-        models = [_build(j, shared) for j in jobs]
+    models = [_build(j, shared) for j in jobs]
     kws = [_run_kw(j, m) for j, m in zip(jobs, models)]
     groups = {}
     for i, (m, (kw, _)) in enumerate(zip(models, kws)):

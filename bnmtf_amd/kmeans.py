@@ -24,9 +24,8 @@ max_iterations = 200
 
 
 class KMeans(object):
-    def __init__(self, X, M, K, resolve_empty='singleton', *, device=0, rng=None):
+    def __init__(self, X, M, K, resolve_empty='singleton', *, device=0):
         self._device = 0 if device is None else int(device)
-        self._random = random if rng is None else rng           # the module's global stream (the reference's), or a `random.Random` of the caller's
         self._dh = None
         self.X = np.array(X, dtype=float)
         self.M = np.array(M, dtype=float)
@@ -35,7 +34,7 @@ class KMeans(object):
         assert len(self.X.shape) == 2, "Input matrix X is not a two-dimensional array, but instead %s-dimensional." % len(self.X.shape)
         assert self.X.shape == self.M.shape, "Input matrix X is not of the same size as the indicator matrix M: %s and %s respectively." % (self.X.shape, self.M.shape)
         assert self.K > 0, "K should be greater than 0."
-        self.no_unique_points = len(set(tuple(l) for l in self.X.tolist()))
+        self._X_as_given = self.X                        # (no_unique_points: counted when an empty cluster first asks -- a model search builds two of these per model)
         for i, c in enumerate(self.M.sum(axis=1)):
             assert c != 0, "Fully unobserved row in X, row %s." % i
         keep = self.M.sum(axis=0) > 0                    # unobserved columns do not influence the clustering
@@ -43,13 +42,20 @@ class KMeans(object):
         (self.no_points, self.no_coordinates) = self.X.shape
         self.distances = np.zeros(self.no_points)
 
+    @property
+    def no_unique_points(self):
+        """kmeans.py:47 (the reference counts in its constructor; here: the first time the empty-cluster rule needs the number)."""
+        if getattr(self, "_no_unique_points", None) is None:
+            self._no_unique_points = len(set(tuple(l) for l in self._X_as_given.tolist()))
+        return self._no_unique_points
+
     def initialise(self, seed=None):
         if seed is not None:
-            self._random.seed(seed)
+            random.seed(seed)
         big = np.where(self.M > 0, self.X, np.inf); small = np.where(self.M > 0, self.X, -np.inf)
         self.mins, self.maxs = big.min(axis=0), small.max(axis=0)
         # a list, as in the reference: an entry may become a view of a row of X (see the header)
-        self.centroids = [np.array([self._random.uniform(self.mins[j], self.maxs[j]) for j in range(self.no_coordinates)]) for _ in range(self.K)]
+        self.centroids = [np.array([random.uniform(self.mins[j], self.maxs[j]) for j in range(self.no_coordinates)]) for _ in range(self.K)]
         self.cluster_assignments = -np.ones(self.no_points, dtype=int)
         self.mask_centroids = np.ones((self.K, self.no_coordinates))
         self._alias = [None] * self.K                    # centroid c is the row _alias[c] of X
@@ -111,7 +117,7 @@ class KMeans(object):
                     self._device_sums()                   # memberships changed: the sums of the clusters still to come
                     self._update_cluster(old)
                 else:
-                    self.centroids[c] = np.array([self._random.uniform(self.mins[j], self.maxs[j]) for j in range(self.no_coordinates)])
+                    self.centroids[c] = np.array([random.uniform(self.mins[j], self.maxs[j]) for j in range(self.no_coordinates)])
                     self._alias[c] = None
                     self.mask_centroids[c] = np.ones(self.no_coordinates)
             return
