@@ -52,6 +52,9 @@ class ReplicaError(Exception):
         return str(self).split("\n", 1)[0]
 
 
+SMALL_TRI_DENSE_RANK = 10      # the one-launch kernel's dense S step (csrc/kernel_small.hip: small_tri_dense): K, L <= 10
+
+
 class ReplicaPool(object):
     def __init__(self, devices=None, shared=None, batched=False):
         """devices: list of device ordinals, one worker each (repeat an ordinal to run several models on one GPU at
@@ -217,9 +220,15 @@ def _build(job, shared):
         if _accepts(cls.__init__, "seed"):
             kw["seed"] = job["seed"]
     model = cls(R, np.asarray(job["M"], dtype=float), *job["args"], **kw)
-    if shared.get("_small_path_tri") is not None and getattr(model, "L", 0) and hasattr(model, "set_small_path"):
-        model.set_small_path(shared["_small_path_tri"])
     model.initialise(**job["init"])
+    # (after initialise: set_small_path creates the device handle, and a model built without a seed draws its Philox key from
+    # NumPy's global stream at that moment -- the initial factors must see the same stream as on the single-slot path.)
+    # Forced only where it was measured to pay: the DENSE S step of the one-launch kernel (K, L <= 10: 9.4 -> 7.5 s for the greedy
+    # search's job on four slots).  Wider ranks walk S sequentially on the block (K = L = 32: 0.6 k it/s against 4.3 k alone on the
+    # multi-launch path): they keep the library's own rule ('auto': small_wanted's batch threshold).
+    if (shared.get("_small_path_tri") is not None and getattr(model, "L", 0) and hasattr(model, "set_small_path")
+            and max(int(model.K), int(model.L)) <= SMALL_TRI_DENSE_RANK):
+        model.set_small_path(shared["_small_path_tri"])
     return model
 
 

@@ -1411,21 +1411,31 @@ int bnmf_gibbs_run_many(const bnmtf_handle* hs, int n_models, int n_iter, int up
   if (n_models < 0 || n_iter < 0) { set_error("negative count"); return BNMTF_EINVAL; }
   if (n_models == 0 || n_iter == 0) return BNMTF_OK;
   if (update < 0 || update > BNMTF_UPDATE_ICM) { set_error("unknown update rule"); return BNMTF_EINVAL; }
+  for (int b = 0; b < n_models; ++b) if (hs[b]->L != 0) { set_error("bnmf_gibbs_run_many on a BNMTF handle (model %d)", b); return BNMTF_ESTATE; }
   // models of the one-launch path go down in one grid per device; the others run one after the other
   std::vector<bnmtf_model*> batch; std::vector<SmallOut> outs;
   auto out_of = [&](int b) { return SmallOut{U_outs ? U_outs[b] : nullptr, V_outs ? V_outs[b] : nullptr, tau_outs ? tau_outs[b] : nullptr,
                                              perf_outs ? perf_outs[b] : nullptr, times_outs ? times_outs[b] : nullptr,
                                              U_final ? U_final[b] : nullptr, V_final ? V_final[b] : nullptr, tau_final ? tau_final[b] : nullptr}; };
   std::vector<char> taken(n_models, 0);
-  auto peers = [&](int b) {                   // models of the one-launch kind on model b's device, b included
+  // models on model b's device that actually JOIN the launch, b included: the rule of a CU-filling or wide-rank model depends on
+  // the batch size (small_wanted), so the count is taken to its fixed point -- a model that would run alone on the multi-launch
+  // path does not make a "batch" for the others (round 5's advice)
+  auto peers = [&](int b) {
     int n = 0;
     for (int c = 0; c < n_models; ++c) n += (hs[c]->small && hs[c]->small_mode != 0 && hs[c]->device == hs[b]->device) ? 1 : 0;
+    for (int round = 0; round < n_models && n > 0; ++round) {
+      int m = 0;
+      for (int c = 0; c < n_models; ++c) m += (hs[c]->device == hs[b]->device && small_wanted(hs[c], n)) ? 1 : 0;
+      if (m == n) break;
+      n = m;
+    }
     return n;
   };
   for (int b = 0; b < n_models; ++b) {
     if (taken[b]) continue;
     const int np = peers(b);
-    if (!small_wanted(hs[b], np) || hs[b]->L != 0) {
+    if (!small_wanted(hs[b], np)) {
       const SmallOut o = out_of(b);
       CHK(bnmf_gibbs_run(hs[b], n_iter, update, o.U, o.V, o.tau, o.perf, o.times));
       if (o.U_final || o.V_final || o.tau_final) CHK(bnmf_get_state(hs[b], o.U_final, o.V_final, o.tau_final));

@@ -1,0 +1,201 @@
+// Test infrastructure (CPU box only): drives the C ABI of the library's HOST side, linked against hip_stub.cpp instead of the
+// HIP runtime, under AddressSanitizer + UBSan (`make asan`) or ThreadSanitizer (`make tsan`).  Kernels do not run, so no number
+// that comes back means anything; what is checked is the host code the calls go through: bnmtf_create's layout passes (worker
+// threads, slot tables, shard ranges, the hand-over table sizes), the arenas and pools of created / destroyed models, every
+// host<->"device" copy's extent (device memory is heap memory here), the sample ring of run(), run_many's batching, and the
+// in-process multi-rank rendezvous of comm.hip with one host thread per rank.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <thread>
+#include <vector>
+
+#include "bnmtf_hip.h"
+
+extern "C" long hipstub_launches();
+extern "C" long hipstub_live_allocs();
+
+#define OK(expr)                                                                                     \
+  do {                                                                                               \
+    const int rc_ = (expr);                                                                          \
+    if (rc_ != BNMTF_OK) { fprintf(stderr, "FAILED %s -> %d (%s)\n", #expr, rc_, bnmtf_last_error()); exit(2); } \
+  } while (0)
+#define EXPECT_ERR(expr)                                                                             \
+  do {                                                                                               \
+    const int rc_ = (expr);                                                                          \
+    if (rc_ == BNMTF_OK) { fprintf(stderr, "expected an error: %s\n", #expr); exit(2); }             \
+  } while (0)
+
+struct Data {
+  int I, J;
+  std::vector<float> R;
+  std::vector<uint8_t> M;
+};
+static Data make_data(int I, int J, double missing, unsigned seed) {
+  Data d{I, J, std::vector<float>((size_t)I * J), std::vector<uint8_t>((size_t)I * J, 1)};
+  std::mt19937 g(seed);
+  std::uniform_real_distribution<float> u(0.f, 10.f);
+  std::uniform_real_distribution<double> p(0.0, 1.0);
+  for (auto& x : d.R) x = u(g);
+  for (auto& m : d.M) m = p(g) < missing ? 0 : 1;
+  for (int i = 0; i < I; ++i) d.M[(size_t)i * J + (i % J)] = 1;          // no empty row ...
+  for (int j = 0; j < J; ++j) d.M[(size_t)(j % I) * J + j] = 1;          // ... or column
+  return d;
+}
+
+static bnmtf_handle create(const Data& d, int K, int L, int rank, int world, const uint8_t* cid, uint64_t seed = 7) {
+  std::vector<double> lr((size_t)d.I * K, 0.1), lc((size_t)d.J * (L ? L : K), 0.1), ls((size_t)K * (L ? L : 1), 0.1);
+  bnmtf_problem p;
+  memset(&p, 0, sizeof p);
+  p.I = d.I; p.J = d.J; p.K = K; p.L = L; p.R = d.R.data(); p.M = d.M.data();
+  p.lambda_rows = lr.data(); p.lambda_cols = lc.data(); p.lambda_S = L ? ls.data() : nullptr;
+  p.alpha = p.beta = 1.0; p.seed = seed; p.device = 0; p.rank = rank; p.world = world; p.comm_id = cid;
+  bnmtf_handle h = nullptr;
+  OK(bnmtf_create(&p, &h));
+  return h;
+}
+
+static void bnmf_round_trip(const Data& d, int K, int iters, bool samples) {
+  bnmtf_handle h = create(d, K, 0, 0, 1, nullptr);
+  std::vector<double> U((size_t)d.I * K, 1.0), V((size_t)d.J * K, 1.0);
+  OK(bnmf_set_state(h, U.data(), V.data(), 1.0));
+  uint64_t total = 0;
+  std::vector<uint32_t> row(d.I), col(d.J);
+  OK(bnmtf_omega_counts(h, &total, row.data(), col.data()));
+  uint64_t expect = 0;
+  for (uint8_t m : d.M) expect += m;
+  if (total != expect) { fprintf(stderr, "omega count %llu != %llu\n", (unsigned long long)total, (unsigned long long)expect); exit(2); }
+  std::vector<float> Uo, Vo;
+  if (samples) { Uo.resize((size_t)iters * d.I * K); Vo.resize((size_t)iters * d.J * K); }
+  std::vector<double> tau(iters), perf((size_t)iters * 3), times(iters);
+  OK(bnmf_gibbs_run(h, iters, BNMTF_UPDATE_DRAW, samples ? Uo.data() : nullptr, samples ? Vo.data() : nullptr, tau.data(), perf.data(), times.data()));
+  OK(bnmf_gibbs_run(h, 2, BNMTF_UPDATE_MODE, nullptr, nullptr, nullptr, nullptr, nullptr));
+  std::vector<double> num(d.I), tp(d.I);
+  OK(bnmf_cond_params(h, 0, K - 1, num.data(), tp.data()));
+  EXPECT_ERR(bnmf_cond_params(h, 0, K, num.data(), tp.data()));
+  OK(bnmtf_set_expectation(h, 1, 2));
+  OK(bnmf_gibbs_run(h, 5, BNMTF_UPDATE_DRAW, nullptr, nullptr, nullptr, nullptr, nullptr));
+  double t = 0; uint64_t cnt = 0;
+  OK(bnmtf_get_expectation(h, U.data(), nullptr, V.data(), &t, &cnt));
+  OK(bnmf_get_state(h, U.data(), V.data(), &t));
+  char buf[2048];
+  OK(bnmtf_describe(h, buf, sizeof buf));
+  OK(bnmtf_destroy(h));
+}
+
+static void vb_round_trip(const Data& d, int K) {
+  bnmtf_handle h = create(d, K, 0, 0, 1, nullptr);
+  std::vector<double> a((size_t)d.I * K, 1.0), b((size_t)d.J * K, 1.0);
+  OK(bnmf_vb_set_state(h, a.data(), a.data(), a.data(), a.data(), b.data(), b.data(), b.data(), b.data(), 1.0));
+  std::vector<double> et(4), perf(12), times(4), elbo(40);
+  OK(bnmf_vb_run(h, 4, et.data(), perf.data(), elbo.data(), times.data()));
+  double e = 0;
+  OK(bnmf_vb_exp_square_diff(h, &e));
+  OK(bnmtf_destroy(h));
+}
+
+static void tri_round_trip(const Data& d, int K, int L, int iters) {
+  bnmtf_handle h = create(d, K, L, 0, 1, nullptr);
+  std::vector<double> F((size_t)d.I * K, 1.0), S((size_t)K * L, 1.0), G((size_t)d.J * L, 1.0);
+  OK(bnmtf_set_state(h, F.data(), S.data(), G.data(), 1.0));
+  std::vector<float> Fo((size_t)iters * d.I * K), So((size_t)iters * K * L), Go((size_t)iters * d.J * L);
+  std::vector<double> tau(iters), perf((size_t)iters * 3);
+  OK(bnmtf_gibbs_run(h, iters, BNMTF_UPDATE_DRAW, Fo.data(), So.data(), Go.data(), tau.data(), perf.data(), nullptr));
+  double t;
+  OK(bnmtf_get_state(h, F.data(), S.data(), G.data(), &t));
+  OK(bnmtf_destroy(h));
+}
+
+// the one-launch path's batch entry points: models of different sizes, a duplicate handle (must be refused), a wrong-kind handle
+static void batches() {
+  std::vector<Data> ds;
+  std::vector<bnmtf_handle> hs;
+  for (int i = 0; i < 5; ++i) {
+    ds.push_back(make_data(60 + 17 * i, 50 + 11 * i, 0.1, 100 + i));
+  }
+  for (int i = 0; i < 5; ++i) {
+    hs.push_back(create(ds[i], 4 + i, 0, 0, 1, nullptr, 11 + i));
+    std::vector<double> U((size_t)ds[i].I * (4 + i), 1.0), V((size_t)ds[i].J * (4 + i), 1.0);
+    OK(bnmf_set_state(hs.back(), U.data(), V.data(), 1.0));
+  }
+  OK(bnmf_gibbs_run_many(hs.data(), (int)hs.size(), 6, BNMTF_UPDATE_DRAW, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+  std::vector<bnmtf_handle> dup = {hs[0], hs[1], hs[0]};
+  (void)bnmf_gibbs_run_many(dup.data(), 3, 2, BNMTF_UPDATE_DRAW, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);   // refused when both take the one-launch path
+  Data dt = make_data(70, 60, 0.1, 5);
+  bnmtf_handle tri = create(dt, 4, 3, 0, 1, nullptr);
+  std::vector<double> F(70 * 4, 1.0), S(12, 1.0), G(60 * 3, 1.0);
+  OK(bnmtf_set_state(tri, F.data(), S.data(), G.data(), 1.0));
+  std::vector<bnmtf_handle> mixed = {hs[0], tri};
+  EXPECT_ERR(bnmf_gibbs_run_many(mixed.data(), 2, 2, BNMTF_UPDATE_DRAW, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+  EXPECT_ERR(bnmtf_gibbs_run_many(mixed.data(), 2, 2, BNMTF_UPDATE_DRAW, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+  std::vector<bnmtf_handle> tris = {tri};
+  OK(bnmtf_gibbs_run_many(tris.data(), 1, 3, BNMTF_UPDATE_DRAW, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+  OK(bnmtf_destroy(tri));
+  for (auto h : hs) OK(bnmtf_destroy(h));
+  // pooled arenas: create / destroy in a loop, as a model search does
+  for (int i = 0; i < 6; ++i) {
+    bnmtf_handle h = create(ds[i % 5], 5, 0, 0, 1, nullptr);
+    OK(bnmtf_destroy(h));
+  }
+}
+
+// `world` ranks of this process, one thread each, joined by the in-process transport (communicator id "BNMTFLOC...")
+static void sharded(const Data& d, int K, int L, int world, const char* token, int iters) {
+  uint8_t cid[128];
+  memset(cid, 0, sizeof cid);
+  snprintf(reinterpret_cast<char*>(cid), sizeof cid, "BNMTFLOC%s", token);
+  std::vector<std::thread> ts;
+  std::vector<int> rc(world, 0);
+  for (int r = 0; r < world; ++r)
+    ts.emplace_back([&, r] {
+      bnmtf_handle h = create(d, K, L, r, world, cid);
+      if (L == 0) {
+        std::vector<double> U((size_t)d.I * K, 1.0), V((size_t)d.J * K, 1.0);
+        OK(bnmf_set_state(h, U.data(), V.data(), 1.0));
+        std::vector<float> Uo((size_t)iters * d.I * K), Vo((size_t)iters * d.J * K);
+        OK(bnmf_gibbs_run(h, iters, BNMTF_UPDATE_DRAW, Uo.data(), Vo.data(), nullptr, nullptr, nullptr));
+        OK(bnmf_vb_set_state(h, U.data(), U.data(), U.data(), U.data(), V.data(), V.data(), V.data(), V.data(), 1.0));
+        OK(bnmf_vb_run(h, 2, nullptr, nullptr, nullptr, nullptr));
+      } else {
+        std::vector<double> F((size_t)d.I * K, 1.0), S((size_t)K * L, 1.0), G((size_t)d.J * L, 1.0);
+        OK(bnmtf_set_state(h, F.data(), S.data(), G.data(), 1.0));
+        OK(bnmtf_gibbs_run(h, iters, BNMTF_UPDATE_MODE, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+      }
+      OK(bnmtf_destroy(h));
+      rc[r] = 1;
+    });
+  for (auto& t : ts) t.join();
+  for (int r = 0; r < world; ++r) if (!rc[r]) { fprintf(stderr, "rank %d did not finish\n", r); exit(2); }
+}
+
+int main(int argc, char** argv) {
+  const bool quick = argc > 1 && !strcmp(argv[1], "quick");
+  int n = 0;
+  OK(bnmtf_device_count(&n));
+  int64_t first, count;
+  for (int w = 1; w <= 8; ++w) for (int r = 0; r < w; ++r) OK(bnmtf_shard_range(1000 + w, r, w, &first, &count));
+  EXPECT_ERR(bnmtf_shard_range(10, 3, 2, &first, &count));
+
+  // small models (the one-launch path's arena), then shapes that take the multi-launch structures: the 8-wave and -- with
+  // enough units -- the 16-wave slot layout, the two-chunk inner extent, a mask with rows the on-chip kernels refuse
+  bnmf_round_trip(make_data(100, 80, 0.1, 1), 10, 6, true);
+  bnmf_round_trip(make_data(640, 512, 0.12, 2), 24, 9, true);            // sample ring: more iterations than its depth
+  bnmf_round_trip(make_data(1, 40, 0.0, 3), 3, 3, true);
+  bnmf_round_trip(make_data(40, 1, 0.0, 4), 1, 3, false);
+  bnmf_round_trip(make_data(300, 200, 0.9, 5), 8, 3, true);              // 90 % missing
+  vb_round_trip(make_data(515, 389, 0.12, 6), 40);
+  tri_round_trip(make_data(100, 80, 0.1, 7), 5, 5, 4);
+  tri_round_trip(make_data(400, 300, 0.1, 8), 32, 17, 3);
+  batches();
+  sharded(make_data(640, 512, 0.12, 9), 24, 0, 2, "a2", 5);
+  sharded(make_data(515, 389, 0.12, 10), 40, 0, 3, "a3", 5);
+  sharded(make_data(300, 260, 0.1, 11), 8, 6, 2, "t2", 3);
+  if (!quick) {
+    bnmf_round_trip(make_data(6200, 6144, 0.1, 12), 64, 3, false);       // >= 192 blocks of 32 units: the 16-wave layout + hand-over tables
+    bnmf_round_trip(make_data(700, 12288, 0.1, 13), 16, 2, false);       // inner extent of two LDS panels for the rows direction
+    sharded(make_data(2048, 2048, 0.1, 14), 64, 0, 8, "a8", 2);
+  }
+  printf("sanitize driver: ok (%ld stub launches, %ld live stub allocations)\n", hipstub_launches(), hipstub_live_allocs());
+  return 0;
+}

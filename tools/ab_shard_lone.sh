@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 for v in new prev new prev; do
   if [ $v = prev ]; then export BNMTF_LIB=$repo/tools/lib_prev.so; else unset BNMTF_LIB; fi
   for rows in 1024 2048; do
-    rm -rf /tmp/abs_$v_$rows
+    rm -rf /tmp/abs_${v}_$rows
     rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abs_${v}_$rows -o s -- python3 $repo/tools/shard_shape_times.py $rows > /dev/null 2>&1
     f=$(find /tmp/abs_${v}_$rows -name "s_kernel_stats.csv" | head -1)
     python3 -c "
