@@ -207,19 +207,9 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
     const uint32_t kNone = 0xFFFFFFFFu;
     std::vector<int> Eu(d.n, 0);
     std::vector<std::vector<uint32_t>> lanes((size_t)d.n * 32 * nch);     // per unit, per chunk, per lane: slot contents (kNone = empty), chunk-local inner indices
-    parallel_chunks(d.n, 64, [&](int ua, int ub) {
-    std::vector<std::vector<uint32_t>> over(32);
-    for (int ul = ua; ul < ub; ++ul) {
-      int ehalf = 0;
-      for (int ch = 0; ch < nch; ++ch) {
-      std::vector<uint32_t>* L = &lanes[((size_t)ul * nch + ch) * 32];
-      const uint32_t lo = ch == 0 ? 0u : (uint32_t)d.mh, hi = (nch == 2 && ch == 0) ? (uint32_t)d.mh : 0xFFFFFFFFu;
-      size_t cnt = 0;
-      {   // one allocation per lane instead of a doubling chain (32 lanes x 8192 units: the layout pass was mostly malloc)
-        const size_t guess = (size_t)(miss_end(ul) - miss_begin(ul)) / (32 * (size_t)nch) + 8;
-        for (int r = 0; r < 32; ++r) L[r].reserve(guess);
-      }
-      for (const uint32_t* pj = miss_begin(ul); pj != miss_end(ul); ++pj) { const uint32_t j = *pj; if (j >= lo && j < hi) { L[(j - lo) & 31].push_back(j - lo); ++cnt; } }
+    // E slots per lane for the 32 lane lists of one half wave (L[r]: the entries of residue class r, `cnt` in all), balanced:
+    // E = ceil(cnt / 32) rounded up to even, the entries of over-full classes parked in lanes with room (see above)
+    auto balance_lanes = [&](std::vector<uint32_t>* L, size_t cnt, std::vector<std::vector<uint32_t>>& over) -> int {
       int emax = 0;
       for (int r = 0; r < 32; ++r) emax = std::max(emax, (int)L[r].size());
       int E = std::max(2, (emax + 1) & ~1);
@@ -252,6 +242,22 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
             for (int r = 0; r < 32; ++r) if (!over[r].empty()) { L[lane][row] = over[r].back(); over[r].pop_back(); --nover; break; }
           }
       }
+      return E;
+    };
+    parallel_chunks(d.n, 64, [&](int ua, int ub) {
+    std::vector<std::vector<uint32_t>> over(32);
+    for (int ul = ua; ul < ub; ++ul) {
+      int ehalf = 0;
+      for (int ch = 0; ch < nch; ++ch) {
+      std::vector<uint32_t>* L = &lanes[((size_t)ul * nch + ch) * 32];
+      const uint32_t lo = ch == 0 ? 0u : (uint32_t)d.mh, hi = (nch == 2 && ch == 0) ? (uint32_t)d.mh : 0xFFFFFFFFu;
+      size_t cnt = 0;
+      {   // one allocation per lane instead of a doubling chain (32 lanes x 8192 units: the layout pass was mostly malloc)
+        const size_t guess = (size_t)(miss_end(ul) - miss_begin(ul)) / (32 * (size_t)nch) + 8;
+        for (int r = 0; r < 32; ++r) L[r].reserve(guess);
+      }
+      for (const uint32_t* pj = miss_begin(ul); pj != miss_end(ul); ++pj) { const uint32_t j = *pj; if (j >= lo && j < hi) { L[(j - lo) & 31].push_back(j - lo); ++cnt; } }
+      const int E = balance_lanes(L, cnt, over);
       ehalf = std::max(ehalf, E);
       }
       Eu[ul] = nch * ehalf;                  // two chunks: each gets half of the unit's slot rows (a multiple of 4 in all)
@@ -377,6 +383,64 @@ static int build_dir(Dir& d, int nglob, int m, int W, int rank, int world, const
         HIPCHK(hipMemcpy(d.f_row_blk, row_blk.data(), row_blk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
       }
     }
+    // ---- the unit-per-wave layout (kernel_sweep_unit.hip, round 6): few units per CU -- a shard of a multi-GPU run, a small
+    // problem.  A pair's two halves belong to the SAME unit: residue class r of the unit's missing entries is dealt in turn to
+    // lanes r and r + 32 (each half of a 64-lane LDS read touches 32 distinct banks), each half balanced like a 32-lane unit.
+    // Pair p = local unit p (no sorting: a block's waves do not share slot work).  Beside the layout above (the variational
+    // sweeps keep it), a few MB at these sizes.
+    d.uw_ok = false;
+    // (a test that forces another block shape -- BNMTF_WIDE, BNMTF_FAST_NW -- gets that shape; BNMTF_UNIT=0 switches this one off)
+    if (d.n > 0 && d.n <= kUnitMaxUnits && nch == 1 && d.pair_ok && sweep_unit_supported(d.KP, d.pw) && !getenv("BNMTF_WIDE") && !getenv("BNMTF_FAST_NW") &&
+        !(getenv("BNMTF_UNIT") && atoi(getenv("BNMTF_UNIT")) == 0)) {
+      std::vector<std::vector<uint32_t>> ul((size_t)d.n * 64);
+      std::vector<uint32_t> uE(d.n, 0u), uB(d.n, 0u);
+      parallel_chunks(d.n, 64, [&](int ua, int ub) {
+        std::vector<std::vector<uint32_t>> over(32);
+        for (int u = ua; u < ub; ++u) {
+          std::vector<uint32_t>* L = &ul[(size_t)u * 64];
+          size_t cnt[2] = {0, 0};
+          uint8_t turn[32] = {};
+          for (const uint32_t* pj = miss_begin(u); pj != miss_end(u); ++pj) {
+            const int r = (int)(*pj & 31u), hh = turn[r]; turn[r] ^= 1;
+            L[hh * 32 + r].push_back(*pj); ++cnt[hh];
+          }
+          const int e0 = balance_lanes(L, cnt[0], over), e1 = balance_lanes(L + 32, cnt[1], over);
+          uE[u] = (uint32_t)std::max(e0, e1);
+        }
+      });
+      size_t rows = 0; uint32_t emax = 0;
+      for (int u = 0; u < d.n; ++u) { uB[u] = (uint32_t)rows; rows += uE[u]; emax = std::max(emax, uE[u]); }
+      if ((int)emax <= kUnitMaxSlots) {
+        std::vector<uint32_t> o16(std::max<size_t>(rows / 2, 1) * 64, 0);
+        parallel_chunks(d.n, 64, [&](int ua, int ub) {
+          for (int u = ua; u < ub; ++u)
+            for (uint32_t sidx = 0; sidx < uE[u]; ++sidx)
+              for (int l = 0; l < 64; ++l) {
+                const auto& lst = ul[(size_t)u * 64 + l];
+                uint32_t v = (uint32_t)d.mz + (uint32_t)(l & 31);
+                if (sidx < lst.size() && lst[sidx] != kNone) v = lst[sidx];
+                uint32_t& w = o16[((size_t)(uB[u] + sidx) / 2) * 64 + l];
+                w = ((uB[u] + sidx) & 1u) ? (w & 0xFFFFu) | (v << 16) : (w & 0xFFFF0000u) | v;
+              }
+        });
+        std::vector<int> um((size_t)d.n * 2);
+        for (int u = 0; u < d.n; ++u) um[2 * u] = um[2 * u + 1] = u;
+        CHK(dalloc(&d.u_unit_map, um.size(), false));
+        HIPCHK(hipMemcpy(d.u_unit_map, um.data(), um.size() * sizeof(int), hipMemcpyHostToDevice));
+        CHK(dalloc(&d.u_pair_E, uE.size(), false));
+        HIPCHK(hipMemcpy(d.u_pair_E, uE.data(), uE.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        CHK(dalloc(&d.u_pair_base, uB.size(), false));
+        HIPCHK(hipMemcpy(d.u_pair_base, uB.data(), uB.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        CHK(dalloc(&d.u_off16, o16.size(), false));
+        HIPCHK(hipMemcpy(d.u_off16, o16.data(), o16.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        d.u_nw = d.n <= 4 * 256 ? 4 : 8;
+        if (const char* e = getenv("BNMTF_UNIT_NW")) d.u_nw = atoi(e) == 8 ? 8 : 4;
+        d.u_emax = (int)emax;
+        d.uw_ok = true;
+        d.stats_blocks = std::max(d.stats_blocks, (d.n + d.u_nw - 1) / d.u_nw + 2);
+      }
+      laps.lap("    layout: unit-per-wave tables");
+    }
     CHK(dalloc(&d.stats, (size_t)d.stats_blocks * 4));
     laps.lap("    layout: tables uploaded");
   }
@@ -460,6 +524,7 @@ static void free_dir(Dir& d) {
   if (d.ev_gram_all) (void)hipEventDestroy(d.ev_gram_all);
   dfree(d.XT2); dfree(d.Cpart); dfree(d.spart); dfree(d.s2part); dfree(d.f_unit_map); dfree(d.f_pair_E);
   dfree(d.f_pair_base); dfree(d.f_off); dfree(d.f_off16); dfree(d.stats); dfree(d.f_gen_units);
+  dfree(d.u_unit_map); dfree(d.u_pair_E); dfree(d.u_pair_base); dfree(d.u_off16);
   dfree(d.vb_stats);
   dfree(d.ho_in); dfree(d.ho_out); dfree(d.ho_pk); dfree(d.ho_region_ofs); dfree(d.ho_region); dfree(d.f_row_blk);
   dfree(d.mu); dfree(d.tauq); dfree(d.var); dfree(d.S2); dfree(d.S2T); dfree(d.XS); dfree(d.vb_asq); dfree(d.vb_vsq); dfree(d.mbits); dfree(d.XB); dfree(d.mslabs); dfree(d.xb_umax); dfree(d.xb_cexp); dfree(d.xb_mpart); dfree(d.numer); dfree(d.taup);
@@ -644,12 +709,28 @@ static void set_handover(bnmtf_model* h, Dir& d, const Dir& other, FastArgs& f, 
 static void enqueue_sweep(bnmtf_model* h, Dir& d, const Dir& other, SweepArgs& s, bool want_stats) {
   s.unit_list = nullptr;
   h->last_sweep_fast = false;
+  if (h->use_fast && d.uw_ok && other.X && s.cond_k < 0 && s.mode != kSweepVB && !s.cov_S && !s.order && (!h->ho_enabled || h->uw_force)) {
+    // few units per CU: one unit per wave (kernel_sweep_unit.hip); every unit of the direction (a layout with a unit beyond
+    // kFastMaxSlots slots per lane is not built)
+    FastArgs f;
+    memset(&f, 0, sizeof(f));
+    f.unit_map = d.u_unit_map; f.pair_E = d.u_pair_E; f.pair_base = d.u_pair_base; f.off16 = d.u_off16;
+    f.npairs = d.n; f.mz = d.mz; f.pw = d.pw; f.nw = d.u_nw; f.nch = 1;
+    f.XoT = other.XT; f.ldT_o = other.ldT; f.Xo = other.X; f.Xo_rows = other.nglob;
+    f.stats = want_stats ? d.stats : nullptr;
+    SweepArgs s2 = s;
+    s2.acc = nullptr;
+    if (h->ho_active) { d.ho_filled = false; }        // (q is not handed over by this shape: the next reader of a region rebuilds)
+    launch_sweep_unit(s2, f, h->stream);
+    h->last_sweep_fast = true;
+    return;
+  }
   if (h->use_fast && d.fast_ok && s.cond_k < 0 && s.mode != kSweepVB && (d.nch == 2 || sweep_fast_supported(d.KP, d.pw))) {
     FastArgs f;
     f.unit_map = d.f_unit_map; f.pair_E = d.f_pair_E; f.pair_base = d.f_pair_base; f.off = d.f_off;
     f.npairs = d.f_npairs; f.mz = d.mz; f.pw = d.nch == 2 ? d.pw_chunk : d.pw; f.nw = d.f_nw;
     f.nch = d.nch; f.mh = d.mh; f.pw1 = d.pw1; f.twin = d.use_twin ? 1 : 0;
-    f.XoT = other.XT; f.ldT_o = other.ldT; f.XoT2 = other.XT2; f.ld2_o = other.ldT;
+    f.XoT = other.XT; f.ldT_o = other.ldT; f.XoT2 = other.XT2; f.ld2_o = other.ldT; f.Xo = other.X; f.Xo_rows = other.nglob;
     f.stats = want_stats ? d.stats : nullptr;
     SweepArgs s2 = s;
     s2.acc = nullptr;
@@ -1086,6 +1167,7 @@ static int build_standard(bnmtf_model* h, const double* lambda_S, const uint8_t*
     const auto t_ho0 = std::chrono::steady_clock::now();
     if (want && build_handover(h, h->rows, h->cols) && build_handover(h, h->cols, h->rows)) h->rows.ho_ready = h->cols.ho_ready = h->ho_enabled = true;
     if (const char* r = getenv("BNMTF_HANDOVER_REFRESH")) h->ho_refresh = (uint64_t)std::max(1, atoi(r));
+    if (const char* u = getenv("BNMTF_UNIT")) h->uw_force = atoi(u) == 1;      // A/B switch: the unit-per-wave shape also where q could be handed over
     if (getenv("BNMTF_CREATE_TIMING")) fprintf(stderr, "hand-over tables: %.1f ms (create so far %.1f ms)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_ho0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create0).count());
   }
   h->std_built = true;
@@ -1105,6 +1187,10 @@ static void describe_model(bnmtf_model* h) {
            h->rows.nmiss, h->rows.nslots, h->rows.f_nw, (int)h->rows.use_turns, (int)h->rows.use_twin, (int)h->ho_enabled, h->rows.f_emax, h->rows.f_gen_count, h->cols.n, h->cols.n_pad, h->cols.split,
            h->cols.ipw, h->cols.inner_pad, h->cols.nmiss, h->cols.nslots, h->cols.f_nw, (int)h->cols.use_turns, h->cols.f_emax, h->cols.f_gen_count, n_obs, h->create_ms);
   h->description = buf;
+  // which directions run the unit-per-wave sweep (kernel_sweep_unit.hip), its unit waves per block and most slots per lane
+  snprintf(buf, sizeof(buf), " unit_sweep[rows=%d/%d/%d cols=%d/%d/%d]", (int)(h->rows.uw_ok && (!h->ho_enabled || h->uw_force)), h->rows.u_nw, h->rows.u_emax,
+           (int)(h->cols.uw_ok && (!h->ho_enabled || h->uw_force)), h->cols.u_nw, h->cols.u_emax);
+  h->description += buf;
   if (h->small) {
     snprintf(buf, sizeof(buf), " small[block=%d entry_threads=%d/%d slots=%d/%d lds=%zu std_built=%d]", h->small->nt, h->small->dev.rows.nthreads, h->small->dev.cols.nthreads,
              h->small->dev.rows.em, h->small->dev.cols.em, h->small->lds_bytes, (int)h->std_built);

@@ -122,6 +122,7 @@ struct FastArgs {
   const uint32_t* ho_out; const uint32_t* ho_pk; float* ho_dst;
   const float* XoT; int ldT_o;   // other factor transposed [KP][ldT_o]
   const float* XoT2; int ld2_o;  // other factor, column pairs interleaved [KP/2][ld2_o][2]
+  const float* Xo; int Xo_rows;  // other factor row major [Xo_rows][KP] (kernel_sweep_unit.hip: q rebuilt from its rows)
   double* stats;               // [blocks][4] partial (sum P.X', sum_miss q, sum_miss q^2) or null
   // VB sweep (kernel_sweep_vb.hip)
   const float* XoS;            // other factor's (E, S2) pair panels [KP][ld2_o][2]
@@ -138,6 +139,12 @@ bool sweep_fast_supported(int KP, int pw);
 bool sweep_two_chunks_plan(int KP, int m, int* mh, int* pw, int* pw1);
 void launch_sweep_fast(const SweepArgs& a, const FastArgs& f, hipStream_t st);
 void launch_sweep_small(const SweepArgs& a, const FastArgs& f, hipStream_t st);   // nw = 2, 4 (kernel_sweep_small.hip)
+// one unit per 64-lane wave, f.nw = 4 or 8 unit waves + a staging wave per block (kernel_sweep_unit.hip): few units per CU --
+// shards of a multi-GPU run, small problems.  The layout: Dir::u_* (both halves of a pair hold entries of the same unit)
+constexpr int kUnitMaxUnits = 2048;          // local units of a direction up to which the shape is used: eight per CU
+constexpr int kUnitMaxSlots = 32;            // ... and slots per lane (2 048 missing entries per unit); a direction with a fuller unit keeps the pair layout's kernels
+bool sweep_unit_supported(int KP, int pw);
+void launch_sweep_unit(const SweepArgs& a, const FastArgs& f, hipStream_t st);
 // 16-wave instantiation (kernel_sweep_wide.hip): at most kWideMaxSlots slots per lane, 16 pairs per block
 constexpr int kWideMaxSlots = 32;
 constexpr int kTwinPanelStride = 8448;       // the twin shape (sweep_chip.inc, TW = 1): floats between its two panel buffers = the largest panel it takes

@@ -58,6 +58,9 @@ struct Dir {
   int pw = 0;                                     // LDS panel floats = round_up(mz + 32, 256)
   int nch = 1, mh = 0, pw_chunk = 0, pw1 = 0;     // an inner extent of two LDS panels (FastArgs::nch): chunk split, panel floats of the longer chunk / of chunk 1
   int* f_gen_units = nullptr; int f_gen_count = 0;
+  // the unit-per-wave layout (kernel_sweep_unit.hip; built for directions of at most kUnitMaxUnits local units): pair p = unit p
+  bool uw_ok = false; int u_nw = 4, u_emax = 0;
+  int* u_unit_map = nullptr; uint32_t* u_pair_E = nullptr; uint32_t* u_pair_base = nullptr; uint32_t* u_off16 = nullptr;
   double* stats = nullptr; int stats_blocks = 0;
   bool fast_ok = false;
   int gemm_tw = 4;                       // contraction: 32-column tiles per wave
@@ -177,6 +180,7 @@ struct bnmtf_model {
   uint32_t profiling = 0;                // bit k: bracket the launches of kernel k with events
   bool ho_regions_current = false;              // the regions hold q of the state as the last run call left it (no set_state since)
   bool ho_enabled = false, ho_active = false;   // q hand-over between the half sweeps (Dir::ho_*): tables built / in use by the running loop
+  bool uw_force = false;           // BNMTF_UNIT=1: the unit-per-wave sweep even where the hand-over is on (A/B)
   uint64_t ho_refresh = 64;                     // the rows sweep runs its pre-pass every ho_refresh-th iteration
   uint64_t profile_stride = 1;           // ... in every profile_stride-th iteration
   double kernel_ms[BNMTF_KERNEL_COUNT] = {0};

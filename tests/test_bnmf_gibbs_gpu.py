@@ -103,6 +103,15 @@ def test_postrun_api_matches_reference(golden, name):
     assert str(e.value) == "Unrecognised metric for model quality: FAIL."
 
 
+def _chip_shape(monkeypatch, path):
+    """Problems of this size run the on-chip sweep with one unit per wave (kernel_sweep_unit.hip: "chip"); "chip-pairs" switches
+    that shape off, which leaves the pair layout's blocks (sweep_chip.inc: two units per wave).  Decided when the model is built."""
+    if path == "chip-pairs":
+        monkeypatch.setenv("BNMTF_UNIT", "0")
+        return "chip"
+    return path
+
+
 def _set_path(b, path):
     """small: the one-launch kernel (kernel_small.hip); chip: the multi-launch path with the on-chip sweep; generic: with the generic sweep"""
     b.set_small_path(path == "small")
@@ -110,9 +119,9 @@ def _set_path(b, path):
     assert b.is_small() == (path == "small")
 
 
-@pytest.mark.parametrize("fast", ["small", "chip", "generic"])
+@pytest.mark.parametrize("fast", ["small", "chip", "chip-pairs", "generic"])
 @pytest.mark.parametrize("name", ["toy", "r37x29", "r40x33"])
-def test_mode_update_trajectory_matches_oracle(golden, name, fast):
+def test_mode_update_trajectory_matches_oracle(golden, name, fast, monkeypatch):
     """Deterministic end-to-end parity: with every draw replaced by the mode
     max(0,mu) (the ICM update, nmf_icm.py:124-134) the whole data path -- both
     contractions, the sequential column loop, q maintenance, Gram-identity SSE, tau,
@@ -121,10 +130,14 @@ def test_mode_update_trajectory_matches_oracle(golden, name, fast):
     o = O.BNMFGibbsOracle(c["R"], c["M"], int(c["K"]), _pri(c))
     o.U, o.V, o.tau = c["U"].copy(), c["V"].copy(), float(c["tau"])
     o.run(8, draw=False)
+    fast = _chip_shape(monkeypatch, fast)
     b = bnmf_gibbs_optimised(c["R"], c["M"], int(c["K"]), _pri(c), verbose=False)
     b.U, b.V, b.tau = c["U"].copy(), c["V"].copy(), float(c["tau"])
     _set_path(b, fast)
     b.run(8, update='mode')
+    if fast == "chip":
+        import os
+        assert ("unit_sweep[rows=1" in b.describe()) == (os.environ.get("BNMTF_UNIT") != "0"), b.describe()
     np.testing.assert_allclose(b.all_performances['MSE'], o.all_performances['MSE'], rtol=2e-4)
     np.testing.assert_allclose(b.all_tau, o.all_tau, rtol=2e-4)
     assert np.abs(b.all_U[0] - o.all_U[0]).max() < 2e-4 * max(1.0, np.abs(o.all_U[0]).max())
@@ -134,8 +147,8 @@ def test_mode_update_trajectory_matches_oracle(golden, name, fast):
     assert np.allclose(b.U, b.all_U[-1]) and np.allclose(b.V, b.all_V[-1]) and abs(b.tau - b.all_tau[-1]) < 1e-12
 
 
-@pytest.mark.parametrize("fast", ["small", "chip", "generic"])
-def test_gibbs_draws_follow_oracle_with_same_philox_stream(golden, fast):
+@pytest.mark.parametrize("fast", ["small", "chip", "chip-pairs", "generic"])
+def test_gibbs_draws_follow_oracle_with_same_philox_stream(golden, fast, monkeypatch):
     """Same seed, same counters: the device sampler reproduces the oracle's draws
     (first sweep: every element within fp32 noise unless an accept/reject decision
     sits on a rounding boundary) and the MSE trajectory stays together."""
@@ -146,6 +159,7 @@ def test_gibbs_draws_follow_oracle_with_same_philox_stream(golden, fast):
     o = O.BNMFGibbsOracle(t["R"], t["M"], K, pri, seed=77)
     o.U, o.V, o.tau = g["U0_seed0"].copy(), g["V0_seed0"].copy(), float(g["tau0_seed0"])
     o.run(30)
+    fast = _chip_shape(monkeypatch, fast)
     b = bnmf_gibbs_optimised(t["R"], t["M"], K, pri, verbose=False, seed=77)
     b.U, b.V, b.tau = g["U0_seed0"].copy(), g["V0_seed0"].copy(), float(g["tau0_seed0"])
     _set_path(b, fast)
