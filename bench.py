@@ -42,6 +42,7 @@ WORKLOADS = {
     "bnmf_8192_k32": dict(kind="bnmf", I=8192, J=8192, K=32),          # the 16-wave sweep with one register of columns per lane
     "bnmtf_4096_k32": dict(kind="bnmtf", I=4096, J=4096, K=32, L=32),  # configs[3]
     "vb_8192_k64": dict(kind="vb", I=8192, J=8192, K=64),              # configs[4]
+    "bnmtf_vb_4096_k32": dict(kind="trivb", I=4096, J=4096, K=32, L=32),   # bnmtf_vb_optimised (round 6: the first measurement of it)
     "vb_4096_k32": dict(kind="vb", I=4096, J=4096, K=32),
     "vb_8192_k32": dict(kind="vb", I=8192, J=8192, K=32),
     # the shapes the reference itself publishes numbers for: one small model / a model-selection job
@@ -151,6 +152,29 @@ def cpu_baseline(w, R, M, whole=False):
         sample = "%d of %d F columns %.2fs, %d of %d S entries %.2fs, %d of %d G columns %.2fs, tau+metrics %.2fs" % (
             nf, K, t1 - t0, ns, K * L, t2 - t1, nf, L, t3 - t2, t4 - t3)
         kind_note = "extrapolated from %d of %d F columns, %d of %d S entries, %d of %d G columns" % (nf, K, ns, K * L, nf, L)
+    elif kind == "trivb":
+        import random as _random
+        L = w["L"]
+        o = O.BNMTFVBOracle(R, M, K, L, PRI3)
+        np.random.seed(0); _random.seed(0)
+        o.initialise("random", "random")          # (host TN moments of every entry + one exp_square_diff: not timed)
+        nf, ns = 2, 6
+        t0 = tic()
+        for kk, ll in [(0, l) for l in range(ns)]:
+            o.update_S(kk, ll); o.update_exp_S(kk, ll)
+        t1 = tic()
+        for k in range(nf):
+            o.update_F(k); o.update_exp_F(k)
+        t2 = tic()
+        for l in range(nf):
+            o.update_G(l); o.update_exp_G(l)
+        t3 = tic()
+        o.update_tau(); o.update_exp_tau(); o.predict(o.M)
+        t4 = tic()
+        sec = K * L * (t1 - t0) / ns + K * (t2 - t1) / nf + L * (t3 - t2) / nf + (t4 - t3)
+        sample = "%d of %d S entries %.2fs, %d of %d F columns %.2fs, %d of %d G columns %.2fs, tau+metrics %.2fs" % (
+            ns, K * L, t1 - t0, nf, K, t2 - t1, nf, L, t3 - t2, t4 - t3)
+        kind_note = "extrapolated from %d of %d S entries, %d of %d F columns, %d of %d G columns" % (ns, K * L, nf, K, nf, L)
     else:
         o = O.BNMFVBOracle(R, M, K, PRI2)
         o.muU = rs.exponential(1.0, (o.I, K)); o.muV = rs.exponential(1.0, (o.J, K))
@@ -207,6 +231,12 @@ def build_model(w, R, M, rank, world, local_rank, comm_id):
         m.initialise("random")
     elif w["kind"] == "bnmtf":
         m = bnmtf_amd.bnmtf_gibbs_optimised(R, M, w["K"], w["L"], PRI3, **kw)
+        m.initialise("random", "random")
+    elif w["kind"] == "trivb":
+        import random as _random
+        assert world == 1, "bnmtf_vb runs on one GPU"
+        m = bnmtf_amd.bnmtf_vb_optimised(R, M, w["K"], w["L"], PRI3, device=local_rank, verbose=False)
+        _random.seed(0)
         m.initialise("random", "random")
     else:
         kw.pop("seed")
@@ -454,7 +484,7 @@ def main():
 
     w = WORKLOADS[a.workload]
     I, J, K, kind = w["I"], w["J"], w["K"], w["kind"]
-    if kind == "bnmtf":
+    if kind in ("bnmtf", "trivb"):
         R, M, _, _, _ = generate_bnmtf(I, J, K, w["L"], 0.1, seed_data=0, seed_mask=1)
     else:
         R, M, _, _ = generate_bnmf(I, J, K, 0.1, tau=1.0, seed_data=0, seed_mask=1)
@@ -475,12 +505,19 @@ def main():
             _lib.check(L.bnmf_gibbs_run(h, n, _lib.UPDATE_DRAW, _lib.ptr(s[0]), _lib.ptr(s[1]), None, _lib.ptr(perf), None))
         elif kind == "bnmtf":
             _lib.check(L.bnmtf_gibbs_run(h, n, _lib.UPDATE_DRAW, _lib.ptr(s[0]), _lib.ptr(s[2]), _lib.ptr(s[1]), None, _lib.ptr(perf), None))
+        elif kind == "trivb":
+            _lib.check(L.bnmtf_vb_run(h, n, _lib.ptr(tri_orders[:n]), None, _lib.ptr(perf), None, None))
         else:
             _lib.check(L.bnmf_vb_run(h, n, None, _lib.ptr(perf), None, None))
 
     # the reference's run() hands every sample to the host (all_U[it], all_V[it]): the timed loop does too -- page-locked
     # arrays of --steps samples (re-used by every timed region), asynchronous copies behind the compute stream
-    with_samples = kind != "vb" and not a.no_samples
+    tri_orders = None
+    if kind == "trivb":           # the three shuffles of every iteration, drawn the reference's way (bnmtf_vb_optimised.py:171-186): reused by every region
+        import random as _random
+        _random.seed(1)
+        tri_orders = np.ascontiguousarray(model._draw_orders(max(a.steps, a.warmup, 50)))
+    with_samples = kind not in ("vb", "trivb") and not a.no_samples
     bufs = None
     if with_samples:
         if kind == "bnmf":
@@ -502,7 +539,7 @@ def main():
     # record drains the queue for ~4 us: two per iteration were 2 % of the headline iteration)
     # (BNMTF: the cols direction's contraction is no pass over R~ any more -- (R~^T F) S from the S step's slabs -- so the
     # roofline kernel there is the rows direction's, R~ . (G S^T))
-    ROOF = _lib.KERNEL_GEMM_ROWS if kind == "bnmtf" else _lib.KERNEL_GEMM_COLS
+    ROOF = _lib.KERNEL_GEMM_ROWS if kind in ("bnmtf", "trivb") else _lib.KERNEL_GEMM_COLS
     model.set_profiling(True, kernel=ROOF, every=4)
     perf_first = None
     dts = []
@@ -552,7 +589,7 @@ def main():
     # what the box sustains under this loop: the pool's boxes differ by +-5 % in rate, and that spread is the shader clock
     # (~861 k cycles per iteration of the headline on either kind) -- rocm-smi read a few times beside ~2 s of the
     # device-resident loop, after everything that is timed; None when rocm-smi is not there or says nothing
-    clock = _clock_beside(lambda: run(max(a.steps, 50)), sync) if world == 1 and not a.no_clock else None
+    clock = _clock_beside(lambda: run(max(a.steps, 50) if kind != "trivb" else min(max(a.steps, 50), len(tri_orders))), sync) if world == 1 and not a.no_clock else None
 
     import ctypes as C_
     ck, cr = C_.c_int(), C_.c_int()
@@ -593,7 +630,7 @@ def main():
                     "unit": "TFLOP/s", "frac": ach / PEAK_F32_VECTOR_TFLOPS, "traffic": None}
         else:
             ach = bytes_alg / (g["avg_us"] * 1e-6) / 1e9 if g["avg_us"] > 0 else 0.0
-            roof = {"bound": "hbm", "kernel": ("gemm_rows: P = R~.(G S^T)" if kind == "bnmtf" else "gemm_cols: Pv = R~^T.U") + " (bf16x3 MFMA 32x32x16, fp32-exact products)", "achieved": ach,
+            roof = {"bound": "hbm", "kernel": ("gemm_rows: P = R~.(G S^T)" if kind in ("bnmtf", "trivb") else "gemm_cols: Pv = R~^T.U") + " (bf16x3 MFMA 32x32x16, fp32-exact products)", "achieved": ach,
                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": traffic}
         roof.update({"algorithmic_per_launch": {"flop": flops, "bytes": bytes_alg,
                                                 "bytes_note": "4 B per element: the operand is the PRE-MASKED R~ = M.R (fp32, built once at create), so a launch reads no mask; "
@@ -618,19 +655,19 @@ def main():
         sweep_ach = sweep_flop / (sw["avg_us"] * 1e-6) / 1e12 if sw["avg_us"] > 0 else 0.0
         out = {
             "metric": {"bnmf": "Gibbs iterations/sec (BNMF, I=J=%d, K=%d)", "bnmtf": "Gibbs iterations/sec (BNMTF, I=J=%d, K=L=%d)",
-                       "vb": "VB iterations/sec (BNMF VB, I=J=%d, K=%d)"}[kind] % (I, K),
-            "value": a.steps / dt, "unit": "iterations/s" if kind == "vb" else "Gibbs iterations/s", "n_gpus": world, "steps": a.steps,
+                       "vb": "VB iterations/sec (BNMF VB, I=J=%d, K=%d)", "trivb": "VB iterations/sec (BNMTF VB, I=J=%d, K=L=%d)"}[kind] % (I, K),
+            "value": a.steps / dt, "unit": "iterations/s" if kind in ("vb", "trivb") else "Gibbs iterations/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s, synthetic R %dx%d K=%d%s, 10%% missing mask, priors alpha=beta=1 lambda=0.1, init %s" % (
-                           {"bnmf": "BNMF Gibbs", "bnmtf": "BNMTF Gibbs", "vb": "BNMF VB"}[kind], I, J, K, " L=%d" % w["L"] if "L" in w else "",
+                           {"bnmf": "BNMF Gibbs", "bnmtf": "BNMTF Gibbs", "vb": "BNMF VB", "trivb": "BNMTF VB (bnmtf_vb_optimised, shuffled update orders)"}[kind], I, J, K, " L=%d" % w["L"] if "L" in w else "",
                            "exp" if kind == "vb" else "random"),
                        "parallelism": "rows/cols split x%d, RCCL all-gather of factor blocks" % world if world > 1 else "single GPU",
                        "rccl_ranks": int(cr.value) if ck.value == 1 else 0,
                        "communicator": {0: "none", 1: "rccl", 2: "in-process"}[int(ck.value)] + " (%d ranks by its own count, world %d)" % (cr.value, world),
                        "samples": ("handed to the host every iteration (all_U/all_V: %.1f MiB per iteration, page-locked arrays, copy stream)" % (
                                        4.0 * (I * K + J * Wc + (K * Wc if kind == "bnmtf" else 0)) / 2 ** 20)) if with_samples else
-                                  ("none (the variational run() stores no samples)" if kind == "vb" else "device-resident (--no-samples)")},
+                                  ("none (the variational run() stores no samples)" if kind in ("vb", "trivb") else "device-resident (--no-samples)")},
             "repeats": {"n": len(dts), "timed_seconds": float(sum(dts)), "values": [a.steps / d for d in dts[:40]], "min": a.steps / max(dts), "median": a.steps / dt, "max": a.steps / min(dts)},
             "device_resident": None if resident is None else {"value": resident, "unit": "iterations/s", "what": "same loop, samples left on the device"},
             "clock": clock,

@@ -1,0 +1,154 @@
+"""Ranks above 64: a BNMF factorisation run as COLUMN BLOCKS (round 6).
+
+The reference takes any K (code/models/bnmf_gibbs_optimised.py:54-78).  The device kernels hold one latent factor per wave lane
+(K <= 64), so a wider model is cut into ceil(K / 64) blocks of columns, each an ordinary device model (one handle) of rank
+K_b <= 64 on the same R, M.  Given the other blocks, the conditionals of block b's columns are those of a rank-K_b model on the
+residual data R - sum_{b' != b} U_b' V_b'^T (the other blocks' part of U V^T moves to the data side of
+M . (R - U V^T + U_k V_k^T), bnmf_gibbs_optimised.py:170-171, 176-177).  So one iteration of run() (:133-155) is
+
+    for every block b in order:  residual data of b  ->  half sweep of U_b          (:134-137, columns in order)
+    for every block b in order:  residual data of b  ->  half sweep of V_b          (:139-142)
+    tau ~ Gamma(alpha_s, beta_s)  with beta_s from the full-width masked SSE         (:144, :161-165)
+    the three metrics of the full-width sample on the training mask                  (:147-150)
+
+-- the reference's sequential column order exactly, with the draws keyed by the wide model's column index (the Philox column
+word of block b's column k is 64 b + k: csrc bnmf_set_column_block), so the chain is the oracle's chain for the same seed.
+The blocks' half sweeps, residual updates and the full-width metric sums are device calls (include/bnmtf_hip.h: bnmf_half_sweep,
+bnmf_set_residual_data, bnmtf_metric_sums_wide); this file only orders them.  One GPU; Gibbs draws, mode and ICM updates.
+Not a fast path: every half sweep of a block is preceded by a pass over R (the residual), and the per-iteration control is
+Python -- it exists so that a search over value lists that reach past 64 runs instead of failing."""
+import ctypes as C
+import time
+
+import numpy as np
+
+from . import _lib
+
+BLOCK = 64
+MAX_BLOCKS = 4          # csrc kernels.h kMaxOtherBlocks + 1: ranks up to 256
+
+
+def block_ranges(K):
+    return [(c0, min(c0 + BLOCK, K)) for c0 in range(0, K, BLOCK)]
+
+
+class ColumnBlocks(object):
+    """The child models of a wide bnmf_gibbs / nmf_icm instance `owner` (which keeps the full-width U, V, tau attributes)."""
+
+    def __init__(self, owner, child_cls):
+        self.owner = owner
+        self.ranges = block_ranges(owner.K)
+        assert len(self.ranges) <= MAX_BLOCKS
+        self.children = []
+        for (c0, c1) in self.ranges:
+            pri = {"alpha": owner.alpha, "beta": owner.beta, "lambdaU": owner.lambdaU[:, c0:c1], "lambdaV": owner.lambdaV[:, c0:c1]}
+            ch = child_cls(owner.R, owner.M, c1 - c0, pri, seed=owner._seed, device=owner._device, verbose=False)
+            self.children.append(ch)
+        self._ready = False
+        self.iteration = 0
+
+    # -- device plumbing ----------------------------------------------------------
+    def _prepare(self):
+        if self._ready:
+            return
+        L = _lib.lib()
+        if self.owner._seed is None:                      # one Philox key for all blocks: drawn once, like a single handle's
+            self.owner._seed = int(np.random.randint(0, 2 ** 62))
+        for ch, (c0, _) in zip(self.children, self.ranges):
+            ch._seed = self.owner._seed
+            _lib.check(L.bnmf_set_column_block(ch._handle(), int(c0)))
+        self._ready = True
+
+    def handles(self):
+        self._prepare()
+        return [ch._handle() for ch in self.children]
+
+    def push(self, U, V, tau):
+        self._prepare()
+        for ch, (c0, c1) in zip(self.children, self.ranges):
+            ch.U, ch.V, ch.tau = np.ascontiguousarray(U[:, c0:c1]), np.ascontiguousarray(V[:, c0:c1]), float(tau)
+            ch._device_state = None
+            ch._push()
+
+    def pull(self):
+        I, J, K = self.owner.I, self.owner.J, self.owner.K
+        U = np.zeros((I, K)); V = np.zeros((J, K))
+        for ch, (c0, c1) in zip(self.children, self.ranges):
+            ch._pull()
+            U[:, c0:c1] = ch.U; V[:, c0:c1] = ch.V
+        return U, V
+
+    def _others(self, b):
+        hs = self.handles()
+        o = [hs[i] for i in range(len(hs)) if i != b]
+        arr = (C.c_void_p * max(len(o), 1))(*[h.value for h in o])
+        return arr, len(o)
+
+    def residual(self, b):
+        arr, n = self._others(b)
+        _lib.check(_lib.lib().bnmf_set_residual_data(self.handles()[b], arr, n))
+
+    def set_tau(self, tau):
+        for ch in self.children:
+            # (factors stay where they are: only the scalar changes)
+            _lib.check(_lib.lib().bnmtf_set_tau(ch._handle(), float(tau)))
+            ch.tau = float(tau)
+
+    def set_iteration(self, it):
+        for ch in self.children:
+            _lib.check(_lib.lib().bnmtf_set_iteration(ch._handle(), C.c_uint64(int(it))))
+
+    def metric_sums(self, M_pred, A, B):
+        out = np.zeros(6)
+        Mp = None if M_pred is None else np.ascontiguousarray(np.asarray(M_pred) != 0, dtype=np.uint8)
+        A = _lib.f64(A); B = _lib.f64(B)
+        _lib.check(_lib.lib().bnmtf_metric_sums_wide(self.handles()[0], _lib.ptr(Mp), _lib.ptr(A), _lib.ptr(B), int(A.shape[1]), _lib.ptr(out)))
+        return out
+
+    def cond(self, which, k):
+        """(numerator, tau_k) of the conditional of column k of U (which = 0) or V: block b's hook on its residual data."""
+        b = int(k) // BLOCK
+        self.residual(b)
+        n = self.owner.I if which == 0 else self.owner.J
+        numer = np.zeros(n); tauk = np.zeros(n)
+        _lib.check(_lib.lib().bnmf_cond_params(self.handles()[b], which, int(k) - BLOCK * b, _lib.ptr(numer), _lib.ptr(tauk)))
+        return numer, tauk
+
+    # -- the iteration --------------------------------------------------------------
+    def run(self, iterations, update, tau_rule, minimum_TN=0.0, store=None, each=None):
+        """`iterations` iterations from the state that was pushed.  update: _lib.UPDATE_DRAW / MODE / ICM; tau_rule(it, sse) ->
+        the new tau; store(it, U, V): sample hand-off (or None); each(it, U, V, tau): anything else per iteration (posterior sums).
+        Returns (taus, perf [n][3], times)."""
+        L = _lib.lib()
+        hs = self.handles()
+        nb = len(hs)
+        taus = np.zeros(iterations); perf = np.zeros((iterations, 3)); times = np.zeros(iterations)
+        for ch in self.children:
+            _lib.check(L.bnmtf_set_minimum_tn(ch._handle(), float(minimum_TN)))
+        t0 = time.time()
+        from ._base import metrics_from_sums
+        for it in range(iterations):
+            self.set_iteration(self.iteration)
+            for which in (0, 1):
+                for b in range(nb):
+                    if nb > 1:
+                        self.residual(b)
+                    _lib.check(L.bnmf_half_sweep(hs[b], which, int(update)))
+            U, V = self.pull()
+            s = self.metric_sums(None, U, V)
+            sse = s[2] - 2.0 * s[5] + s[4]
+            tau = tau_rule(self.iteration, sse)
+            self.set_tau(tau)
+            m = metrics_from_sums(s)
+            taus[it] = tau; perf[it] = (m["MSE"], m["R^2"], m["Rp"]); times[it] = time.time() - t0
+            if store is not None:
+                store(it, U, V)
+            if each is not None:
+                each(it, U, V, tau)
+            self.iteration += 1
+        self.last = (U, V, float(tau)) if iterations > 0 else None
+        return taus, perf, times
+
+    def close(self):
+        for ch in self.children:
+            ch.close()

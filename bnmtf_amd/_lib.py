@@ -76,6 +76,11 @@ _SIGS = {
     "bnmtf_kmeans_sums": ([_P, _P, _P, _P], C.c_int),
     "bnmtf_kmeans_set_row": ([_P, C.c_int, _P], C.c_int),
     "bnmtf_metric_sums": ([_P, _P, _P, _P, _P, _P], C.c_int),
+    "bnmtf_metric_sums_wide": ([_P, _P, _P, _P, C.c_int, _P], C.c_int),
+    "bnmtf_set_tau": ([_P, C.c_double], C.c_int),
+    "bnmf_set_column_block": ([_P, C.c_int], C.c_int),
+    "bnmf_set_residual_data": ([_P, _P, C.c_int], C.c_int),
+    "bnmf_half_sweep": ([_P, C.c_int, C.c_int], C.c_int),
     "bnmtf_tn_sample": ([_P, _P, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, _P], C.c_int),
     "bnmtf_tn_moments": ([_P, _P, C.c_size_t, C.c_int, _P, _P], C.c_int),
     "bnmtf_gamma_sample": ([C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_double)], C.c_int),

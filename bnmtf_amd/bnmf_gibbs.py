@@ -22,6 +22,9 @@ import numpy as np
 
 from . import _lib
 from ._base import DeviceModel, broadcast_lambda, check_rank, check_R_M, metrics_from_sums
+from ._blocked import BLOCK, MAX_BLOCKS, ColumnBlocks
+
+MAX_RANK_BLOCKED = BLOCK * MAX_BLOCKS      # 256: ranks above 64 run as column blocks (_blocked.py)
 
 
 class bnmf_gibbs_optimised(DeviceModel):
@@ -30,7 +33,7 @@ class bnmf_gibbs_optimised(DeviceModel):
         self.M = np.array(M, dtype=float)
         self.K = K
         check_R_M(self.R, self.M)
-        check_rank("bnmf_gibbs_optimised", 64, K=self.K)
+        check_rank("bnmf_gibbs_optimised", MAX_RANK_BLOCKED, K=self.K)
         (self.I, self.J) = self.R.shape
         self.size_Omega = self.M.sum()
         self.alpha, self.beta = float(priors['alpha']), float(priors['beta'])
@@ -38,9 +41,24 @@ class bnmf_gibbs_optimised(DeviceModel):
         self.lambdaV = broadcast_lambda(priors['lambdaV'], (self.J, self.K), "lambdaV")
         self.verbose = verbose
         self._init_device(seed, device, rank, world, comm_id)
+        # ranks above 64 (the reference has no limit, :54-78): column blocks of at most 64, one device model each (_blocked.py)
+        self._blocks = None
+        if self.K > BLOCK:
+            assert world == 1, "ranks above %d run on one GPU (column blocks: DESIGN.md section 8)" % BLOCK
+            self._blocks = ColumnBlocks(self, bnmf_gibbs_optimised)
 
     def _lambda_arrays(self):
         return self.lambdaU, self.lambdaV, None
+
+    def close(self):
+        if getattr(self, "_blocks", None) is not None:
+            self._blocks.close()
+        super(bnmf_gibbs_optimised, self).close()
+
+    def _handle(self):
+        if getattr(self, "_blocks", None) is not None:       # shape-only entry points (omega_counts, ...): the first block's handle
+            return self._blocks.handles()[0]
+        return super(bnmf_gibbs_optimised, self)._handle()
 
     # Initialise and run the sampler (bnmf_gibbs_optimised.py:94-96)
     def train(self, init, iterations):
@@ -61,6 +79,13 @@ class bnmf_gibbs_optimised(DeviceModel):
 
     def _push(self, tau=None):
         tau = getattr(self, "tau", 1.0) if tau is None else tau
+        if self._blocks is not None:
+            held = getattr(self, "_device_state", None)
+            if held is not None and float(tau) == held[3] and np.array_equal(self.U, held[1]) and np.array_equal(self.V, held[2]):
+                return
+            self._blocks.push(np.asarray(self.U, dtype=float), np.asarray(self.V, dtype=float), float(tau))
+            self._device_state = (None, np.array(self.U, dtype=float), np.array(self.V, dtype=float), float(tau))
+            return
         # the state the device holds already (nothing touched U, V, tau since the last run() pulled them): no upload -- and the
         # device keeps what it carries between its half sweeps, so run(a); run(b) is the chain of run(a + b)
         held = getattr(self, "_device_state", None)
@@ -82,11 +107,83 @@ class bnmf_gibbs_optimised(DeviceModel):
         expectation=(burn_in, thinning) also accumulates the posterior means of exactly that
         approx_expectation(burn_in, thinning) on the device (what the model-selection drivers
         need: with store_samples=False no sample ever crosses to the host)."""
+        if self._blocks is not None:
+            return self._run_blocked(iterations, _lib.UPDATE_MODE if update == 'mode' else _lib.UPDATE_DRAW, store_samples, expectation)
         bufs = self._run_prepare(iterations, store_samples, expectation)
         it, U_out, V_out, taus, perf, times = bufs
         _lib.check(_lib.lib().bnmf_gibbs_run(self._handle(), it, _lib.UPDATE_MODE if update == 'mode' else _lib.UPDATE_DRAW,
                                              _lib.ptr(U_out), _lib.ptr(V_out), _lib.ptr(taus), _lib.ptr(perf), _lib.ptr(times)))
         return self._run_finish(bufs, store_samples)
+
+    def _run_blocked(self, iterations, update, store_samples, expectation, minimum_TN=0.0, icm=False):
+        """run() of a model wider than 64 columns: the blocks' half sweeps in turn (_blocked.py); tau by the update rule's own
+        law -- a Gamma(alpha_s, beta_s) draw keyed like the single-handle loop's (seed, iteration), its ratio mean is not used
+        here; mode updates keep the Gibbs harness's tau draw, ICM takes the Gamma mode (nmf_icm.py:137)."""
+        from .distributions import gamma_draw
+        it = int(iterations)
+        self._push()
+        blocks = self._blocks
+        all_U = np.zeros((it, self.I, self.K), dtype=np.float32) if store_samples else None
+        all_V = np.zeros((it, self.J, self.K), dtype=np.float32) if store_samples else None
+        self._dev_expect = None
+        acc = None
+        if expectation is not None:
+            burn_in, thinning = int(expectation[0]), int(expectation[1])
+            assert 0 <= burn_in < it and thinning >= 1, "expectation=(burn_in, thinning) needs 0 <= burn_in < iterations, thinning >= 1"
+            acc = {"U": np.zeros((self.I, self.K)), "V": np.zeros((self.J, self.K)), "tau": 0.0, "n": 0, "sel": set(range(burn_in, it, thinning))}
+        alpha_s = self.alpha_s()
+
+        def tau_rule(iteration, sse):
+            beta_s = self.beta + 0.5 * sse
+            if icm:
+                return (alpha_s - 1.0) / beta_s
+            return gamma_draw(alpha_s, beta_s, seed=self._seed, it=iteration, device=self._device)
+
+        def store(i, U, V):
+            all_U[i] = U; all_V[i] = V
+
+        def each(i, U, V, tau):
+            if i in acc["sel"]:
+                acc["U"] += U; acc["V"] += V; acc["tau"] += tau; acc["n"] += 1
+
+        taus, perf, times = blocks.run(it, update, tau_rule, minimum_TN=minimum_TN, store=store if store_samples else None,
+                                       each=each if acc is not None else None)
+        if it > 0:
+            self.U, self.V, self.tau = blocks.last
+            self._device_state = (None, self.U.copy(), self.V.copy(), float(self.tau))
+        if acc is not None and acc["n"] > 0:
+            self._host_expect = ((burn_in, thinning), acc["U"] / acc["n"], acc["V"] / acc["n"], acc["tau"] / acc["n"])
+        self.all_U = all_U if store_samples else np.zeros((0, self.I, self.K))
+        self.all_V = all_V if store_samples else np.zeros((0, self.J, self.K))
+        self.all_tau = taus
+        self.all_times = list(times)
+        self.all_performances = {'MSE': list(perf[:, 0]), 'R^2': list(perf[:, 1]), 'Rp': list(perf[:, 2])}
+        if self.verbose:
+            for i in range(it):
+                print("Iteration %s. MSE: %s. R^2: %s. Rp: %s." % (i + 1, perf[i, 0], perf[i, 1], perf[i, 2]))
+        return (self.all_U, self.all_V, self.all_tau)
+
+    def _device_expectation(self, burn_in, thinning):
+        if self._blocks is not None:           # (the blocked run keeps the posterior sums on the host)
+            he = getattr(self, "_host_expect", None)
+            if he is not None and he[0] == (int(burn_in), int(thinning)) and len(getattr(self, "all_U", ())) == 0:
+                return (he[1], None, he[2], he[3])
+            return None
+        return super(bnmf_gibbs_optimised, self)._device_expectation(burn_in, thinning)
+
+    def _metric_sums(self, M_pred, A, S, B):
+        if self._blocks is not None:
+            if M_pred is not None:
+                Mp_ = np.asarray(M_pred)
+                assert ((Mp_ == 0) | (Mp_ == 1)).all(), "The indicator matrix M_pred must contain only 0 and 1."
+            return self._blocks.metric_sums(M_pred, self.U if A is None else A, self.V if B is None else B)
+        return super(bnmf_gibbs_optimised, self)._metric_sums(M_pred, A, S, B)
+
+    def describe(self):
+        if self._blocks is not None:
+            self._blocks._prepare()
+            return "column blocks %s: " % (self._blocks.ranges,) + " | ".join(ch.describe() for ch in self._blocks.children)
+        return super(bnmf_gibbs_optimised, self).describe()
 
     def _run_prepare(self, iterations, store_samples, expectation):
         """State on the device, expectation switch, output arrays of one run() call (also used by bnmtf_amd.run_many)."""
@@ -121,6 +218,9 @@ class bnmf_gibbs_optimised(DeviceModel):
         return self.alpha + self.size_Omega / 2.0
 
     def beta_s(self):
+        if self._blocks is not None:           # :164-165 from the full-width masked SSE
+            s = self._metric_sums(None, np.asarray(self.U, dtype=float), None, np.asarray(self.V, dtype=float))
+            return self.beta + 0.5 * (s[2] - 2.0 * s[5] + s[4])
         self._push()
         out = C.c_double()
         _lib.check(_lib.lib().bnmtf_beta_s(self._handle(), C.byref(out)))
@@ -128,6 +228,8 @@ class bnmf_gibbs_optimised(DeviceModel):
 
     def _cond(self, which, k):
         self._push()
+        if self._blocks is not None:
+            return self._blocks.cond(which, k)
         n = self.I if which == 0 else self.J
         numer = np.zeros(n); tauk = np.zeros(n)
         _lib.check(_lib.lib().bnmf_cond_params(self._handle(), which, int(k), _lib.ptr(numer), _lib.ptr(tauk)))

@@ -570,7 +570,7 @@ struct HandoverScope {
   // (a call that follows another one of the same handle with the state untouched in between picks the regions up where that
   // call left them: run(50) + run(50) is the chain of run(100), bit for bit)
   explicit HandoverScope(bnmtf_model* h_) : h(h_) {
-    h->ho_active = h->ho_enabled && !h->comm && h->use_fast;
+    h->ho_active = h->ho_enabled && !h->comm && h->use_fast && !h->block_mode;
     if (!h->ho_active || !h->ho_regions_current) h->rows.ho_filled = h->cols.ho_filled = false;
     h->ho_regions_current = false;            // (an error return out of the loop leaves them unknown)
   }
@@ -754,6 +754,7 @@ static SweepArgs sweep_args(bnmtf_model* h, Dir& d, const Dir& other, int mode, 
   memset(&s, 0, sizeof(s));
   s.min_x = mode == kSweepMode ? h->cur_min_x : 0.f;
   s.n = d.n; s.n0 = d.n0; s.K = d.W; s.KP = d.KP; s.mode = mode; s.cond_k = -1; s.qinit_only = 0; s.only_k = -1; s.vb_moments = 1; s.vb_stats = nullptr;
+  s.col0 = h->col0;
   s.slabs = d.slabs; s.split = d.split; s.n_pad = d.n_pad; s.lambda = d.lambda;
   s.Xself = d.X; s.XselfT = nullptr; s.ldT_self = d.ldT;
   s.XoT = other.XT; s.ldT_o = other.ldT; s.C32 = other.C32;
@@ -1287,6 +1288,11 @@ int bnmtf_get_expectation(bnmtf_handle h, double* A, double* S, double* B, doubl
 }
 
 int bnmtf_set_iteration(bnmtf_handle h, uint64_t it) { h->iteration = it; return BNMTF_OK; }
+int bnmtf_set_tau(bnmtf_handle h, double tau) {        // the noise precision alone (the factors on the device stay as they are)
+  if (!h->have_state) { set_error("bnmtf_set_tau before the state is set"); return BNMTF_ESTATE; }
+  HIPCHK(hipSetDevice(h->device));
+  return set_tau(h, tau);
+}
 int bnmtf_get_iteration(bnmtf_handle h, uint64_t* it) { *it = h->iteration; return BNMTF_OK; }
 
 int bnmtf_set_minimum_tn(bnmtf_handle h, double minimum_TN) {
@@ -1541,9 +1547,80 @@ int bnmf_gibbs_run_many(const bnmtf_handle* hs, int n_models, int n_iter, int up
   return BNMTF_OK;
 }
 
+// ---------------------------------------------------------------------- ranks above 64: a factorisation as column blocks
+// The reference takes any K (bnmf_gibbs_optimised.py:54-78).  The kernels hold a latent factor per wave lane (K <= 64), so a wider
+// model runs as ceil(K / 64) COLUMN BLOCKS, one handle each (bnmtf_amd/_blocked.py): the conditionals of block b's columns given the
+// other blocks are those of a rank-K_b model on the residual data R - sum_{b' != b} U_b' V_b'^T -- exactly the reference's
+// sequential column order when the blocks' half sweeps run in turn, rows first (:134-137), then columns (:139-142).
+int bnmf_set_column_block(bnmtf_handle h, int col0) {
+  if (col0 < 0) { set_error("negative column offset"); return BNMTF_EINVAL; }
+  if (h->L != 0 || h->comm) { set_error("column blocks: BNMF handles on one GPU"); return BNMTF_ESTATE; }
+  h->col0 = (uint32_t)col0;
+  h->block_mode = true;
+  h->small_mode = 0;                          // (the one-launch kernel runs whole iterations: not a block's half sweeps)
+  return BNMTF_OK;
+}
+
+int bnmf_set_residual_data(bnmtf_handle h, const bnmtf_handle* others, int n_others) {
+  if (n_others < 0 || n_others > kMaxOtherBlocks) { set_error("at most %d other column blocks", kMaxOtherBlocks); return BNMTF_EINVAL; }
+  if (h->L != 0 || h->comm) { set_error("residual data: BNMF handles on one GPU"); return BNMTF_ESTATE; }
+  HIPCHK(hipSetDevice(h->device));
+  CHK(ensure_std(h));
+  ResidualSpec rs;
+  memset(&rs, 0, sizeof(rs));
+  rs.n = n_others;
+  for (int b = 0; b < n_others; ++b) {
+    bnmtf_model* o = others[b];
+    if (!o || o == h || o->I != h->I || o->J != h->J || o->L != 0 || o->device != h->device || !o->have_state) { set_error("residual data: block %d does not fit (shape, device, state)", b); return BNMTF_EINVAL; }
+    CHK(ensure_std(o));
+    if (!o->std_cur) { set_error("residual data: block %d's state is not on its multi-launch structures", b); return BNMTF_ESTATE; }
+    HIPCHK(hipStreamSynchronize(o->stream));                 // (its last half sweep runs on its own stream)
+    rs.A[b] = o->rows.X; rs.B[b] = o->cols.X; rs.KP[b] = o->rows.KP; rs.W[b] = o->rows.W;
+  }
+  for (int which = 0; which < 2; ++which) {
+    Dir& d = which == 0 ? h->rows : h->cols;
+    launch_residual_operand(h->Rfull, h->Mtrain, h->I, h->J, which == 0 ? 1 : 0, d.n0, d.n, d.m, d.big, d.n_pad, rs, h->stream);
+  }
+  HIPCHK(hipGetLastError());
+  return BNMTF_OK;
+}
+
+// one half of an iteration of run(): the contraction, the K sequential column updates of one factor (which = 0: U, :134-137; 1: V,
+// :139-142) with the handle's current tau and iteration counter, the relayout + Gram the other direction reads.  tau, the
+// metrics, the samples and the iteration counter are the caller's (a column-blocked model: bnmtf_amd/_blocked.py).
+int bnmf_half_sweep(bnmtf_handle h, int which, int update) {
+  if (which < 0 || which > 1 || update < 0 || update > BNMTF_UPDATE_ICM) { set_error("bnmf_half_sweep: which in {0, 1}, a known update rule"); return BNMTF_EINVAL; }
+  if (h->L != 0 || h->comm) { set_error("bnmf_half_sweep: BNMF handles on one GPU"); return BNMTF_ESTATE; }
+  if (!h->have_state) { set_error("no state set"); return BNMTF_ESTATE; }
+  HIPCHK(hipSetDevice(h->device));
+  CHK(ensure_std(h));
+  if (!h->std_cur) { set_error("bnmf_half_sweep: set the state first"); return BNMTF_ESTATE; }
+  h->small_cur = false;
+  const int mode = update == BNMTF_UPDATE_DRAW ? kSweepDraw : kSweepMode;
+  h->cur_min_x = update == BNMTF_UPDATE_ICM ? (float)h->min_tn : 0.f;
+  Dir& d = which == 0 ? h->rows : h->cols;
+  Dir& o = which == 0 ? h->cols : h->rows;
+  h->ho_active = false;
+  h->rows.ho_filled = h->cols.ho_filled = false;
+  enqueue_gemm(h, d, o, which == 0 ? BNMTF_KERNEL_GEMM_ROWS : BNMTF_KERNEL_GEMM_COLS);
+  SweepArgs s = sweep_args(h, d, o, mode, which == 0 ? kStreamRows : kStreamCols);
+  enqueue_sweep(h, d, o, s, false);
+  CHK(exchange_factor(h, d));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
+  return BNMTF_OK;
+}
+
 // ---------------------------------------------------------------------- metrics
+static int metric_sums_impl(bnmtf_handle h, const uint8_t* Mp, const double* A, const double* S, const double* B, double sums_out[6], int Kc_given);
 int bnmtf_metric_sums(bnmtf_handle h, const uint8_t* Mp, const double* A, const double* S, const double* B,
-                      double sums_out[6]) {
+                      double sums_out[6]) { return metric_sums_impl(h, Mp, A, S, B, sums_out, 0); }
+int bnmtf_metric_sums_wide(bnmtf_handle h, const uint8_t* Mp, const double* A, const double* B, int Kc, double sums_out[6]) {
+  if (!A || !B || Kc <= 0) { set_error("bnmtf_metric_sums_wide: A [I][Kc], B [J][Kc] and Kc > 0 required"); return BNMTF_EINVAL; }
+  if (h->L != 0) { set_error("bnmtf_metric_sums_wide on a BNMTF handle"); return BNMTF_ESTATE; }
+  return metric_sums_impl(h, Mp, A, nullptr, B, sums_out, Kc);
+}
+static int metric_sums_impl(bnmtf_handle h, const uint8_t* Mp, const double* A, const double* S, const double* B, double sums_out[6], int Kc_given) {
   HIPCHK(hipSetDevice(h->device));
   const int I = h->I, J = h->J;
   std::vector<double> a_own, b_own, as;
@@ -1582,7 +1659,12 @@ int bnmtf_metric_sums(bnmtf_handle h, const uint8_t* Mp, const double* A, const 
     Kc = h->L > 0 ? h->L : h->K;
     if (h->L > 0) { set_error("bnmtf_metric_sums: S required for a BNMTF handle"); return BNMTF_EINVAL; }
   }
-  if (!h->Ad) { CHK(dalloc(&h->Ad, (size_t)I * 64, false)); CHK(dalloc(&h->Bd, (size_t)J * 64, false)); }
+  if (A && !S && h->L == 0 && Kc_given > 0) Kc = Kc_given;       // (a column-blocked factorisation hands over all its columns: bnmtf_metric_sums_wide)
+  if (!h->Ad || h->ABd_width < Kc) {
+    dfree(h->Ad); dfree(h->Bd); h->Ad = nullptr; h->Bd = nullptr;
+    h->ABd_width = std::max(64, Kc);
+    CHK(dalloc(&h->Ad, (size_t)I * h->ABd_width, false)); CHK(dalloc(&h->Bd, (size_t)J * h->ABd_width, false));
+  }
   HIPCHK(hipMemcpyAsync(h->Ad, A, sizeof(double) * (size_t)I * Kc, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->Bd, B, sizeof(double) * (size_t)J * Kc, hipMemcpyHostToDevice, h->stream));
   const uint8_t* mask = h->Mtrain;

@@ -180,23 +180,37 @@ __global__ __launch_bounds__(256) void metric_kernel(MetricArgs a) {
   const int K = a.K;
   const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
   const int tid = threadIdx.y * 32 + threadIdx.x;
-  for (int t = tid; t < 32 * K; t += 256) {
-    const int r = t / K, k = t % K;
-    At[r * 65 + k] = (i0 + r < a.I) ? a.A[(size_t)(i0 + r) * K + k] : 0.0;
-    Bt[r * 65 + k] = (j0 + r < a.J) ? a.B[(size_t)(j0 + r) * K + k] : 0.0;
-  }
-  __syncthreads();
   double s[7] = {0, 0, 0, 0, 0, 0, 0};
   const int j = j0 + threadIdx.x;
+  // the contraction in chunks of 64 columns (round 6: ranks above 64 -- the tiles hold 64): the element's product and the
+  // product of squares accumulate over the chunks, the sums follow behind the last one
+  double pr4[4] = {0, 0, 0, 0}, sq4[4] = {0, 0, 0, 0};
+  for (int k0 = 0; k0 < K; k0 += 64) {
+    const int kc = min(64, K - k0);
+    if (k0) __syncthreads();
+    for (int t = tid; t < 32 * kc; t += 256) {
+      const int r = t / kc, k = t % kc;
+      At[r * 65 + k] = (i0 + r < a.I) ? a.A[(size_t)(i0 + r) * K + k0 + k] : 0.0;
+      Bt[r * 65 + k] = (j0 + r < a.J) ? a.B[(size_t)(j0 + r) * K + k0 + k] : 0.0;
+    }
+    __syncthreads();
+    for (int rr = 0; rr < 4; ++rr) {
+      const int il = threadIdx.y + 8 * rr, i = i0 + il;
+      if (i < a.I && j < a.J && a.Mp[(size_t)i * a.J + j]) {
+        double pr = pr4[rr], sq = sq4[rr];
+        for (int k = 0; k < kc; ++k) {
+          const double av = At[il * 65 + k], bv = Bt[threadIdx.x * 65 + k];
+          pr = fma(av, bv, pr);
+          sq = fma(av * av, bv * bv, sq);
+        }
+        pr4[rr] = pr; sq4[rr] = sq;
+      }
+    }
+  }
   for (int rr = 0; rr < 4; ++rr) {
     const int il = threadIdx.y + 8 * rr, i = i0 + il;
     if (i < a.I && j < a.J && a.Mp[(size_t)i * a.J + j]) {
-      double pr = 0.0, sq = 0.0;
-      for (int k = 0; k < K; ++k) {
-        const double av = At[il * 65 + k], bv = Bt[threadIdx.x * 65 + k];
-        pr = fma(av, bv, pr);
-        sq = fma(av * av, bv * bv, sq);
-      }
+      const double pr = pr4[rr], sq = sq4[rr];
       const double r = (double)a.R[(size_t)i * a.J + j];
       s[0] += 1.0; s[1] += r; s[2] += r * r; s[3] += pr; s[4] += pr * pr; s[5] += r * pr; s[6] -= sq;
     }

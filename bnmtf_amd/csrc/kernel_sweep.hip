@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void sweep_generic_kernel(SweepArgs a) {
       if (tp.live) {
         for (uint32_t round = 0; round < 64u; ++round) {
           float xc;
-          const bool acc = tn_candidate(tp, (uint32_t)gi, (uint32_t)k, a.it, a.stream, round * 64u + lane,
+          const bool acc = tn_candidate(tp, (uint32_t)gi, a.col0 + (uint32_t)k, a.it, a.stream, round * 64u + lane,
                                         a.key0, a.key1, &xc);
           const unsigned long long m = __ballot(acc);
           if (m) { xnew = tn_guard(__shfl(xc, __ffsll((long long)m) - 1, 64)); break; }

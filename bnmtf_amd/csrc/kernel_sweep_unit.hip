@@ -132,7 +132,7 @@ __device__ __forceinline__ void sweep_unit_body(const SweepArgs& a, const FastAr
   if (MODE == kSweepDraw) {
     for (int e = lane; e < KP * NC; e += 64) {
       const int c = e % NC, col = e / NC;
-      const U4 r = philox4x32_10(gi, (uint32_t)col, a.it, a.stream + 16u * (uint32_t)c, a.key0, a.key1);
+      const U4 r = philox4x32_10(gi, a.col0 + (uint32_t)col, a.it, a.stream + 16u * (uint32_t)c, a.key0, a.key1);
       const TnCand cd = tn_cand_pre(r.x, r.y);
       tab[(size_t)wave * KP * NC + e] = f32x4t{cd.nl, cd.z, cd.sw, 0.f};
     }
@@ -267,7 +267,7 @@ __device__ __forceinline__ void sweep_unit_body(const SweepArgs& a, const FastAr
       if (__builtin_expect(live && m == 0ull, 0)) {
         uint32_t cbase = NC;
         do {
-          const U4 r = philox4x32_10(gi, (uint32_t)k, a.it, a.stream + 16u * (cbase + (uint32_t)lane), a.key0, a.key1);
+          const U4 r = philox4x32_10(gi, a.col0 + (uint32_t)k, a.it, a.stream + 16u * (cbase + (uint32_t)lane), a.key0, a.key1);
           acc = tn_eval_fast(tf, r.x, r.y, &xc);
           xc = tn_guard(xc);
           m = __ballot(acc);

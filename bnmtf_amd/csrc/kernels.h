@@ -68,6 +68,8 @@ struct SweepArgs {
   int cond_k;                // >= 0: only evaluate column cond_k, write numer/tau, change nothing
   int qinit_only;            // generic kernel: compute q = X_i . Xo_j on the missing entries and stop
   int only_k;                // >= 0 (VB hooks): update only this column (update_U(k) / update_V(k))
+  uint32_t col0;             // this factor holds columns [col0, col0 + K) of a wider factorisation (ranks above 64 run as column blocks:
+                             // bnmf_set_column_block): the Philox column word of local column k is col0 + k
   float min_x;               // mode updates: lower clamp of the new value (ICM minimum_TN; 0 otherwise)
   int vb_moments;            // VB: also refresh exp/var from the new mu/tau (update_exp_U(k))
   double* vb_stats;          // VB: [n][8] per-unit ELBO / exp_square_diff partial sums (may be null)
@@ -189,6 +191,12 @@ void launch_post_gram_rows(const PostArgs& a, int own0, int own1, hipStream_t st
 // bnmtf_create's passes over the I x J data, on the device (kernel_layout.hip): the masked (and, for the rows direction, transposed)
 // contraction operand big[r][ul], and every unit's missing inner indices in order (64-wide slots, padded with m)
 void launch_masked_operand(const float* R, const uint8_t* M, int I, int J, int by_rows, int unit0, int n, int m, float* out, int ld, hipStream_t st);
+// the same operand for the RESIDUAL data of a column block: M ? R - sum_b A_b[i] . B_b[j] : 0 (up to kMaxOtherBlocks products of
+// width W_b, row-major [.][KP_b] factors): what the other column blocks of a wider factorisation explain is taken off the data
+constexpr int kMaxOtherBlocks = 3;
+struct ResidualSpec { int n; const float* A[kMaxOtherBlocks]; const float* B[kMaxOtherBlocks]; int KP[kMaxOtherBlocks]; int W[kMaxOtherBlocks]; };
+void launch_residual_operand(const float* R, const uint8_t* M, int I, int J, int by_rows, int unit0, int n, int m, float* out, int ld,
+                             const ResidualSpec& rs, hipStream_t st);
 void launch_missing_lists(const uint8_t* M, int I, int J, int by_rows, int unit0, int n, int m, const uint32_t* ptr, uint32_t* idx, hipStream_t st);
 // q hand-over tables of one writer / reader pair of directions, built on the device (kernel_handover.hip)
 struct HandoverArgs {

@@ -39,6 +39,9 @@ class nmf_icm(bnmf_gibbs_optimised):
     def run(self, iterations, minimum_TN=0.):
         """:114-150.  One device call runs all iterations; returns None like the reference."""
         it = int(iterations)
+        if self._blocks is not None:            # ranks above 64: column blocks (_blocked.py), ICM rules
+            self._run_blocked(it, _lib.UPDATE_ICM, False, None, minimum_TN=float(minimum_TN), icm=True)
+            return
         self._push()
         taus = np.zeros(it); perf = np.zeros((it, 3)); times = np.zeros(it)
         L = _lib.lib()

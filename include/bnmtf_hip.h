@@ -111,6 +111,8 @@ BNMTF_API int bnmtf_get_expectation(bnmtf_handle h, double* A, double* S, double
 
 /* Gibbs iteration counter = RNG counter word 2 (continues across run calls). */
 BNMTF_API int bnmtf_set_iteration(bnmtf_handle h, uint64_t it);
+/* tau alone (self.tau = ... between half sweeps: the factors on the device stay as they are) */
+BNMTF_API int bnmtf_set_tau(bnmtf_handle h, double tau);
 BNMTF_API int bnmtf_get_iteration(bnmtf_handle h, uint64_t* it);
 
 /* ---- BNMF Gibbs state: attributes U, V, tau (bnmf_gibbs_optimised.py:102-117) */
@@ -146,6 +148,26 @@ BNMTF_API int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_ou
 BNMTF_API int bnmf_gibbs_run_many(const bnmtf_handle* hs, int n_models, int n_iter, int update, float* const* U_outs, float* const* V_outs,
                         double* const* tau_outs, double* const* perf_outs, double* const* times_outs,
                         double* const* U_final, double* const* V_final, double* const* tau_final);
+
+/* ---- ranks above 64: a BNMF factorisation as column blocks (round 6) -------
+ * The reference takes any K (code/models/bnmf_gibbs_optimised.py:54-78).  The kernels hold a latent factor per wave lane
+ * (K <= BNMTF_MAX_RANK), so a wider model runs as ceil(K / 64) column blocks, one handle each, driven by the host class
+ * (bnmtf_amd/_blocked.py): the conditionals of block b's columns given the other blocks are those of a rank-K_b model on
+ * the residual data R - sum_{b' != b} U_b' V_b'^T, so the blocks' half sweeps in turn -- all blocks' rows (:134-137), then
+ * all blocks' columns (:139-142) -- are the reference's sequential column order.  One GPU, BNMF Gibbs / ICM. */
+/* this handle holds columns [col0, col0 + K) of the wider model: the Philox column word of its column k is col0 + k (the
+ * draws are keyed by the wide model's column index: oracle/rng.py); no one-launch path, no q hand-over */
+BNMTF_API int bnmf_set_column_block(bnmtf_handle h, int col0);
+/* the contraction operands of h become M . (R - sum_b U_b V_b^T) over the n_others (<= 3) handles' current factors
+ * (n_others = 0: M . R again); predict() / metric entry points keep the full R */
+BNMTF_API int bnmf_set_residual_data(bnmtf_handle h, const bnmtf_handle* others, int n_others);
+/* one half of an iteration of run(): contraction, the K sequential column updates of U (which = 0, :134-137) or V
+ * (which = 1, :139-142) with the handle's current tau and iteration counter, then the relayout + Gram the other half reads.
+ * tau, metrics, samples and the iteration counter are the caller's. */
+BNMTF_API int bnmf_half_sweep(bnmtf_handle h, int which, int update);
+/* bnmtf_metric_sums for explicit factors of ANY width Kc: A [I][Kc], B [J][Kc] (compute_MSE / R2 / Rp, :208-223, and
+ * beta_s, :164-165, of a column-blocked model) */
+BNMTF_API int bnmtf_metric_sums_wide(bnmtf_handle h, const uint8_t* Mp, const double* A, const double* B, int Kc, double sums_out[6]);
 
 /* ---- BNMTF Gibbs (bnmtf_gibbs_optimised.py) ---------------------------- */
 BNMTF_API int bnmtf_set_state(bnmtf_handle h, const double* F, const double* S, const double* G, double tau);

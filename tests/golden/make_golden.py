@@ -525,6 +525,42 @@ def make_gdsc():
     np.savez_compressed(os.path.join(HERE, "gdsc.npz"), **out)
 
 
+def make_wide_rank():
+    """Ranks above 64 (round 6: the device runs them as column blocks): the reference's conditional parameters for every column
+    of a K = 96 model from a random state, and a whole nmf_icm trajectory at K = 70 (deterministic)."""
+    from BNMTF.code.models.bnmf_gibbs_optimised import bnmf_gibbs_optimised
+    from BNMTF.code.models.nmf_icm import nmf_icm
+    rs = np.random.RandomState(2026)
+    out = {}
+    I, J, K = 57, 44, 96
+    R = rs.exponential(1.0, (I, 8)) @ rs.exponential(1.0, (J, 8)).T + rs.normal(0, 1, (I, J))
+    M = rand_mask(rs, I, J, 0.25)
+    pri = dict(alpha=2.0, beta=0.5, lambdaU=rs.uniform(0.05, 2.0, (I, K)), lambdaV=rs.uniform(0.05, 2.0, (J, K)))
+    b = bnmf_gibbs_optimised(R, M, K, pri)
+    b.U = rs.exponential(0.3, (I, K)); b.V = rs.exponential(0.3, (J, K)); b.tau = 0.8
+    for k_, v in dict(R=R, M=M, K=K, U=b.U, V=b.V, tau=b.tau, **pri).items():
+        out["k96/" + k_] = np.asarray(v)
+    tU = np.array([b.tauU(k) for k in range(K)]); mU = np.array([b.muU(tU[k], k) for k in range(K)])
+    tV = np.array([b.tauV(k) for k in range(K)]); mV = np.array([b.muV(tV[k], k) for k in range(K)])
+    out["k96/tauU"], out["k96/muU"], out["k96/tauV"], out["k96/muV"] = tU, mU, tV, mV
+    out["k96/beta_s"] = np.float64(b.beta_s())
+    p = b.predict_while_running()
+    out["k96/perf"] = np.array([p["MSE"], p["R^2"], p["Rp"]])
+    I, J, K = 60, 48, 70
+    R = rs.exponential(1.0, (I, 6)) @ rs.exponential(1.0, (J, 6)).T + rs.normal(0, 1, (I, J))
+    M = rand_mask(rs, I, J, 0.15)
+    pri = dict(alpha=1.0, beta=1.0, lambdaU=np.ones((I, K)), lambdaV=np.ones((J, K)))
+    np.random.seed(5)
+    c = nmf_icm(R, M, K, pri)
+    c.initialise("random")
+    out["icm70/R"], out["icm70/M"], out["icm70/U0"], out["icm70/V0"], out["icm70/tau0"] = R, M, c.U.copy(), c.V.copy(), np.array(c.tau)
+    with quiet(), np.errstate(all="ignore"):
+        c.run(6, minimum_TN=0.01)
+    out["icm70/U"], out["icm70/V"], out["icm70/all_tau"] = c.U.copy(), c.V.copy(), c.all_tau.copy()
+    out["icm70/mse"] = np.array(c.all_performances["MSE"])
+    np.savez_compressed(os.path.join(HERE, "wide_rank.npz"), **out)
+
+
 def make_toy_data():
     """The reference's toy inputs (data files its own tests/experiments hold) as one fixture."""
     out = {}
@@ -537,7 +573,7 @@ def make_toy_data():
 
 if __name__ == "__main__":
     import_reference()
-    which = sys.argv[1:] or ["toy", "bnmf", "bnmtf", "vb", "tn", "traj", "icm", "trivb", "masks", "kmeans", "gdsc"]
+    which = sys.argv[1:] or ["toy", "bnmf", "bnmtf", "vb", "tn", "traj", "icm", "trivb", "masks", "kmeans", "gdsc", "wide"]
     if "toy" in which: make_toy_data()
     if "bnmf" in which: make_bnmf_cond()
     if "bnmtf" in which: make_bnmtf_cond()
@@ -549,6 +585,7 @@ if __name__ == "__main__":
     if "masks" in which: make_masks()
     if "kmeans" in which: make_kmeans()
     if "gdsc" in which: make_gdsc()
+    if "wide" in which: make_wide_rank()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

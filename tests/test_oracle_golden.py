@@ -290,3 +290,29 @@ def test_gibbs_toy_trajectory_within_reference_bands(golden):
     m_ref = ref[:, 150:].mean(axis=1)
     assert m_ref.min() * 0.97 < mse[150:].mean() < m_ref.max() * 1.03
     assert abs(np.mean(b.all_tau[150:]) - g["tau"][:, 150:].mean()) < 0.05
+
+
+def test_oracle_matches_the_reference_at_ranks_above_64(golden):
+    """tests/golden/wide_rank.npz (round 6): the reference's conditional parameters for every column of a K = 96 model and its
+    nmf_icm trajectory at K = 70 -- what pins the oracle where the device runs column blocks (tests/test_wide_rank_gpu.py)."""
+    c = golden("wide_rank.npz").case("k96")
+    K = int(c["K"])
+    pri = dict(alpha=float(c["alpha"]), beta=float(c["beta"]), lambdaU=c["lambdaU"], lambdaV=c["lambdaV"])
+    o = O.BNMFGibbsOracle(c["R"], c["M"], K, pri)
+    o.U, o.V, o.tau = c["U"].copy(), c["V"].copy(), float(c["tau"])
+    for k in (0, 63, 64, 95):
+        t = o.tauU(k)
+        np.testing.assert_allclose(t, c["tauU"][k], rtol=1e-12)
+        np.testing.assert_allclose(o.muU(t, k), c["muU"][k], rtol=1e-9, atol=1e-12)
+        t = o.tauV(k)
+        np.testing.assert_allclose(t, c["tauV"][k], rtol=1e-12)
+        np.testing.assert_allclose(o.muV(t, k), c["muV"][k], rtol=1e-9, atol=1e-12)
+    assert abs(o.beta_s() / float(c["beta_s"]) - 1) < 1e-12
+    g = golden("wide_rank.npz").case("icm70")
+    I, J = g["R"].shape
+    pri = dict(alpha=1.0, beta=1.0, lambdaU=np.ones((I, 70)), lambdaV=np.ones((J, 70)))
+    m = O.NMFICMOracle(g["R"], g["M"], 70, pri)
+    m.U, m.V, m.tau = g["U0"].copy(), g["V0"].copy(), float(g["tau0"])
+    m.run(6, minimum_TN=0.01)
+    np.testing.assert_allclose(m.all_tau, g["all_tau"], rtol=1e-9)
+    np.testing.assert_allclose(m.U, g["U"], rtol=1e-8, atol=1e-10)
