@@ -35,14 +35,15 @@ def block_ranges(K):
 class ColumnBlocks(object):
     """The child models of a wide bnmf_gibbs / nmf_icm instance `owner` (which keeps the full-width U, V, tau attributes)."""
 
-    def __init__(self, owner, child_cls):
+    def __init__(self, owner, child_cls, seeded=True):
         self.owner = owner
         self.ranges = block_ranges(owner.K)
         assert len(self.ranges) <= MAX_BLOCKS
         self.children = []
         for (c0, c1) in self.ranges:
             pri = {"alpha": owner.alpha, "beta": owner.beta, "lambdaU": owner.lambdaU[:, c0:c1], "lambdaV": owner.lambdaV[:, c0:c1]}
-            ch = child_cls(owner.R, owner.M, c1 - c0, pri, seed=owner._seed, device=owner._device, verbose=False)
+            kw = {"seed": owner._seed} if seeded else {}
+            ch = child_cls(owner.R, owner.M, c1 - c0, pri, device=owner._device, verbose=False, **kw)
             self.children.append(ch)
         self._ready = False
         self.iteration = 0
@@ -152,3 +153,65 @@ class ColumnBlocks(object):
     def close(self):
         for ch in self.children:
             ch.close()
+
+
+class VBColumnBlocks(ColumnBlocks):
+    """The same for bnmf_vb_optimised (bnmf_vb_optimised.py:121-153): update_U(k) / update_exp_U(k) of block b's columns are the
+    single-block updates on the residual data R - sum_{b' != b} E[U_b'] E[V_b']^T (the other blocks' part of
+    M . (R - E[U] E[V]^T + ...), :189-195, moves to the data side; tauU of a column involves that column alone);
+    exp_square_diff (:185-187) = the full-width masked SSE + the blocks' second-moment sums (a sum over columns)."""
+    NAMES = ("muU", "tauU", "expU", "varU", "muV", "tauV", "expV", "varV")
+
+    def __init__(self, owner, child_cls):
+        ColumnBlocks.__init__(self, owner, child_cls, seeded=False)
+
+    def _prepare(self):
+        if self._ready:
+            return
+        for ch, (c0, _) in zip(self.children, self.ranges):
+            _lib.check(_lib.lib().bnmf_set_column_block(ch._handle(), int(c0)))
+        self._ready = True
+
+    def push(self, exptau):
+        self._prepare()
+        o = self.owner
+        for ch, (c0, c1) in zip(self.children, self.ranges):
+            for n in self.NAMES:
+                setattr(ch, n, np.ascontiguousarray(np.asarray(getattr(o, n), dtype=float)[:, c0:c1]))
+            ch.exptau = float(exptau)
+            ch._device_state = None
+            ch._push()
+
+    def pull(self):
+        o = self.owner
+        out = {n: np.zeros((o.I if n.endswith("U") else o.J, o.K)) for n in self.NAMES}
+        for ch, (c0, c1) in zip(self.children, self.ranges):
+            ch._pull()
+            for n in self.NAMES:
+                out[n][:, c0:c1] = getattr(ch, n)
+        return out
+
+    def esd(self, expU, expV):
+        """exp_square_diff of the full-width model for the state the children hold."""
+        s = self.metric_sums(None, expU, expV)
+        corr = 0.0
+        t = np.zeros(2)
+        for h in self.handles():
+            _lib.check(_lib.lib().bnmf_vb_esd_terms(h, _lib.ptr(t)))
+            corr += t[1]
+        return (s[2] - 2.0 * s[5] + s[4]) + corr, s
+
+    def update(self, which, k, moments):
+        b = int(k) // BLOCK
+        if len(self.children) > 1:
+            self.residual(b)
+        _lib.check(_lib.lib().bnmf_vb_update(self.handles()[b], int(which), int(k) - BLOCK * b, int(moments)))
+
+    def sweep_both(self):
+        L = _lib.lib()
+        hs = self.handles()
+        for which in (0, 1):
+            for b in range(len(hs)):
+                if len(hs) > 1:
+                    self.residual(b)
+                _lib.check(L.bnmf_vb_half_sweep(hs[b], which))

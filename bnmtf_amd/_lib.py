@@ -78,6 +78,8 @@ _SIGS = {
     "bnmtf_metric_sums": ([_P, _P, _P, _P, _P, _P], C.c_int),
     "bnmtf_metric_sums_wide": ([_P, _P, _P, _P, C.c_int, _P], C.c_int),
     "bnmtf_set_tau": ([_P, C.c_double], C.c_int),
+    "bnmf_vb_half_sweep": ([_P, C.c_int], C.c_int),
+    "bnmf_vb_esd_terms": ([_P, _P], C.c_int),
     "bnmf_set_column_block": ([_P, C.c_int], C.c_int),
     "bnmf_set_residual_data": ([_P, _P, C.c_int], C.c_int),
     "bnmf_half_sweep": ([_P, C.c_int, C.c_int], C.c_int),

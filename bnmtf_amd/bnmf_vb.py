@@ -14,6 +14,7 @@ import scipy.special
 from . import _lib
 from ._base import DeviceModel, broadcast_lambda, check_rank, check_R_M, metrics_from_sums
 from .distributions import TN_vector_expectation, TN_vector_variance, gamma_expectation, gamma_expectation_log
+from ._blocked import BLOCK, MAX_BLOCKS, VBColumnBlocks
 
 
 class bnmf_vb_optimised(DeviceModel):
@@ -22,7 +23,7 @@ class bnmf_vb_optimised(DeviceModel):
         self.M = np.array(M, dtype=float)
         self.K = K
         check_R_M(self.R, self.M)
-        check_rank("bnmf_vb_optimised", 64, K=self.K)
+        check_rank("bnmf_vb_optimised", BLOCK * MAX_BLOCKS, K=self.K)
         (self.I, self.J) = self.R.shape
         self.size_Omega = self.M.sum()
         self.alpha, self.beta = float(priors['alpha']), float(priors['beta'])
@@ -30,15 +31,51 @@ class bnmf_vb_optimised(DeviceModel):
         self.lambdaV = broadcast_lambda(priors['lambdaV'], (self.J, self.K), "lambdaV")
         self.verbose = verbose
         self._init_device(0, device, rank, world, comm_id)      # VB draws nothing: the key is unused, 0 on every rank
+        # ranks above 64 (the reference has no limit, :53-77): column blocks of at most 64, one device model each (_blocked.py)
+        self._blocks = None
+        if self.K > BLOCK:
+            assert world == 1, "ranks above %d run on one GPU (column blocks: DESIGN.md section 8)" % BLOCK
+            self._blocks = VBColumnBlocks(self, bnmf_vb_optimised)
 
     def _lambda_arrays(self):
         return self.lambdaU, self.lambdaV, None
+
+    def close(self):
+        if getattr(self, "_blocks", None) is not None:
+            self._blocks.close()
+        super(bnmf_vb_optimised, self).close()
+
+    def _handle(self):
+        if getattr(self, "_blocks", None) is not None:       # shape-only entry points: the first block's handle
+            return self._blocks.handles()[0]
+        return super(bnmf_vb_optimised, self)._handle()
+
+    def _metric_sums(self, M_pred, A, S, B):
+        if self._blocks is not None:
+            if M_pred is not None:
+                Mp_ = np.asarray(M_pred)
+                assert ((Mp_ == 0) | (Mp_ == 1)).all(), "The indicator matrix M_pred must contain only 0 and 1."
+            return self._blocks.metric_sums(M_pred, self.expU if A is None else A, self.expV if B is None else B)
+        return super(bnmf_vb_optimised, self)._metric_sums(M_pred, A, S, B)
+
+    def describe(self):
+        if self._blocks is not None:
+            self._blocks._prepare()
+            return "column blocks %s: " % (self._blocks.ranges,) + " | ".join(ch.describe() for ch in self._blocks.children)
+        return super(bnmf_vb_optimised, self).describe()
 
     # -- state hand-off -------------------------------------------------------
     _NAMES = ("muU", "tauU", "expU", "varU", "muV", "tauV", "expV", "varV")
 
     def _push(self):
         exptau = float(getattr(self, "exptau", 1.0))
+        if self._blocks is not None:
+            held = getattr(self, "_device_state", None)
+            if held is not None and held[1] == exptau and all(np.array_equal(getattr(self, n), a) for n, a in zip(self._NAMES, held[2])):
+                return
+            self._blocks.push(exptau)
+            self._device_state = (None, exptau, [np.array(getattr(self, n), dtype=float) for n in self._NAMES])
+            return
         # the state the device holds already (nothing touched the q parameters since the last run() pulled them): no upload,
         # and the device keeps what it carries between its half sweeps -- run(a); run(b) is the trajectory of run(a + b)
         held = getattr(self, "_device_state", None)
@@ -49,6 +86,12 @@ class bnmf_vb_optimised(DeviceModel):
         _lib.check(_lib.lib().bnmf_vb_set_state(self._handle(), *[_lib.ptr(a) for a in arrs], exptau))
 
     def _pull(self):
+        if self._blocks is not None:
+            got = self._blocks.pull()
+            for n in self._NAMES:
+                setattr(self, n, got[n])
+            self._device_state = (None, float(getattr(self, "exptau", 1.0)), [got[n].copy() for n in self._NAMES])
+            return
         shapes = [(self.I, self.K)] * 4 + [(self.J, self.K)] * 4
         arrs = [np.zeros(s) for s in shapes]
         _lib.check(_lib.lib().bnmf_vb_get_state(self._handle(), *[_lib.ptr(a) for a in arrs]))
@@ -77,6 +120,8 @@ class bnmf_vb_optimised(DeviceModel):
     def run(self, iterations):
         """:121-153.  all_elbo (the value the reference only prints) is kept as an extra attribute."""
         it = int(iterations)
+        if self._blocks is not None:
+            return self._run_blocked(it)
         self._push()
         exptau = np.zeros(it); perf = np.zeros((it, 3)); terms = np.zeros((it, 10)); times = np.zeros(it)
         _lib.check(_lib.lib().bnmf_vb_run(self._handle(), it, _lib.ptr(exptau), _lib.ptr(perf), _lib.ptr(terms), _lib.ptr(times)))
@@ -95,6 +140,33 @@ class bnmf_vb_optimised(DeviceModel):
         if self.verbose:
             for i in range(it):
                 print("Iteration %s. ELBO: %s. MSE: %s. R^2: %s. Rp: %s." % (i + 1, self.all_elbo[i], perf[i, 0], perf[i, 1], perf[i, 2]))
+        return
+
+    def _run_blocked(self, it):
+        """run() of a model wider than 64 columns (_blocked.py): per iteration the blocks' half sweeps in turn (:134-141), then
+        update_tau / update_exp_tau (:143-144) from the full-width exp_square_diff, the metrics and the ELBO (:146-150)."""
+        import time
+        blocks = self._blocks
+        self._push()
+        self.all_exp_tau, self.all_times, self.all_elbo = [], [], []
+        self.all_performances = {'MSE': [], 'R^2': [], 'Rp': []}
+        t0 = time.time()
+        for i in range(it):
+            blocks.sweep_both()
+            self._pull()
+            esd, s = blocks.esd(self.expU, self.expV)
+            self.alpha_s = self.alpha + self.size_Omega / 2.0
+            self.beta_s = self.beta + 0.5 * esd
+            self.update_exp_tau()
+            blocks.set_tau(self.exptau)
+            self._device_state = (None, float(self.exptau), self._device_state[2])
+            perf = metrics_from_sums(s)
+            elbo = self._elbo_given_esd(esd)
+            for m in ('MSE', 'R^2', 'Rp'):
+                self.all_performances[m].append(perf[m])
+            self.all_exp_tau.append(self.exptau); self.all_elbo.append(elbo); self.all_times.append(time.time() - t0)
+            if self.verbose:
+                print("Iteration %s. ELBO: %s. MSE: %s. R^2: %s. Rp: %s." % (i + 1, elbo, perf['MSE'], perf['R^2'], perf['Rp']))
         return
 
     def train(self, iterations, init_UV='random'):
@@ -123,12 +195,15 @@ class bnmf_vb_optimised(DeviceModel):
 
     def elbo(self):
         """:163-177 for the current attributes: exp_square_diff on the device, the O((I+J)K) sums on the host."""
+        return self._elbo_given_esd(self.exp_square_diff())
+
+    def _elbo_given_esd(self, esd):
         def sums(mu, tau, ex, var, lam):
             with np.errstate(all='ignore'):
                 return ((tau / 2. * (var + (ex - mu) ** 2)).sum(),
                         np.log(0.5 * scipy.special.erfc(-mu * np.sqrt(tau) / math.sqrt(2))).sum(),
                         np.log(tau).sum(), (lam * ex).sum())
-        return self._elbo_scalar_part(self.exp_square_diff(), self.alpha_s, self.beta_s, self.exptau, self.explogtau,
+        return self._elbo_scalar_part(esd, self.alpha_s, self.beta_s, self.exptau, self.explogtau,
                                       sums(self.muU, self.tauU, self.expU, self.varU, self.lambdaU),
                                       sums(self.muV, self.tauV, self.expV, self.varV, self.lambdaV))
 
@@ -141,6 +216,7 @@ class bnmf_vb_optimised(DeviceModel):
     def masked_sums(self, which):
         """Hook (tests): sum over the MISSING entries of a unit of the other factor's S2 = var + exp^2 and of its exp^2, per column --
         the chain-independent parts of tauU / muU (which = 0) or tauV / muV (which = 1), from the matrix-core product run() uses."""
+        assert self._blocks is None, "masked_sums is a hook of the single-block model (K <= %d)" % BLOCK
         self._push()
         n = self.I if which == 0 else self.J
         asq = np.zeros((n, self.K)); vsq = np.zeros((n, self.K))
@@ -153,12 +229,18 @@ class bnmf_vb_optimised(DeviceModel):
             if not hasattr(self, n):
                 setattr(self, n, np.ones((self.I if n.endswith("U") else self.J, self.K)))
         self._push()
+        if self._blocks is not None:
+            return self._blocks.esd(self.expU, self.expV)[0]
         out = C.c_double()
         _lib.check(_lib.lib().bnmf_vb_exp_square_diff(self._handle(), C.byref(out)))
         return out.value
 
     def _update(self, which, k, moments):
         self._push()
+        if self._blocks is not None:
+            self._blocks.update(which, k, moments)
+            self._pull()
+            return
         _lib.check(_lib.lib().bnmf_vb_update(self._handle(), which, int(k), int(moments)))
         self._pull()
 

@@ -1573,7 +1573,7 @@ int bnmf_set_residual_data(bnmtf_handle h, const bnmtf_handle* others, int n_oth
     bnmtf_model* o = others[b];
     if (!o || o == h || o->I != h->I || o->J != h->J || o->L != 0 || o->device != h->device || !o->have_state) { set_error("residual data: block %d does not fit (shape, device, state)", b); return BNMTF_EINVAL; }
     CHK(ensure_std(o));
-    if (!o->std_cur) { set_error("residual data: block %d's state is not on its multi-launch structures", b); return BNMTF_ESTATE; }
+    if (!o->std_cur && !o->vb_ready) { set_error("residual data: block %d's state is not on its multi-launch structures", b); return BNMTF_ESTATE; }
     HIPCHK(hipStreamSynchronize(o->stream));                 // (its last half sweep runs on its own stream)
     rs.A[b] = o->rows.X; rs.B[b] = o->cols.X; rs.KP[b] = o->rows.KP; rs.W[b] = o->rows.W;
   }

@@ -169,6 +169,13 @@ BNMTF_API int bnmf_half_sweep(bnmtf_handle h, int which, int update);
  * beta_s, :164-165, of a column-blocked model) */
 BNMTF_API int bnmtf_metric_sums_wide(bnmtf_handle h, const uint8_t* Mp, const double* A, const double* B, int Kc, double sums_out[6]);
 
+/* the variational model (bnmf_vb_optimised.py) as column blocks: one half of an iteration (:134-141) -- update_U(k) +
+ * update_exp_U(k) for every k (which = 0) or the same for V -- with the handle's current exptau (bnmtf_set_tau); and
+ * exp_square_diff() (:185-187) in its two parts, out[0] = sum_Omega (R - E[U] E[V]^T)^2, out[1] = the second-moment sum
+ * over the handle's own columns (additive over blocks) */
+BNMTF_API int bnmf_vb_half_sweep(bnmtf_handle h, int which);
+BNMTF_API int bnmf_vb_esd_terms(bnmtf_handle h, double out[2]);
+
 /* ---- BNMTF Gibbs (bnmtf_gibbs_optimised.py) ---------------------------- */
 BNMTF_API int bnmtf_set_state(bnmtf_handle h, const double* F, const double* S, const double* G, double tau);
 BNMTF_API int bnmtf_get_state(bnmtf_handle h, double* F, double* S, double* G, double* tau);

@@ -331,3 +331,25 @@ def test_joint_map_survives_a_walk_that_fails():
     for t in ts: t.start()
     for t in ts: t.join(timeout=30)
     assert not any(t.is_alive() for t in ts) and errs == ["the device call failed"] * 2
+
+
+def test_rank_limits_are_said_at_construction_and_wide_bnmf_models_are_column_blocks():
+    """The reference takes any rank (bnmf_gibbs_optimised.py:54-78).  Here: bnmf_gibbs / nmf_icm up to 256 (column blocks of 64,
+    _blocked.py: built without touching a device), the tri-factorisations up to 64 / 32 -- and what lies beyond is refused when
+    the class is constructed, with the limit in the message, not at the first device call of a search."""
+    import bnmtf_amd
+    from bnmtf_amd._lib import BnmtfError
+    from bnmtf_amd._blocked import block_ranges
+    R = np.ones((6, 5)); M = np.ones((6, 5))
+    pri = dict(alpha=1., beta=1., lambdaU=1., lambdaV=1.)
+    b = bnmtf_amd.bnmf_gibbs_optimised(R, M, 200, pri, verbose=False)
+    assert b._blocks is not None and b._blocks.ranges == [(0, 64), (64, 128), (128, 192), (192, 200)] == block_ranges(200)
+    assert [c.K for c in b._blocks.children] == [64, 64, 64, 8] and b._blocks.children[3].lambdaU.shape == (6, 8)
+    assert bnmtf_amd.nmf_icm(R, M, 65, pri, verbose=False)._blocks.ranges == [(0, 64), (64, 65)]
+    assert bnmtf_amd.bnmf_gibbs_optimised(R, M, 64, pri, verbose=False)._blocks is None
+    with pytest.raises(BnmtfError, match="K = 257 is outside what this build runs"):
+        bnmtf_amd.bnmf_gibbs_optimised(R, M, 257, pri, verbose=False)
+    with pytest.raises(BnmtfError, match="outside what this build runs"):
+        bnmtf_amd.bnmtf_gibbs_optimised(R, M, 65, 3, dict(alpha=1., beta=1., lambdaF=1., lambdaS=1., lambdaG=1.), verbose=False)
+    with pytest.raises(BnmtfError, match="outside what this build runs"):
+        bnmtf_amd.bnmf_vb_optimised(R, M, 65, pri, verbose=False)

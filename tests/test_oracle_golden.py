@@ -316,3 +316,15 @@ def test_oracle_matches_the_reference_at_ranks_above_64(golden):
     m.run(6, minimum_TN=0.01)
     np.testing.assert_allclose(m.all_tau, g["all_tau"], rtol=1e-9)
     np.testing.assert_allclose(m.U, g["U"], rtol=1e-8, atol=1e-10)
+
+
+def test_vb_oracle_matches_the_reference_at_k70(golden):
+    c = golden("wide_rank.npz").case("vb70")
+    pri = dict(alpha=1.0, beta=1.0, lambdaU=c["lambdaU"], lambdaV=c["lambdaV"])
+    o = O.BNMFVBOracle(c["R"], c["M"], 70, pri)
+    o.initialise("exp")
+    assert abs(o.exptau / float(c["exptau0"]) - 1) < 1e-12
+    o.run(5)
+    np.testing.assert_allclose(o.all_performances["MSE"], c["mse"], rtol=1e-9)
+    np.testing.assert_allclose(o.all_exp_tau, c["exptau"], rtol=1e-9)
+    np.testing.assert_allclose(o.expU, c["expU"], rtol=1e-7, atol=1e-12)

@@ -113,3 +113,33 @@ def test_post_run_api_and_device_side_expectation_of_a_wide_model():
     assert abs(ft / et - 1) < 1e-9
     assert abs(c.quality("loglikelihood", 4, 2) / q - 1) < 1e-6
     b.close(); c.close()
+
+
+def test_vb_trajectory_at_k70_matches_the_reference(golden):
+    """bnmf_vb_optimised beyond 64 columns (deterministic from init='exp'): five iterations against the reference's own numbers
+    (tests/golden/wide_rank.npz: vb70) -- MSE, exptau, the ELBO, the moments -- and single updates through the class hooks."""
+    from bnmtf_amd import bnmf_vb_optimised
+    c = golden("wide_rank.npz").case("vb70")
+    K = 70
+    pri = dict(alpha=1.0, beta=1.0, lambdaU=c["lambdaU"], lambdaV=c["lambdaV"])
+    b = bnmf_vb_optimised(c["R"], c["M"], K, pri, verbose=False)
+    b.initialise("exp")
+    assert abs(b.exptau / float(c["exptau0"]) - 1) < 1e-6
+    b.run(5)
+    np.testing.assert_allclose(b.all_performances["MSE"], c["mse"], rtol=1e-3)
+    np.testing.assert_allclose(b.all_exp_tau, c["exptau"], rtol=1e-3)
+    assert np.isneginf(b.all_elbo[0]) == np.isneginf(c["elbo"][0])
+    np.testing.assert_allclose(b.all_elbo[1:], c["elbo"][1:], rtol=1e-3)
+    for name in ("expU", "expV", "varU", "tauU", "muV"):
+        ref = c[name]
+        assert np.abs(getattr(b, name) - ref).max() < 3e-3 * max(1e-3, np.abs(ref).max()), name
+    # single updates on the second block, against the oracle from the state the run left
+    o = O.BNMFVBOracle(c["R"], c["M"], K, pri)
+    for n in ("muU", "tauU", "expU", "varU", "muV", "tauV", "expV", "varV"):
+        setattr(o, n, getattr(b, n).copy())
+    o.exptau = b.exptau
+    o.update_U(66); b.update_U(66)
+    np.testing.assert_allclose(b.tauU[:, 66], o.tauU[:, 66], rtol=5e-6)
+    assert np.abs(b.muU[:, 66] - o.muU[:, 66]).max() < 1e-4 * (1.0 + np.abs(o.muU[:, 66]).max())
+    assert abs(b.exp_square_diff() / o.exp_square_diff() - 1) < 1e-6
+    b.close()
