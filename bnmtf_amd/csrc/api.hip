@@ -1213,7 +1213,7 @@ int bnmtf_destroy(bnmtf_handle h) {
   dfree(h->muS); dfree(h->tauS); dfree(h->varS); dfree(h->mv_rows); dfree(h->mv_cols); dfree(h->tri_order); dfree(h->tri_sums);
   dfree(h->ss_Wc); dfree(h->ss_Gc); dfree(h->ss_cands); dfree(h->ss_slabs); dfree(h->ss_AB); dfree(h->ss_r); dfree(h->ss_bpart); dfree(h->ss_tinv); dfree(h->ss_rec);
   dfree(h->Rfull); h->Mtrain = nullptr; h->out6 = nullptr; h->tau_d = nullptr; h->tau_f = nullptr; h->acc = nullptr;   // (one allocation: bnmtf_create)
-  dfree(h->Mscratch); dfree(h->Ad); dfree(h->Bd);
+  dfree(h->Mscratch); dfree(h->Ad); dfree(h->Bd); dfree(h->AdW); dfree(h->BdW);
   dfree(h->A2d); dfree(h->B2d); dfree(h->vb_rec); dfree(h->vbred);
   dfree(h->rec); dfree(h->gunit); dfree(h->S);
   for (auto& pe : h->pending_events) { (void)hipEventDestroy(pe.second.first); (void)hipEventDestroy(pe.second.second); }
@@ -1660,13 +1660,19 @@ static int metric_sums_impl(bnmtf_handle h, const uint8_t* Mp, const double* A, 
     if (h->L > 0) { set_error("bnmtf_metric_sums: S required for a BNMTF handle"); return BNMTF_EINVAL; }
   }
   if (A && !S && h->L == 0 && Kc_given > 0) Kc = Kc_given;       // (a column-blocked factorisation hands over all its columns: bnmtf_metric_sums_wide)
-  if (!h->Ad || h->ABd_width < Kc) {
-    dfree(h->Ad); dfree(h->Bd); h->Ad = nullptr; h->Bd = nullptr;
-    h->ABd_width = std::max(64, Kc);
-    CHK(dalloc(&h->Ad, (size_t)I * h->ABd_width, false)); CHK(dalloc(&h->Bd, (size_t)J * h->ABd_width, false));
-  }
-  HIPCHK(hipMemcpyAsync(h->Ad, A, sizeof(double) * (size_t)I * Kc, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->Bd, B, sizeof(double) * (size_t)J * Kc, hipMemcpyHostToDevice, h->stream));
+  // operand copies: the handle's [I][64] / [J][64] buffers (part of a small model's arena: never freed here); factors wider than
+  // 64 columns (a column-blocked model) get buffers of their own
+  double* Ad = h->Ad; double* Bd = h->Bd;
+  if (Kc > 64) {
+    if (h->ABd_width < Kc) {
+      dfree(h->AdW); dfree(h->BdW); h->AdW = nullptr; h->BdW = nullptr;
+      CHK(dalloc(&h->AdW, (size_t)I * Kc, false)); CHK(dalloc(&h->BdW, (size_t)J * Kc, false));
+      h->ABd_width = Kc;
+    }
+    Ad = h->AdW; Bd = h->BdW;
+  } else if (!h->Ad) { CHK(dalloc(&h->Ad, (size_t)I * 64, false)); CHK(dalloc(&h->Bd, (size_t)J * 64, false)); Ad = h->Ad; Bd = h->Bd; }
+  HIPCHK(hipMemcpyAsync(Ad, A, sizeof(double) * (size_t)I * Kc, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(Bd, B, sizeof(double) * (size_t)J * Kc, hipMemcpyHostToDevice, h->stream));
   const uint8_t* mask = h->Mtrain;
   if (Mp) {
     if (!h->Mscratch) CHK(dalloc(&h->Mscratch, (size_t)I * J, false));
@@ -1674,7 +1680,7 @@ static int metric_sums_impl(bnmtf_handle h, const uint8_t* Mp, const double* A, 
     mask = h->Mscratch;
   }
   MetricArgs m;
-  m.R = h->Rfull; m.Mp = mask; m.I = I; m.J = J; m.A = h->Ad; m.B = h->Bd; m.K = Kc; m.out6 = h->out6; m.A2 = nullptr; m.B2 = nullptr;
+  m.R = h->Rfull; m.Mp = mask; m.I = I; m.J = J; m.A = Ad; m.B = Bd; m.K = Kc; m.out6 = h->out6; m.A2 = nullptr; m.B2 = nullptr;
   launch_metric_sums(m, h->stream);
   HIPCHK(hipMemcpyAsync(sums_out, h->out6, 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));

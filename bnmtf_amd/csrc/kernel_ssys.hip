@@ -209,8 +209,114 @@ __global__ __launch_bounds__(256) void ssys_gemm_kernel(SSysGemmArgs a) {
         slab[(size_t)row * PLp + tr * 64 + 32 * y + c] = acc[x][y][t];
       }
 }
+// Round 6: the same product on the bf16 matrix cores, fp32-exact.  Every fp32 operand is split on the fly into three bf16 terms
+// (round-to-nearest residuals; kernel_gemm.hip's split, restated here: the two kernels share no header) and a product is six
+// v_mfma_f32_32x32x16_bf16 (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid; what is dropped is below 2^-24 of the product and has
+// no systematic sign): 6 x 32 cycles per 16 columns and tile against 8 x 64 of the f32 form.  A step is 16 columns j: lane (c, g)
+// takes rows j0 + 8 g + 0..7 -- eight 8-byte loads per operand, the same count as before (a load still gives the lane its element
+// of BOTH interleaved tiles) -- splits its four fragments (a0, a1, b0, b1) and issues the 24 products; the next step's rows are
+// on their way in a second register set meanwhile.  Ranges are cut at multiples of 16 columns; past a range's end the zero rows
+// behind the arrays are read.  Same tiles, same slab layout, same epilogue as ssys_gemm_kernel.
+namespace {
+typedef __bf16 g_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 g_bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t g_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t g_pack_rne(float a0, float a1) {
+  f32x2 v; v.x = a0; v.y = a1;
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, g_bf16x2));
+}
+__device__ __forceinline__ void g_split3(const float (&v)[8], g_u32x4& hi, g_u32x4& mid, g_u32x4& lo) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float a0 = v[2 * p], a1 = v[2 * p + 1];
+    const uint32_t h = g_pack_rne(a0, a1);
+    hi[p] = h;
+    const float b0 = a0 - __builtin_bit_cast(float, h << 16);                 // exact
+    const float b1 = a1 - __builtin_bit_cast(float, h & 0xffff0000u);
+    const uint32_t m = g_pack_rne(b0, b1);
+    mid[p] = m;
+    const float c0 = b0 - __builtin_bit_cast(float, m << 16);                 // exact
+    const float c1 = b1 - __builtin_bit_cast(float, m & 0xffff0000u);
+    lo[p] = g_pack_rne(c0, c1);
+  }
+}
+}  // namespace
+__host__ __device__ inline int ssys_gemm_range(int n, int nsplit) { return ((n + nsplit - 1) / nsplit + 15) & ~15; }     // columns per range: a multiple of a step
+__global__ __launch_bounds__(256) void ssys_gemm_bf16_kernel(SSysGemmArgs a) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, c = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int PKp = tri_padded(a.K), PLp = tri_padded(a.L), TR = PLp / 64;
+  const int wt = blockIdx.x * 4 + wave, sp = blockIdx.y;
+  if (wt >= (PKp / 64) * TR) return;
+  const int tp = wt / TR, tr = wt % TR;
+  const int per = ssys_gemm_range(a.n, a.nsplit);
+  const int jbeg = sp * per, jend = min(a.n, jbeg + per);
+  const int offA = 4 * (tp * 64 + 2 * c), offB = 4 * (tr * 64 + 2 * c);
+  const __amdgpu_buffer_rsrc_t rsA = panel_rsrc(a.Wc, (size_t)(a.n + 2) * PKp * 4), rsB = panel_rsrc(a.Gc, (size_t)(a.n + 2) * PLp * 4);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) acc[x][y][t] = 0.f;
+  struct Raw { float a0[8], a1[8], b0[8], b1[8]; };
+  auto fetch = [&](int j0, Raw& r) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int jj = j0 + 8 * half + t;
+      const int j = jj < jend ? jj : a.n;                            // (rows n, n + 1 are zero)
+      const f32x2 av = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsA, offA + j * PKp * 4, 0, 0));
+      const f32x2 bv = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsB, offB + j * PLp * 4, 0, 0));
+      r.a0[t] = av.x; r.a1[t] = av.y; r.b0[t] = bv.x; r.b1[t] = bv.y;
+    }
+  };
+  auto products = [&](const Raw& r) {
+    g_u32x4 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
+    g_split3(r.a0, ah[0], am[0], al[0]); g_split3(r.a1, ah[1], am[1], al[1]);
+    g_split3(r.b0, bh[0], bm[0], bl[0]); g_split3(r.b1, bh[1], bm[1], bl[1]);
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y) {
+        f32x16 d = acc[x][y];
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(g_bf16x8, al[x]), __builtin_bit_cast(g_bf16x8, bh[y]), d, 0, 0, 0);     // small terms first
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(g_bf16x8, ah[x]), __builtin_bit_cast(g_bf16x8, bl[y]), d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(g_bf16x8, am[x]), __builtin_bit_cast(g_bf16x8, bm[y]), d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(g_bf16x8, am[x]), __builtin_bit_cast(g_bf16x8, bh[y]), d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(g_bf16x8, ah[x]), __builtin_bit_cast(g_bf16x8, bm[y]), d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(g_bf16x8, ah[x]), __builtin_bit_cast(g_bf16x8, bh[y]), d, 0, 0, 0);
+        acc[x][y] = d;
+      }
+  };
+  Raw r0, r1;
+  fetch(jbeg, r0);
+  for (int j0 = jbeg; j0 < jend; j0 += 32) {                        // two steps per trip: the register sets alternate without copies
+    fetch(j0 + 16, r1);                                             // (a step past the range multiplies zeros: no branch around the products)
+    __builtin_amdgcn_sched_barrier(0);
+    products(r0);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(j0 + 32, r0);
+    __builtin_amdgcn_sched_barrier(0);
+    products(r1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float* slab = a.slabs + (size_t)sp * PKp * PLp;
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int row = tp * 64 + 32 * x + (t & 3) + 8 * (t >> 2) + 4 * half;
+        slab[(size_t)row * PLp + tr * 64 + 32 * y + c] = acc[x][y][t];
+      }
+}
 void launch_ssys_gemm(const SSysGemmArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(ssys_gemm_kernel, dim3((ssys_gemm_wave_tiles(a.K, a.L) + 3) / 4, a.nsplit), dim3(256), 0, st, a);
+  const dim3 grid((ssys_gemm_wave_tiles(a.K, a.L) + 3) / 4, a.nsplit);
+  const char* e = getenv("BNMTF_SSYS_GEMM");        // A/B switch: "f32" = the f32-MFMA form of rounds 2-5
+  if (e && !strcmp(e, "f32")) hipLaunchKernelGGL(ssys_gemm_kernel, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(ssys_gemm_bf16_kernel, grid, dim3(256), 0, st, a);
 }
 
 // A[(k,l)][(k',l')] = sum of the column-range slabs (in range order) at (p(k,k'), r(l,l')).  One block per packed pair p:

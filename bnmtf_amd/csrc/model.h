@@ -181,7 +181,7 @@ struct bnmtf_model {
   bool ho_regions_current = false;              // the regions hold q of the state as the last run call left it (no set_state since)
   bool ho_enabled = false, ho_active = false;   // q hand-over between the half sweeps (Dir::ho_*): tables built / in use by the running loop
   uint32_t col0 = 0; bool block_mode = false;    // a column block of a wider factorisation (bnmf_set_column_block): Philox column offset; no q hand-over
-  int ABd_width = 0;               // columns the metric kernel's operand copies (Ad, Bd) hold
+  double* AdW = nullptr; double* BdW = nullptr; int ABd_width = 0;     // the metric kernel's operand copies for factors wider than 64 columns (bnmtf_metric_sums_wide)
   bool uw_force = false;           // BNMTF_UNIT=1: the unit-per-wave sweep even where the hand-over is on (A/B)
   uint64_t ho_refresh = 64;                     // the rows sweep runs its pre-pass every ho_refresh-th iteration
   uint64_t profile_stride = 1;           // ... in every profile_stride-th iteration

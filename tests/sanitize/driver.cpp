@@ -79,6 +79,16 @@ static void bnmf_round_trip(const Data& d, int K, int iters, bool samples) {
   double t = 0; uint64_t cnt = 0;
   OK(bnmtf_get_expectation(h, U.data(), nullptr, V.data(), &t, &cnt));
   OK(bnmf_get_state(h, U.data(), V.data(), &t));
+  // the metric entry points: the handle's own operand copies (part of a small model's arena), and factors wider than 64 columns
+  double sums[6];
+  OK(bnmtf_beta_s(h, &t));
+  OK(bnmtf_metric_sums(h, nullptr, U.data(), nullptr, V.data(), sums));
+  {
+    const int Kw = 96;
+    std::vector<double> A((size_t)d.I * Kw, 0.5), B((size_t)d.J * Kw, 0.5);
+    OK(bnmtf_metric_sums_wide(h, d.M.data(), A.data(), B.data(), Kw, sums));
+    OK(bnmtf_metric_sums(h, nullptr, U.data(), nullptr, V.data(), sums));
+  }
   char buf[2048];
   OK(bnmtf_describe(h, buf, sizeof buf));
   OK(bnmtf_destroy(h));
@@ -140,6 +150,30 @@ static void batches() {
   }
 }
 
+// a factorisation wider than 64 columns as two column blocks (bnmtf_amd/_blocked.py's call sequence)
+static void column_blocks(const Data& d) {
+  bnmtf_handle a = create(d, 64, 0, 0, 1, nullptr), b = create(d, 17, 0, 0, 1, nullptr);
+  OK(bnmf_set_column_block(a, 0)); OK(bnmf_set_column_block(b, 64));
+  std::vector<double> Ua((size_t)d.I * 64, 1.0), Va((size_t)d.J * 64, 1.0), Ub((size_t)d.I * 17, 1.0), Vb((size_t)d.J * 17, 1.0);
+  OK(bnmf_set_state(a, Ua.data(), Va.data(), 1.0)); OK(bnmf_set_state(b, Ub.data(), Vb.data(), 1.0));
+  for (int it = 0; it < 2; ++it)
+    for (int which = 0; which < 2; ++which) {
+      OK(bnmf_set_residual_data(a, &b, 1)); OK(bnmf_half_sweep(a, which, BNMTF_UPDATE_DRAW));
+      OK(bnmf_set_residual_data(b, &a, 1)); OK(bnmf_half_sweep(b, which, BNMTF_UPDATE_MODE));
+    }
+  OK(bnmtf_set_tau(a, 0.5)); OK(bnmtf_set_iteration(a, 3));
+  EXPECT_ERR(bnmf_set_residual_data(a, &a, 1));
+  OK(bnmf_set_residual_data(a, nullptr, 0));
+  std::vector<double> num(d.I), tp(d.I);
+  OK(bnmf_cond_params(b, 0, 16, num.data(), tp.data()));
+  OK(bnmf_vb_set_state(a, Ua.data(), Ua.data(), Ua.data(), Ua.data(), Va.data(), Va.data(), Va.data(), Va.data(), 1.0));
+  OK(bnmf_vb_set_state(b, Ub.data(), Ub.data(), Ub.data(), Ub.data(), Vb.data(), Vb.data(), Vb.data(), Vb.data(), 1.0));
+  OK(bnmf_set_residual_data(b, &a, 1)); OK(bnmf_vb_half_sweep(b, 0)); OK(bnmf_vb_half_sweep(b, 1));
+  double t2[2];
+  OK(bnmf_vb_esd_terms(b, t2));
+  OK(bnmtf_destroy(a)); OK(bnmtf_destroy(b));
+}
+
 // `world` ranks of this process, one thread each, joined by the in-process transport (communicator id "BNMTFLOC...")
 static void sharded(const Data& d, int K, int L, int world, const char* token, int iters) {
   uint8_t cid[128];
@@ -188,6 +222,8 @@ int main(int argc, char** argv) {
   tri_round_trip(make_data(100, 80, 0.1, 7), 5, 5, 4);
   tri_round_trip(make_data(400, 300, 0.1, 8), 32, 17, 3);
   batches();
+  column_blocks(make_data(150, 120, 0.15, 21));
+  column_blocks(make_data(70, 60, 0.1, 22));             // (blocks that qualify for the one-launch arena)
   sharded(make_data(640, 512, 0.12, 9), 24, 0, 2, "a2", 5);
   sharded(make_data(515, 389, 0.12, 10), 40, 0, 3, "a3", 5);
   sharded(make_data(300, 260, 0.1, 11), 8, 6, 2, "t2", 3);
