@@ -268,40 +268,73 @@ def _small_model(w, R, M, seed):
     return m
 
 
-def _clock_beside(work, sync, seconds=2.0):
-    """Median shader clock (MHz) and socket power (W) by rocm-smi while `work()` is repeated for ~`seconds` (untimed)."""
-    import re, shutil, statistics, subprocess, threading
+_CLOCK_HELPER = r"""
+import json, re, shutil, subprocess, sys, threading
+rows, stop = [], threading.Event()
+def sampler():
+    while not stop.is_set():
+        try:
+            card = json.loads(subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=10).stdout)
+            card = card[sorted(card)[0]]
+            sclk = next((float(re.sub(r"[^0-9.]", "", str(v))) for k, v in card.items() if k.lower().startswith("sclk") and "mhz" in str(v).lower()), None)
+            power = next((float(v) for k, v in card.items() if "power" in k.lower() and re.fullmatch(r"[0-9.]+", str(v))), None)
+            if sclk is not None:
+                rows.append((sclk, power))
+        except Exception:
+            return
+        stop.wait(0.05)
+th = None
+for line in sys.stdin:
+    cmd = line.strip()
+    if cmd == "begin":
+        rows.clear(); stop.clear()
+        th = threading.Thread(target=sampler, daemon=True); th.start()
+    elif cmd == "end":
+        stop.set()
+        if th is not None: th.join(timeout=15)
+        print(json.dumps(rows)); sys.stdout.flush()
+    elif cmd == "quit":
+        break
+"""
+
+
+def _clock_helper_start():
+    """The rocm-smi sampler as a helper PROCESS, started before this process has touched the GPU: rocm-smi is a `#!/usr/bin/env
+    python3` script, and on this pool a process that has initialised the GPU (or a fork of one) must not exec another program
+    (round 6: the boxes refuse it; under rocprofv3 every reading was refused).  The helper never touches the GPU; it samples
+    between "begin" and "end" on its stdin."""
+    import shutil, subprocess
     if shutil.which("rocm-smi") is None:
         return None
-    rows, stop = [], threading.Event()
+    try:
+        return subprocess.Popen([sys.executable, "-c", _CLOCK_HELPER], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+    except Exception:      # noqa: BLE001 -- a reading is optional
+        return None
 
-    def sampler():
-        while not stop.is_set():
-            try:
-                card = json.loads(subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=10).stdout)
-                card = card[sorted(card)[0]]
-                sclk = next((float(re.sub(r"[^0-9.]", "", str(v))) for k, v in card.items() if k.lower().startswith("sclk") and "mhz" in str(v).lower()), None)
-                power = next((float(v) for k, v in card.items() if "power" in k.lower() and re.fullmatch(r"[0-9.]+", str(v))), None)
-                if sclk is not None:
-                    rows.append((sclk, power))
-            except Exception:      # noqa: BLE001 -- a reading is optional
-                return
-            stop.wait(0.05)
 
-    th = threading.Thread(target=sampler, daemon=True)
-    work(); sync()
-    th.start()
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        work()
-        sync()
-    stop.set(); th.join(timeout=15)
+def _clock_beside(helper, work, sync, seconds=2.0):
+    """Median shader clock (MHz) and socket power (W) by rocm-smi (the helper process) while `work()` is repeated for ~`seconds` (untimed)."""
+    import statistics
+    if helper is None:
+        return None
+    try:
+        work(); sync()
+        helper.stdin.write("begin\n"); helper.stdin.flush()
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            work()
+            sync()
+        helper.stdin.write("end\n"); helper.stdin.flush()
+        rows = json.loads(helper.stdout.readline() or "[]")
+        helper.stdin.write("quit\n"); helper.stdin.flush()
+    except Exception:      # noqa: BLE001
+        return None
     rows = [r for r in rows if r[0] > 500.0]          # (a reading taken after the loop ended shows the idle clock)
     if not rows:
         return None
     pw = [r[1] for r in rows if r[1] is not None]
     return {"sclk_mhz_median": statistics.median(r[0] for r in rows), "power_w_median": statistics.median(pw) if pw else None, "readings": len(rows),
-            "what": "rocm-smi beside ~%.0f s of the device-resident loop, after the timed regions (untimed)" % seconds}
+            "what": "rocm-smi (a helper process started before the GPU was touched) beside ~%.0f s of the device-resident loop, after the timed regions (untimed)" % seconds}
 
 
 def main_small(a, w):
@@ -478,6 +511,7 @@ def main():
 
     rank, world, local_rank, comm_id, cp = comm.init_from_env()
     a.gpus = world
+    clock_helper = _clock_helper_start() if (world == 1 and not a.no_clock) else None      # (before anything here touches the GPU)
 
     from bnmtf_amd import _lib
     from bnmtf_amd.synthetic import generate_bnmf, generate_bnmtf
@@ -589,7 +623,7 @@ def main():
     # what the box sustains under this loop: the pool's boxes differ by +-5 % in rate, and that spread is the shader clock
     # (~861 k cycles per iteration of the headline on either kind) -- rocm-smi read a few times beside ~2 s of the
     # device-resident loop, after everything that is timed; None when rocm-smi is not there or says nothing
-    clock = _clock_beside(lambda: run(max(a.steps, 50) if kind != "trivb" else min(max(a.steps, 50), len(tri_orders))), sync) if world == 1 and not a.no_clock else None
+    clock = _clock_beside(clock_helper, lambda: run(max(a.steps, 50) if kind != "trivb" else min(max(a.steps, 50), len(tri_orders))), sync) if clock_helper is not None else None
 
     import ctypes as C_
     ck, cr = C_.c_int(), C_.c_int()

@@ -4,11 +4,14 @@ tag=$1
 mkdir -p gpurun_out/bench_$tag
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > gpurun_out/bench_$tag/gpu_suite.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" >> gpurun_out/bench_$tag/gpu_suite.txt 2>&1
-bash tools/profile_round.sh $tag bnmf_8192_k64 bnmf_4096_k32 bnmtf_4096_k32 vb_8192_k64 > gpurun_out/bench_$tag/profile.log 2>&1
+bash tools/profile_round.sh $tag bnmf_8192_k64 bnmf_4096_k32 bnmtf_4096_k32 vb_8192_k64 bnmtf_vb_4096_k32 > gpurun_out/bench_$tag/profile.log 2>&1
 python bench.py > gpurun_out/bench_$tag/${tag}_bnmf_8192_k64.json 2> gpurun_out/bench_$tag/err.txt
 python bench.py --workload bnmf_4096_k32 --steps 50 > gpurun_out/bench_$tag/${tag}_bnmf_4096_k32.json 2>> gpurun_out/bench_$tag/err.txt
 python bench.py --workload bnmtf_4096_k32 --steps 50 > gpurun_out/bench_$tag/${tag}_bnmtf_4096_k32.json 2>> gpurun_out/bench_$tag/err.txt
 python bench.py --workload vb_8192_k64 > gpurun_out/bench_$tag/${tag}_vb_8192_k64.json 2>> gpurun_out/bench_$tag/err.txt
+python bench.py --workload bnmtf_vb_4096_k32 --steps 20 --warmup 3 > gpurun_out/bench_$tag/${tag}_bnmtf_vb_4096_k32.json 2>> gpurun_out/bench_$tag/err.txt
+python bench.py --workload bnmf_1024_k16 > gpurun_out/bench_$tag/${tag}_bnmf_1024_k16.json 2>> gpurun_out/bench_$tag/err.txt
+bash tools/r06/shard_ab.sh 1024 2048 > gpurun_out/bench_$tag/shard_shapes.txt 2>&1
 for w in bnmtf_toy_100x80_k5 bnmtf_gdsc_622x138_k5 bnmf_toy_100x80_k10 bnmf_gdsc_622x138_k25; do
   python bench.py --workload $w > gpurun_out/bench_$tag/${tag}_$w.json 2>> gpurun_out/bench_$tag/err.txt
 done

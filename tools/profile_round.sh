@@ -12,7 +12,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 md5sum $repo/bnmtf_amd/lib/libbnmtf_hip.so | cut -d' ' -f1 > $out/lib_md5.txt
 for w in $wls; do
-  args="$repo/bench.py --workload $w --steps 40 --warmup 5 --repeats 1 --no-cpu-baseline --no-samples"
+  args="$repo/bench.py --workload $w --steps 40 --warmup 5 --repeats 1 --no-cpu-baseline --no-samples --no-clock"
   rm -rf /tmp/pr_$w
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pr_$w/stats -o s -- python3 $args > $out/${w}_bench_under_profiler.json 2> $out/${w}_stats.err
   cp $(find /tmp/pr_$w/stats -name "s_kernel_stats.csv" | head -1) $out/${w}_kernel_stats.csv
@@ -21,7 +21,7 @@ for w in $wls; do
               "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_WAVES" \
               "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"; do
     name=$(echo $pass | cut -d' ' -f1)
-    rocprofv3 --kernel-trace --pmc $pass --output-format csv -d /tmp/pr_$w/$name -o s -- python3 $repo/bench.py --workload $w --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline --no-samples > /dev/null 2> $out/${w}_pmc_$name.err
+    rocprofv3 --kernel-trace --pmc $pass --output-format csv -d /tmp/pr_$w/$name -o s -- python3 $repo/bench.py --workload $w --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline --no-samples --no-clock > /dev/null 2> $out/${w}_pmc_$name.err
     f=$(find /tmp/pr_$w/$name -name "s_counter_collection.csv" | head -1)
     python3 - "$f" "$out/${w}_pmc_$name.csv" <<'PY'
 import csv, sys, collections
