@@ -215,12 +215,14 @@ def test_gdsc_text_loader_round_trip(tmp_path):
 
 
 def test_bench_clock_reading_is_optional():
-    """bench.py's `clock` object: rocm-smi read beside an untimed loop.  Without a GPU (or without rocm-smi) it is None and nothing raises."""
+    """bench.py's `clock` object: rocm-smi read (by a helper process started before the GPU is touched) beside an untimed loop.
+    Without a GPU (or without rocm-smi) it is None and nothing raises; without a helper likewise."""
     import importlib.util, os, time
     spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    got = bench._clock_beside(lambda: time.sleep(0.01), lambda: None, seconds=0.3)
+    assert bench._clock_beside(None, lambda: time.sleep(0.01), lambda: None, seconds=0.1) is None
+    got = bench._clock_beside(bench._clock_helper_start(), lambda: time.sleep(0.01), lambda: None, seconds=0.3)
     assert got is None or (got["sclk_mhz_median"] > 0 and got["readings"] >= 1)
 
 
@@ -351,5 +353,6 @@ def test_rank_limits_are_said_at_construction_and_wide_bnmf_models_are_column_bl
         bnmtf_amd.bnmf_gibbs_optimised(R, M, 257, pri, verbose=False)
     with pytest.raises(BnmtfError, match="outside what this build runs"):
         bnmtf_amd.bnmtf_gibbs_optimised(R, M, 65, 3, dict(alpha=1., beta=1., lambdaF=1., lambdaS=1., lambdaG=1.), verbose=False)
+    assert bnmtf_amd.bnmf_vb_optimised(R, M, 65, pri, verbose=False)._blocks.ranges == [(0, 64), (64, 65)]
     with pytest.raises(BnmtfError, match="outside what this build runs"):
-        bnmtf_amd.bnmf_vb_optimised(R, M, 65, pri, verbose=False)
+        bnmtf_amd.bnmf_vb_optimised(R, M, 257, pri, verbose=False)
