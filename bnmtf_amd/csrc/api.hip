@@ -1210,7 +1210,7 @@ int bnmtf_destroy(bnmtf_handle h) {
   free_dir(h->rows); free_dir(h->cols); free_dir(h->reff); free_dir(h->ceff);
   dfree(h->slabsS); dfree(h->CfS); dfree(h->deltaS); dfree(h->s_partial); dfree(h->s_w); dfree(h->s_omp); dfree(h->lambdaS); dfree(h->s_numer); dfree(h->s_taup);
   dfree(h->exp_rows); dfree(h->exp_cols); dfree(h->exp_S); dfree(h->exp_tau);
-  dfree(h->muS); dfree(h->tauS); dfree(h->varS); dfree(h->mv_rows); dfree(h->mv_cols); dfree(h->tri_order); dfree(h->tri_sums);
+  dfree(h->muS); dfree(h->tauS); dfree(h->varS); dfree(h->mv_rows); dfree(h->mv_cols); dfree(h->tri_order); dfree(h->tri_sums); dfree(h->tri_third);
   dfree(h->ss_Wc); dfree(h->ss_Gc); dfree(h->ss_cands); dfree(h->ss_slabs); dfree(h->ss_AB); dfree(h->ss_r); dfree(h->ss_bpart); dfree(h->ss_tinv); dfree(h->ss_rec);
   dfree(h->Rfull); h->Mtrain = nullptr; h->out6 = nullptr; h->tau_d = nullptr; h->tau_f = nullptr; h->acc = nullptr;   // (one allocation: bnmtf_create)
   dfree(h->Mscratch); dfree(h->Ad); dfree(h->Bd); dfree(h->AdW); dfree(h->BdW);
@@ -1332,7 +1332,8 @@ int bnmtf_kernel_stats(bnmtf_handle h, int kernel, double* total_ms, uint64_t* l
 int bnmtf_describe(bnmtf_handle h, char* buf, size_t buflen) {
   // (+ which kernels the last variational half sweep ran on: vb_chip_ok)
   static const char* const kVbPath[] = {"", " vb_sweep=generic", " vb_sweep=pairs", " vb_sweep=masked"};
-  snprintf(buf, buflen, "%s%s", h->description.c_str(), kVbPath[h->last_vb_path & 3]);
+  static const char* const kTriPath[] = {"", " tri_vb_sweeps=generic", " tri_vb_sweeps=pairs+cov", ""};      // (bnmtf_vb_run: api_trivb.inc enqueue_tri_sweep)
+  snprintf(buf, buflen, "%s%s%s", h->description.c_str(), kVbPath[h->last_vb_path & 3], kTriPath[h->last_tri_path & 3]);
   return BNMTF_OK;
 }
 

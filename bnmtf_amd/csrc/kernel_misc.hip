@@ -125,6 +125,7 @@ __global__ __launch_bounds__(1024) void vb_finish_kernel(VbFinishArgs a) {
     for (int u = 0; u < 16; ++u) { const int t = wave * q4 + lane + 64 * u; p[u] = 64 * u < q4 ? a.Cr64[t] * a.Cc64[t] : 0.0; }
 #pragma unroll
     for (int u = 0; u < 16; ++u) s0 += p[u];
+    if (wave == 0 && a.extra) for (int b = lane; b < a.n_extra; b += 64) s1 += a.extra[b];
     if (wave >= 1 && lane < KP)
       s1 = wave == 1 ? a.sr[lane] * a.sc[lane] : wave == 2 ? a.s2r[lane] * a.s2c[lane] : a.Cr64[lane * KP + lane] * a.Cc64[lane * KP + lane];
   } else {
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(1024) void vb_finish_kernel(VbFinishArgs a) {
     const double srp = a.acc[0], sp = sp1 - a.acc[1], spp = dot - a.acc[2];
     const double n = a.n_obs;
     const double sse = a.sumR2 - 2.0 * srp + spp;
-    const double esd = sse + (s22 - sv[4]) - (sdd - sv[5]);
+    const double esd = sse + (s22 - sv[4]) - (sdd - sv[5]) + red[0][1];
     const double alpha_s = a.alpha + 0.5 * n, beta_s = a.beta + 0.5 * esd;
     const double exptau = alpha_s / beta_s;
     *a.tau_d = exptau; *a.tau_f = (float)exptau;

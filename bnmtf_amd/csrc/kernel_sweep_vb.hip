@@ -26,9 +26,17 @@ namespace bnmtf {
 //   16 unit waves, 32 units per block (<= 128 VGPRs; wave 0 also evaluates the moments)    -- when that fills the chip;
 //    8 unit waves + 2 service waves (staging of every panel, the first one the moments)     -- smaller problems.
 
-template <int EM, int NX, int NW, int NS>
+// COV = 1 (round 6): the F and G half sweeps of the variational TRI-factorisation (bnmtf_vb_optimised.py:241-250, 264-273) -- the
+// same update against the effective factor (mean and second moment in the pair panels), with
+//   * the columns walked in the order the host hands over (SweepArgs::order: the reference shuffles them, :178, :184) -- the
+//     panel buffers alternate with the STEP, the column of a step sits in a lane of one register (v_readlane);
+//   * the covariance term (:246, :269)  sum_t S(k,t) mv_t (fs_t - x_k S(k,t)),  t = the inner index of S (lane t of the unit's
+//     half wave holds mv_t = the masked variance sum of the other observed-side factor and fs_t = sum_c x_c S(c,t), kept current
+//     with one FMA per column): it rides in the numerator's half-wave sum, S(k, .) comes from an LDS copy laid out [column][t].
+template <int EM, int NX, int NW, int NS, int COV = 0>
 __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs& f, float* lds) {
   constexpr int KP = NX * 32;
+  static_assert(!COV || NX == 1, "the tri-factorisation's sweeps: K, L <= 32");
   constexpr int EH = EM / 2;
   static_assert(EM % 2 == 0, "slots are processed in pairs");
   const int PW = f.pw;
@@ -36,7 +44,8 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
   float* c2s = lds + KP * KP;               // [KP] colsum2 of the other factor
   float* xch = c2s + KP;                    // [2*NW][4] (mu, tau, sum_miss S2, sum_miss E^2) posted by the owners
   float* ret = xch + 2 * NW * 4;            // [2*NW] E back from wave 0
-  float* pan = ret + 2 * NW;                // two pair-panel buffers of 2*PW floats
+  float* Ssl = ret + 2 * NW;                // COV: [32][32] S(column, t), zero beyond (K, cov_n)
+  float* pan = Ssl + (COV ? 1024 : 0);      // two pair-panel buffers of 2*PW floats
   const uint32_t pan_b = (uint32_t)(uintptr_t)(lds_fp)pan;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -44,6 +53,9 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
   const int half = lane >> 5, l5 = lane & 31;
   const int chunks2 = (2 * PW) / 256;
   const uint32_t buf_b = (uint32_t)(2 * PW) * 4u;           // bytes between the two buffers
+  // the column of step kk: lane kk of ordv
+  const int ordv = (COV && a.order && lane < a.K) ? a.order[lane] : lane;
+  auto col_of = [&](int kk) -> int { return COV ? __builtin_amdgcn_readlane(ordv, kk) : kk; };
   if (NS > 0 && wave >= NW) {
     const int sid = wave - NW;               // NS service waves share the staging; the first one also does the moments
     // The service waves: they own no units, so it has the registers for the fp64 moments and the time for the LDS-DMA.
@@ -66,13 +78,14 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
       if (kp + 1 < KP / 2) stage_panel_buf<(NS > 0 ? NS : 1)>(rs2, (uint32_t)(kp + 1) * stride_b, pan + (size_t)((kp + 1) & 1) * 2 * PW, chunks2, sid, lane * 16);
       sync_with_dma();
     }
-    stage_panel_buf<(NS > 0 ? NS : 1)>(rsx, 0u, pan, chunks2, sid, lane * 16);
+    stage_panel_buf<(NS > 0 ? NS : 1)>(rsx, (uint32_t)col_of(0) * stride_b, pan, chunks2, sid, lane * 16);
     sync_with_dma();
 #ifdef BNMTF_PHASE_TIMING
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = tick(0.f);
 #endif
-    for (int k = 0; k < K; ++k) {
-      if (k + 1 < K) stage_panel_buf<(NS > 0 ? NS : 1)>(rsx, (uint32_t)(k + 1) * stride_b, pan + (size_t)((k + 1) & 1) * 2 * PW, chunks2, sid, lane * 16);
+    for (int kk = 0; kk < K; ++kk) {
+      const int k = col_of(kk);
+      if (kk + 1 < K) stage_panel_buf<(NS > 0 ? NS : 1)>(rsx, (uint32_t)col_of(kk + 1) * stride_b, pan + (size_t)((kk + 1) & 1) * 2 * PW, chunks2, sid, lane * 16);
       // first barrier of the column without a vmcnt wait: the pieces just issued land while the moments are evaluated
       // (the second barrier carries the vmcnt(0))
       TICK(0, 0.f);
@@ -145,6 +158,11 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
   }
   for (int t = tid; t < KP * KP; t += NW * 64) Cs[t] = a.C32[t];
   if (tid < KP) c2s[tid] = (float)a.colsum2_o[tid];
+  if (COV)
+    for (int t = tid; t < 1024; t += NW * 64) {
+      const int c = t >> 5, tt = t & 31;
+      Ssl[t] = (c < a.K && tt < a.cov_n) ? a.cov_S[c * a.cov_sc + tt * a.cov_st] : 0.f;
+    }
   // NS == 0: wave 0, lane un: the unit it evaluates the moments for
   int mgi = -1;
   if (NS == 0 && wave == 0 && lane < 2 * NW) {
@@ -165,6 +183,7 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
     if (NS == 0) stage_panel_buf<NW>(rs2, 0u, pan, chunks2, wave, lane * 16);
     sync_with_dma();
     const int npair = KP / 2;
+#pragma nounroll      // (KP = 32: all 16 steps unrolled keep every step's partial sums live -- 1 149 spilled registers in the 16-wave K <= 32 instantiation, found in round 6)
     for (int kp = 0; kp < npair; ++kp) {
       if (NS == 0 && kp + 1 < npair) stage_panel_buf<NW>(rs2, (uint32_t)(kp + 1) * stride_b, pan + (size_t)((kp + 1) & 1) * 2 * PW, chunks2, wave, lane * 16);
       const uint32_t boff = (uint32_t)(kp & 1) * buf_b;
@@ -193,10 +212,15 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
   // for ~250 cycles per 1 KiB piece: at the top of a column that was ~1 000 cycles of every wave's slot work (66 KiB per
   // column here), in the window it costs nothing.  So the first two panels are on their way before the first column.
   if (NS == 0) {
-    stage_panel_buf<NW>(rsx, 0u, pan, chunks2, wave, lane * 16);
-    if (K > 1) stage_panel_buf<NW>(rsx, cstride_b, pan + (size_t)2 * PW, chunks2, wave, lane * 16);
+    stage_panel_buf<NW>(rsx, (uint32_t)col_of(0) * cstride_b, pan, chunks2, wave, lane * 16);
+    if (K > 1) stage_panel_buf<NW>(rsx, (uint32_t)col_of(1) * cstride_b, pan + (size_t)2 * PW, chunks2, wave, lane * 16);
   }
   sync_with_dma();
+  float fs = 0.f, mvl = 0.f;
+  if (COV) {
+    for (int c = 0; c < K; ++c) fs = fmaf(half_bcast(x[0], c, half), Ssl[c * 32 + l5], fs);
+    mvl = (valid && l5 < a.cov_n) ? a.cov_mv[(size_t)u * 32 + l5] : 0.f;
+  }
 #ifdef BNMTF_PHASE_TIMING
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = tick(q2[0].x);
 #endif
@@ -207,8 +231,9 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
   const int ho_np = (int)((ho_rows + 3u) / 4u);
   const bool ho_lds = ho_write && K >= 2 && ho_np <= chunks2;
   float dprev = 0.f;
-  for (int k = 0; k < K; ++k) {
-    const uint32_t boff = (uint32_t)(k & 1) * buf_b;
+  for (int kk = 0; kk < K; ++kk) {
+    const int k = col_of(kk);
+    const uint32_t boff = (uint32_t)(kk & 1) * buf_b;
     const float xsel = (NX == 2 && k >= 32) ? x[NX - 1] : x[0];
     const float xk = half_bcast(xsel, k & 31, half);
     // (A) column k-1's update of q
@@ -231,6 +256,11 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
     float corr_t = fmaf(-xk, vv_t, qv2.x + qv2.y);
 #pragma unroll
     for (int nx = 0; nx < NX; ++nx) corr_t = fmaf(-x[nx], Cs[k * KP + l5 + 32 * nx], corr_t);   // all l: the l = k term is put back below
+    float sc = 0.f;
+    if (COV) {
+      sc = Ssl[k * 32 + l5];
+      corr_t = fmaf(-sc * mvl, fmaf(-xk, sc, fs), corr_t);
+    }
     TICK(1, corr_t);
     corr_t = half_sum_upper(corr_t);     // right in lanes 16-31 of the half
     vv_t = half_sum_upper(vv_t);
@@ -256,15 +286,16 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
       o = *reinterpret_cast<const float4*>(&xch[lane * 4]);
       if (mgi >= 0) tn_moments_f32(o.x, o.y, &ef, &vf);
       ret[lane] = ef;
-    } else if (NS == 0 && wave >= 1 && k + 2 < K) {
+    } else if (NS == 0 && wave >= 1 && kk + 2 < K) {
       typedef __attribute__((address_space(3))) void* lds_ptr;
-      float* dst = pan + (size_t)(k & 1) * 2 * PW;
+      float* dst = pan + (size_t)(kk & 1) * 2 * PW;
+      const uint32_t cb = (uint32_t)col_of(kk + 2) * cstride_b;
       for (int c = wave - 1; c < chunks2; c += NW - 1)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(dst + (size_t)c * 256), 16, lane * 16,
-                                                  (int)((uint32_t)(k + 2) * cstride_b + (uint32_t)c * 1024u), 0, 0);
-    } else if (NS == 0 && wave >= 1 && ho_lds && k + 2 == K) {
+                                                  (int)(cb + (uint32_t)c * 1024u), 0, 0);
+    } else if (NS == 0 && wave >= 1 && ho_lds && kk + 2 == K) {
       typedef __attribute__((address_space(3))) void* lds_ptr;
-      float* dst = pan + (size_t)(k & 1) * 2 * PW;
+      float* dst = pan + (size_t)(kk & 1) * 2 * PW;
       const __amdgpu_buffer_rsrc_t rso = panel_rsrc(reinterpret_cast<const float*>(f.ho_out) + (size_t)ho_row0 * 64, (size_t)ho_rows * 256);
       for (int c = wave - 1; c < ho_np; c += NW - 1)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rso, (lds_ptr)(dst + (size_t)c * 256), 16, lane * 16, (int)((uint32_t)c * 1024u), 0, 0);
@@ -279,6 +310,7 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
     TICK(4, numer);
     const float xnew = ret[2 * wave + half];
     dprev = xnew - xk;
+    if (COV) fs = fmaf(dprev, sc, fs);
 #pragma unroll
     for (int nx = 0; nx < NX; ++nx)
       if (l5 + 32 * nx == k) x[nx] = xnew;
@@ -333,34 +365,39 @@ __device__ __forceinline__ void sweep_vb_body(const SweepArgs& a, const FastArgs
   if (ho_write) ho_send_packets<NW>(f, stage, wave, lane);
 }
 
-template <int NX, int NW, int NS>
+template <int NX, int NW, int NS, int COV = 0>
 __global__ __launch_bounds__((NW + NS) * 64, 1) void sweep_vb_kernel(SweepArgs a, FastArgs f) {
   extern __shared__ float lds[];
   const int wv = (int)(threadIdx.x >> 6);
   const int pr = blockIdx.x * NW + wv;
   const int e0 = __builtin_amdgcn_readfirstlane((wv < NW && pr < f.npairs) ? (int)f.pair_E[pr] : 0);   // service waves run in the smallest class
-  if (e0 <= 8) sweep_vb_body<8, NX, NW, NS>(a, f, lds);
-  else if (e0 <= 16) sweep_vb_body<16, NX, NW, NS>(a, f, lds);
-  else if (e0 <= 24) sweep_vb_body<24, NX, NW, NS>(a, f, lds);
-  else if (e0 <= 28) sweep_vb_body<28, NX, NW, NS>(a, f, lds);
-  else sweep_vb_body<kWideMaxSlots, NX, NW, NS>(a, f, lds);      // host guarantees e0 <= kWideMaxSlots
+  if (e0 <= 8) sweep_vb_body<8, NX, NW, NS, COV>(a, f, lds);
+  else if (e0 <= 16) sweep_vb_body<16, NX, NW, NS, COV>(a, f, lds);
+  else if (e0 <= 24) sweep_vb_body<24, NX, NW, NS, COV>(a, f, lds);
+  else if (e0 <= 28) sweep_vb_body<28, NX, NW, NS, COV>(a, f, lds);
+  else sweep_vb_body<kWideMaxSlots, NX, NW, NS, COV>(a, f, lds);      // host guarantees e0 <= kWideMaxSlots
 }
 
 int sweep_vb_blocks(int npairs, int nw) { return (npairs + nw - 1) / nw; }
-static size_t sweep_vb_lds_bytes(int KP, int pw) { return sizeof(float) * ((size_t)KP * KP + KP + 2 * 16 * 5 + 4 * (size_t)pw); }
+static size_t sweep_vb_lds_bytes(int KP, int pw, bool cov = false) { return sizeof(float) * ((size_t)KP * KP + KP + 2 * 16 * 5 + (cov ? 1024 : 0) + 4 * (size_t)pw); }
 
 bool sweep_vb_supported(int KP, int pw) { return sweep_vb_lds_bytes(KP, pw) <= 160 * 1024; }
+bool sweep_vb_cov_supported(int KP, int pw) { return KP == 32 && sweep_vb_lds_bytes(KP, pw, true) <= 160 * 1024; }
 
-template <int NX, int NW, int NS>
+template <int NX, int NW, int NS, int COV = 0>
 static void launch_vb_inst(const SweepArgs& a, const FastArgs& f, hipStream_t st) {
   static std::atomic<uint64_t> lds_ok{0};
   const int nblocks = sweep_vb_blocks(f.npairs, NW);
-  if (nblocks > 0 && allow_full_lds((const void*)sweep_vb_kernel<NX, NW, NS>, lds_ok)) hipLaunchKernelGGL((sweep_vb_kernel<NX, NW, NS>), dim3(nblocks), dim3((NW + NS) * 64), std::max(sweep_vb_lds_bytes(a.KP, f.pw), sizeof(float) * ((size_t)a.KP * a.KP + a.KP + 2 * 16 * 5 + (size_t)f.ho_lds_floats)), st, a, f);
+  if (nblocks > 0 && allow_full_lds((const void*)sweep_vb_kernel<NX, NW, NS, COV>, lds_ok)) hipLaunchKernelGGL((sweep_vb_kernel<NX, NW, NS, COV>), dim3(nblocks), dim3((NW + NS) * 64), std::max(sweep_vb_lds_bytes(a.KP, f.pw, COV != 0), sizeof(float) * ((size_t)a.KP * a.KP + a.KP + 2 * 16 * 5 + (size_t)f.ho_lds_floats)), st, a, f);
 }
 
 // f.nw = 16: 16 unit waves per block; anything else: 8 unit waves + 2 service waves
 void launch_sweep_vb(const SweepArgs& a, const FastArgs& f, hipStream_t st) {
   const int nx = a.KP / 32;
+  if (a.cov_S) {        // the tri-factorisation's F / G sweeps (callers: sweep_vb_cov_supported)
+    if (f.nw == 16) launch_vb_inst<1, 16, 0, 1>(a, f, st); else launch_vb_inst<1, 8, 2, 1>(a, f, st);
+    return;
+  }
   if (f.nw == 16) { if (nx == 1) launch_vb_inst<1, 16, 0>(a, f, st); else launch_vb_inst<2, 16, 0>(a, f, st); }
   else            { if (nx == 1) launch_vb_inst<1, 8, 2>(a, f, st);  else launch_vb_inst<2, 8, 2>(a, f, st); }
 }

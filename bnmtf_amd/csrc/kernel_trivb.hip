@@ -73,47 +73,87 @@ void launch_masked_colsum(const MaskedColsumArgs& a, hipStream_t st) {
 
 // update_S(k,l) + update_exp_S(k,l) for the entries order[0 .. n_order) in that order (bnmtf_vb_optimised.py:172-176):
 // one block, thread t owns entry t of the residual r = b - A~ E[S]; the owner of a step forms tauS = exptau A~_aa,
-// muS = (-lambda + exptau (r_a + A~_aa E[S_a])) / tauS and the TN moments (fp64 routine), posts delta = E_new - E_old
+// muS = (-lambda + exptau (r_a + A~_aa E[S_a])) / tauS and the TN mean, posts delta = E_new - E_old
 // through LDS, and every thread folds delta A~[a][t] (a coalesced row: A~ is symmetric) into its residual.
+// A step costs what its owner's lane issues between two barriers (a lone wave: ~8 cycles an instruction), so everything that does
+// not depend on the chain is taken off it (round 6: 0.93 -> ~0.3 us a step): tauS, its reciprocal and lambda are per-thread
+// constants formed before the first step; the mean is the sweeps' fp32 routine (device_rng.h: 2.5e-7 against 40-digit values; the
+// fp64 routine was ~1 500 cycles of dependent fp64 arithmetic per step); the variance -- which feeds nothing in the chain -- is
+// evaluated behind the last step by every thread for its own entry, from the (mu, tau) the step stored; the barrier of a step
+// waits for LDS traffic only, so the rows of A~ prefetched for later steps stay in flight.
 // only_params: write mu/tau of the ordered entries, leave the moments alone (update_S without update_exp_S).
 __global__ __launch_bounds__(1024) void ssys_chain_vb_kernel(SSysChainVbArgs a) {
+  constexpr int PF = 8;                                            // rows of A~ prefetched ahead of their step
   __shared__ float dl[2];
-  const int n2 = a.K * a.L, t = threadIdx.x;
+  __shared__ int ordl[1024 + PF], posl[1024];
+  const int n2 = a.K * a.L, t = threadIdx.x, n_order = a.n_order;
   const float tau = *a.tau;
   const bool mine = t < n2;
+  posl[t] = -1;
+  __syncthreads();
+  for (int i = t; i < n_order + PF; i += 1024) {
+    const int ai = i < n_order ? a.order[i] : 0;
+    ordl[i] = ai;
+    if (i < n_order) posl[ai] = i;
+  }
+  __syncthreads();
+  const int mypos = posl[t];                                       // the step that updates this thread's entry (-1: none)
   float r = mine ? a.r0[t] : 0.f;
   float e = mine ? a.E[t] : 0.f;
-  constexpr int PF = 4;                                            // rows of A~ prefetched ahead of their step
+  const float aaa = mine ? a.A[(size_t)t * n2 + t] : 1.f;       // A~[t][t]
+  const float tau_p = tau * aaa, inv_tp = 1.0f / tau_p;
+  const float sig = __builtin_amdgcn_rsqf(tau_p), xs = tau_p * sig;   // (as tn_moments_f32 forms them)
+  const float lam = mine ? a.lambdaS[t] : 0.f;
+  float mu_t = 0.f;
+  // (unconditional loads -- ordl is padded with PF zeros, a thread beyond the system reads its last column: a predicated load
+  // is merged into its register behind a vmcnt(0), i.e. every step waited for a trip to L2: 0.58 us a step, round 6)
+  const uint32_t tcol = (uint32_t)(mine ? t : n2 - 1);
   float pf[PF];
 #pragma unroll
-  for (int q = 0; q < PF; ++q) pf[q] = (q < a.n_order && mine) ? a.A[(size_t)a.order[q] * n2 + t] : 0.f;
-  for (int i0 = 0; i0 < a.n_order; i0 += PF) {
+  for (int q = 0; q < PF; ++q) pf[q] = a.A[(uint32_t)ordl[q] * (uint32_t)n2 + tcol];
+  auto step = [&](int i, float arow) {
+    if (i == mypos) {
+      const float numer = fmaf(tau, fmaf(aaa, e, r), -lam);
+      mu_t = numer * inv_tp;
+      float enew = e;
+      if (!a.only_params) {
+        // x = -mu sqrt(tau) <= -6: the routine's lambda term is below half an ulp of |x| and its result is sig |x|, bit for bit
+        // -- the common case of an entry of S away from zero (its mean many standard deviations above it)
+        const float x = -mu_t * xs;
+        if (x <= -6.0f) {
+          const float ef = sig * (-x);
+          enew = isfinite(ef) ? ef : 0.f;
+        } else {
+          float vf;
+          tn_moments_f32(mu_t, tau_p, &enew, &vf);                  // (the variance's part of the routine is dead code here)
+        }
+      }
+      dl[i & 1] = enew - e;
+      e = enew;
+    }
+    // (LDS traffic only: __syncthreads would also wait for the row loads in flight -- a trip to L2 on every step)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    r = fmaf(-dl[i & 1], arow, r);
+  };
+  // whole groups of PF steps: straight-line code, every register of the ring reloaded right behind its use; then the rest
+  int i0 = 0;
+  for (; i0 + PF <= n_order; i0 += PF) {
 #pragma unroll
     for (int q = 0; q < PF; ++q) {
-      const int i = i0 + q;
-      if (i >= a.n_order) break;
-      const int ai = a.order[i];
       const float arow = pf[q];
-      if (i + PF < a.n_order && mine) pf[q] = a.A[(size_t)a.order[i + PF] * n2 + t];
-      if (t == ai) {
-        const float aaa = arow;                                      // A~[a][a]
-        const float tau_p = tau * aaa;
-        const float numer = fmaf(tau, r + aaa * e, -a.lambdaS[t]);
-        const float mu = numer / tau_p;
-        a.mu[t] = mu; a.tauq[t] = tau_p;
-        float enew = e;
-        if (!a.only_params) {
-          double ed, vd;
-          tn_moments((double)mu, (double)tau_p, &ed, &vd);
-          enew = (float)ed;
-          a.var[t] = (float)vd;
-          a.E[t] = enew;
-        }
-        dl[i & 1] = enew - e;
-        e = enew;
-      }
-      __syncthreads();
-      r = fmaf(-dl[i & 1], arow, r);
+      pf[q] = a.A[(uint32_t)ordl[i0 + q + PF] * (uint32_t)n2 + tcol];
+      step(i0 + q, arow);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < PF; ++q)
+    if (i0 + q < n_order) step(i0 + q, pf[q]);
+  if (mypos >= 0) {
+    a.mu[t] = mu_t; a.tauq[t] = tau_p;
+    if (!a.only_params) {
+      float ef, vf;
+      tn_moments_f32(mu_t, tau_p, &ef, &vf);
+      a.E[t] = e; a.var[t] = vf;
     }
   }
 }
@@ -172,23 +212,31 @@ void launch_tri_factors(const TriFactorArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(tri_factors_kernel, dim3(blocks), dim3(256), 0, st, a);
 }
 
-// update_tau + update_exp_tau (:231-233, 286-288) and the training-mask metrics from the three masked sums
-__global__ void tri_vb_finish_kernel(const double* sums, double alpha, double beta, double* tau_d, float* tau_f, double* rec) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const double n = sums[0], sr = sums[1], srr = sums[2], sp = sums[3], spp = sums[4], srp = sums[5];
-  const double sse = srr - 2.0 * srp + spp;
-  const double esd = sse + sums[8 + 3] + sums[16 + 3];
-  const double alpha_s = alpha + 0.5 * n, beta_s = beta + 0.5 * esd;
-  const double exptau = alpha_s / beta_s;
-  *tau_d = exptau; *tau_f = (float)exptau;
-  const double ss_tot = srr - sr * sr / n, cov = srp - sr * sp / n, vp = spp - sp * sp / n;
-  rec[0] = exptau; rec[1] = sse / n;
-  rec[2] = ss_tot != 0.0 ? 1.0 - sse / ss_tot : __longlong_as_double(0x7ff0000000000000LL);
-  rec[3] = cov / (sqrt(ss_tot) * sqrt(vp));
-  rec[4] = esd; rec[5] = beta_s;
+// exp_square_diff's third term, sum_Omega varF . ((E[S] E[G]^T)^2 - E[S]^2 (E[G]^2)^T) (:238), as a sum over (j, k): the masked
+// sums mv[j][k] = sum_{i in Omega_j} varF_ik are what the G step's covariance term has just used (masked_colsum_kernel), the
+// bracket is a function of row j of E[G] and row k of E[S].  One thread per (j, k), fp64 partial sum per block.
+__global__ __launch_bounds__(256) void tri_third_kernel(TriThirdArgs a) {
+  __shared__ float Ss[32 * 32];
+  __shared__ double red[4];
+  for (int t = threadIdx.x; t < a.K * a.L; t += 256) Ss[t] = a.S[t];
+  __syncthreads();
+  const int j = blockIdx.x * 8 + (threadIdx.x >> 5), k = threadIdx.x & 31;
+  double v = 0.0;
+  if (j < a.rows && k < a.K) {
+    const float* g = a.G + (size_t)j * 32;
+    float m = 0.f, sq = 0.f;
+    for (int l = 0; l < a.L; ++l) { const float t = g[l] * Ss[k * a.L + l]; m += t; sq = fmaf(t, t, sq); }
+    v = (double)a.mv[(size_t)j * 32 + k] * ((double)m * (double)m - (double)sq);
+  }
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) a.part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
-void launch_tri_vb_finish(const double* sums, double alpha, double beta, double* tau_d, float* tau_f, double* rec, hipStream_t st) {
-  hipLaunchKernelGGL(tri_vb_finish_kernel, dim3(1), dim3(64), 0, st, sums, alpha, beta, tau_d, tau_f, rec);
+int tri_third_blocks(int rows) { return (rows + 7) / 8; }
+void launch_tri_third(const TriThirdArgs& a, hipStream_t st) {
+  if (a.rows > 0) hipLaunchKernelGGL(tri_third_kernel, dim3(tri_third_blocks(a.rows)), dim3(256), 0, st, a);
 }
 
 }  // namespace bnmtf

@@ -159,6 +159,7 @@ bool sweep_turns_supported(int KP, int pw);
 void launch_sweep_turns(const SweepArgs& a, const FastArgs& f, hipStream_t st);
 // VB sweep in the 16-wave shape (kernel_sweep_vb.hip) and the ELBO pieces it leaves to a second pass
 bool sweep_vb_supported(int KP, int pw);
+bool sweep_vb_cov_supported(int KP, int pw);   // ... with SweepArgs::cov_S / order: the tri-factorisation's F / G sweeps (K, L <= 32)
 int sweep_vb_blocks(int npairs, int nw = 8);  // blocks (= rows of FastArgs::stats) of a VB sweep over npairs pairs with nw unit waves per block (16 or 8)
 void launch_sweep_vb(const SweepArgs& a, const FastArgs& f, hipStream_t st);
 void launch_vb_pieces(int n, int n0, int KP, int K, const float* mu, const float* tauq, const float* ex, const float* var,
@@ -242,6 +243,7 @@ struct VbFinishArgs {
   double n_obs, sumR, sumR2, alpha, beta;
   double* tau_d; float* tau_f;         // exptau
   double* rec;                         // [16]: exptau, MSE, R2, Rp, ESD, beta_s, then 4 ELBO sums for U and 4 for V
+  const double* extra; int n_extra;    // (tri-factorisation: partial sums of exp_square_diff's third term, added to ESD; null: none)
 };
 void launch_vb_finish(const VbFinishArgs& a, hipStream_t st);
 
@@ -388,7 +390,11 @@ struct SSysChainVbArgs {
 void launch_ssys_chain_vb(const SSysChainVbArgs& a, hipStream_t st);
 struct TriFactorArgs { int which, side, rows, K, L; const float* X; const float* varX; const float* S; const float* varS; double* out; };
 void launch_tri_factors(const TriFactorArgs& a, hipStream_t st);
-void launch_tri_vb_finish(const double* sums, double alpha, double beta, double* tau_d, float* tau_f, double* rec, hipStream_t st);
+// exp_square_diff's third term (bnmtf_vb_optimised.py:238) from the masked variance sums the G step already holds:
+//   sum_jk mv[j][k] ((sum_l S_kl G_jl)^2 - sum_l S_kl^2 G_jl^2),  mv[j][k] = sum_{i in Omega_j} varF_ik;  one partial sum per block
+struct TriThirdArgs { int rows, K, L; const float* G; const float* S; const float* mv; double* part; };
+int tri_third_blocks(int rows);
+void launch_tri_third(const TriThirdArgs& a, hipStream_t st);
 
 // ---------------------------------------------------------------------------
 // small models (kernel_small.hip): the WHOLE run(n) of a BNMF Gibbs model in one launch, one 16-wave block per model --

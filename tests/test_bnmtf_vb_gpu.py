@@ -153,3 +153,62 @@ def test_larger_shape_properties():
         assert np.isfinite(X).all()
         if not n.startswith("mu"):
             assert X.min() >= 0
+
+
+def _orders(rs, n, K, L):
+    return np.array([np.concatenate([rs.permutation(K * L), rs.permutation(K), rs.permutation(L)]) for _ in range(n)], dtype=np.int32)
+
+
+@pytest.mark.parametrize("I,J,K,L,frac", [(1100, 900, 10, 7, 0.12), (2304, 2100, 32, 32, 0.1), (700, 2500, 5, 32, 0.2)])
+def test_on_chip_sweeps_and_the_identity_form_of_exp_square_diff(monkeypatch, I, J, K, L, frac):
+    """Round 6: run()'s F and G half sweeps on the on-chip pair-panel kernel (kernel_sweep_vb.hip, COV: the covariance term and
+    the shuffled column order inside the column loop), the S chain with the fp32 moments, exp_square_diff from the sweeps' own
+    sums -- against the generic kernels (BNMTF_VB_GENERIC=1), the direct fp64 exp_square_diff and the fp64 oracle."""
+    from bnmtf_amd.synthetic import generate_bnmtf
+    from oracle import bnmtf_oracle as O
+    R, M, _, _, _ = generate_bnmtf(I, J, K, L, frac, seed_data=11, seed_mask=12)
+    pri = dict(alpha=1., beta=1., lambdaF=0.1, lambdaS=0.1, lambdaG=0.1)
+    n_it = 3
+    orders = _orders(np.random.RandomState(5), n_it, K, L)
+    out = {}
+    init = None
+    for generic in ("0", "1"):
+        if generic == "1":
+            monkeypatch.setenv("BNMTF_VB_GENERIC", "1")
+        else:
+            monkeypatch.delenv("BNMTF_VB_GENERIC", raising=False)
+        b = bnmtf_vb_optimised(R, M, K, L, pri, verbose=False)
+        np.random.seed(1)
+        b.initialise("random", "random")
+        if init is None:
+            init = {n: getattr(b, n).copy() for n in ("muF", "tauF", "muS", "tauS", "muG", "tauG")}
+        b.run(n_it, orders=orders)
+        d = b.describe()
+        assert ("tri_vb_sweeps=pairs+cov" in d) == (generic == "0") and ("tri_vb_sweeps=generic" in d) == (generic == "1"), d
+        # update_tau of the last iteration took the identity form; exp_square_diff() is the direct fp64 pass over R
+        assert abs(b.beta_s - (1. + 0.5 * b.exp_square_diff())) < 5e-5 * b.beta_s
+        out[generic] = {n: getattr(b, n).copy() for n in NAMES}
+        out[generic].update(exptau=np.array(b.all_exp_tau), mse=np.array(b.all_performances["MSE"]), elbo=b.elbo(),
+                            r2=np.array(b.all_performances["R^2"]), rp=np.array(b.all_performances["Rp"]))
+        b.close()
+    f, g = out["0"], out["1"]
+    for n in NAMES:
+        # (the variances of entries far in a tail move with the last bits of their mean: a looser bound)
+        assert np.abs(f[n] - g[n]).max() < (3e-3 if n.startswith("var") else 5e-4) * np.abs(g[n]).max(), n
+    np.testing.assert_allclose(f["exptau"], g["exptau"], rtol=1e-4)
+    np.testing.assert_allclose(f["mse"], g["mse"], rtol=1e-4)
+    assert (not np.isfinite(g["elbo"]) and f["elbo"] == g["elbo"]) or abs(f["elbo"] - g["elbo"]) < 1e-4 * abs(g["elbo"])   # (-inf early in a run from a random start: log erfc underflows, in the reference too)
+    if I * J > 3e6:
+        return                                            # (the oracle's update_S is a pass over R per entry)
+    o = O.BNMTFVBOracle(R.astype(np.float64), M, K, L, pri)
+    for n, v in init.items():
+        setattr(o, n, v.copy())
+    o.finish_initialise()
+    o.run(n_it, orders=[([(a // L, a % L) for a in row[:K * L]], list(row[K * L:K * L + K]), list(row[K * L + K:])) for row in orders])
+    np.testing.assert_allclose(f["exptau"], o.all_exp_tau, rtol=1e-3)
+    np.testing.assert_allclose(f["mse"], o.all_performances["MSE"], rtol=1e-3)
+    np.testing.assert_allclose(f["r2"], o.all_performances["R^2"], rtol=1e-3, atol=1e-5)      # (R^2 of the first iteration is ~ -1e-4)
+    np.testing.assert_allclose(f["rp"], o.all_performances["Rp"], rtol=1e-3, atol=1e-5)
+    for n in ("expF", "expS", "expG", "tauF", "tauG", "tauS"):
+        ref = getattr(o, n)
+        assert np.abs(f[n] - ref).max() < 3e-3 * np.abs(ref).max(), n

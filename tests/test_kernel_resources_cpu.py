@@ -16,8 +16,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 # (translation unit, substring of the mangled kernel name, max VGPRs, max spilled VGPRs)
 LIMITS = [
-    ("kernel_sweep_vb.hip", "sweep_vb_kernelILi2ELi16ELi0EE", 128, 120),          # VB sweep, K > 32, 16 unit waves (cfg5)
-    ("kernel_sweep_vb.hip", "sweep_vb_kernelILi2ELi8ELi2EE", 256, 40),            # ... 8 unit waves + 2 service waves
+    ("kernel_sweep_vb.hip", "sweep_vb_kernelILi2ELi16ELi0ELi0EE", 128, 120),          # VB sweep, K > 32, 16 unit waves (cfg5)
+    ("kernel_sweep_vb.hip", "sweep_vb_kernelILi2ELi8ELi2ELi0EE", 256, 40),        # ... 8 unit waves + 2 service waves
+    ("kernel_sweep_vb.hip", "sweep_vb_kernelILi1ELi16ELi0ELi0EE", 128, 40),       # ... K <= 32, 16 unit waves (round 6: 1 149 spilled before the pre-pass loop stopped being unrolled)
+    ("kernel_sweep_vb.hip", "sweep_vb_kernelILi1ELi16ELi0ELi1EE", 128, 60),       # the tri-factorisation's F / G sweeps (covariance term, column order), 16 unit waves
+    ("kernel_sweep_vb.hip", "sweep_vb_kernelILi1ELi8ELi2ELi1EE", 256, 40),        # ... 8 unit waves + 2 service waves
     ("kernel_sweep_wide.hip", "sweep_chip_kernelILi2ELi0ELi16ELi0ELi1ELi1ELi0EE", 128, 120),   # Gibbs sweep, draws, 16 waves, split sampler (cfg3)
     ("kernel_sweep_wide.hip", "sweep_chip_kernelILi2ELi1ELi16ELi0ELi1ELi1ELi0EE", 128, 120),   # ... mode updates
 ]
