@@ -1210,7 +1210,7 @@ int bnmtf_destroy(bnmtf_handle h) {
   free_dir(h->rows); free_dir(h->cols); free_dir(h->reff); free_dir(h->ceff);
   dfree(h->slabsS); dfree(h->CfS); dfree(h->deltaS); dfree(h->s_partial); dfree(h->s_w); dfree(h->s_omp); dfree(h->lambdaS); dfree(h->s_numer); dfree(h->s_taup);
   dfree(h->exp_rows); dfree(h->exp_cols); dfree(h->exp_S); dfree(h->exp_tau);
-  dfree(h->muS); dfree(h->tauS); dfree(h->varS); dfree(h->mv_rows); dfree(h->mv_cols); dfree(h->tri_order); dfree(h->tri_sums); dfree(h->tri_third);
+  dfree(h->muS); dfree(h->tauS); dfree(h->varS); dfree(h->mv_rows); dfree(h->mv_cols); dfree(h->tri_order); dfree(h->tri_sums); dfree(h->tri_third); dfree(h->ss_Aperm);
   dfree(h->ss_Wc); dfree(h->ss_Gc); dfree(h->ss_cands); dfree(h->ss_slabs); dfree(h->ss_AB); dfree(h->ss_r); dfree(h->ss_bpart); dfree(h->ss_tinv); dfree(h->ss_rec);
   dfree(h->Rfull); h->Mtrain = nullptr; h->out6 = nullptr; h->tau_d = nullptr; h->tau_f = nullptr; h->acc = nullptr;   // (one allocation: bnmtf_create)
   dfree(h->Mscratch); dfree(h->Ad); dfree(h->Bd); dfree(h->AdW); dfree(h->BdW);

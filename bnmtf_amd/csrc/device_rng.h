@@ -241,4 +241,34 @@ __device__ __forceinline__ void tn_moments_f32(float mu, float tau_p, float* e_o
   *v_out = (isfinite(v) && v >= 0.0f) ? v : 0.0f;
 }
 
+// The mean alone, one regime at a time (the same operations as tn_moments_f32 above, in the same order): for callers that know
+// the sign of x = -mu sqrt(tau) wave-uniformly and have no use for the variance on their critical path (the S chain of the
+// variational tri-factorisation, kernel_trivb.hip).  XPOS: x > 0 (mu < 0).
+template <bool XPOS>
+__device__ __forceinline__ float tn_mean_f32_regime(float mu, float tau_p) {
+  const float sig = __builtin_amdgcn_rsqf(tau_p);
+  const float x = -mu * (tau_p * sig);
+  const float ax = fabsf(x);
+  float e;
+  if (XPOS) {
+    const float s = (ax - kTnF32A) * __builtin_amdgcn_rcpf(ax + kTnF32A);
+    float pr = kTnF32R[kTnF32RDeg];
+#pragma unroll
+    for (int k = kTnF32RDeg - 1; k >= 0; --k) pr = fmaf(pr, s, kTnF32R[k]);
+    e = sig * (pr * __builtin_amdgcn_rcpf(1.0f + ax));
+    if (mu < -30.0f * sig) e = __builtin_amdgcn_rcpf(fabsf(mu) * tau_p);
+  } else {
+    const float t = ax * 0.70710678f;
+    const float st = (t - kTnF32A) * __builtin_amdgcn_rcpf(t + kTnF32A);
+    float pe = kTnF32E[kTnF32EDeg];
+#pragma unroll
+    for (int k = kTnF32EDeg - 1; k >= 0; --k) pe = fmaf(pe, st, kTnF32E[k]);
+    const float ecx = pe * __builtin_amdgcn_rcpf(fmaf(2.0f, t, 1.0f));
+    const float p = __builtin_amdgcn_exp2f(-0.72134752f * ax * ax);          // exp(-x^2/2)
+    const float lam = 0.39894228f * p * __builtin_amdgcn_rcpf(fmaf(-0.5f * p, ecx, 1.0f));
+    e = sig * (lam + ax);
+  }
+  return (isfinite(e) && e >= 0.0f) ? e : 0.0f;
+}
+
 }  // namespace bnmtf

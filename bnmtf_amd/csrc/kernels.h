@@ -386,8 +386,10 @@ struct SSysChainVbArgs {
   const int* order;                    // entries a = k L + l in update order
   const float* A; const float* r0; const float* lambdaS; const float* tau;
   float* E; float* var; float* mu; float* tauq;     // q(S): expS (in/out), varS, muS, tauS  [K L]
+  const float* Aperm;                  // whole passes: A~ in the pass's order (launch_ssys_permute), or null
 };
 void launch_ssys_chain_vb(const SSysChainVbArgs& a, hipStream_t st);
+void launch_ssys_permute(const float* A, const int* order, int n, float* out, hipStream_t st);   // out[s][p] = A[order[s]][order[p]]
 struct TriFactorArgs { int which, side, rows, K, L; const float* X; const float* varX; const float* S; const float* varS; double* out; };
 void launch_tri_factors(const TriFactorArgs& a, hipStream_t st);
 // exp_square_diff's third term (bnmtf_vb_optimised.py:238) from the masked variance sums the G step already holds:

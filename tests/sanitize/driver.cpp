@@ -105,6 +105,30 @@ static void vb_round_trip(const Data& d, int K) {
   OK(bnmtf_destroy(h));
 }
 
+// the variational tri-factorisation: set_state / run with shuffled orders / the direct exp_square_diff / single updates / get_state
+static void tri_vb_round_trip(const Data& d, int K, int L, int iters) {
+  bnmtf_handle h = create(d, K, L, 0, 1, nullptr);
+  std::vector<double> F((size_t)d.I * K, 1.0), S((size_t)K * L, 1.0), G((size_t)d.J * L, 1.0);
+  OK(bnmtf_vb_set_state(h, F.data(), F.data(), F.data(), F.data(), S.data(), S.data(), S.data(), S.data(), G.data(), G.data(), G.data(), G.data(), 1.0));
+  const int per = K * L + K + L;
+  std::vector<int32_t> orders((size_t)iters * per);
+  for (int it = 0; it < iters; ++it) {
+    int32_t* o = &orders[(size_t)it * per];
+    for (int a = 0; a < K * L; ++a) o[a] = K * L - 1 - a;
+    for (int k = 0; k < K; ++k) o[K * L + k] = (k + it) % K;
+    for (int l = 0; l < L; ++l) o[K * L + K + l] = L - 1 - l;
+  }
+  std::vector<double> et(iters), perf((size_t)iters * 3), times(iters), elbo((size_t)iters * 10);
+  OK(bnmtf_vb_run(h, iters, orders.data(), et.data(), perf.data(), elbo.data(), times.data()));
+  double e = 0, sums[6];
+  OK(bnmtf_vb_exp_square_diff(h, &e, sums));
+  OK(bnmtf_vb_update(h, 0, K - 1, 0, 1));
+  OK(bnmtf_vb_update(h, 1, K - 1, L - 1, 1));
+  OK(bnmtf_vb_update(h, 2, 0, L - 1, 0));
+  OK(bnmtf_vb_get_state(h, F.data(), F.data(), F.data(), F.data(), S.data(), S.data(), S.data(), S.data(), G.data(), G.data(), G.data(), G.data()));
+  OK(bnmtf_destroy(h));
+}
+
 static void tri_round_trip(const Data& d, int K, int L, int iters) {
   bnmtf_handle h = create(d, K, L, 0, 1, nullptr);
   std::vector<double> F((size_t)d.I * K, 1.0), S((size_t)K * L, 1.0), G((size_t)d.J * L, 1.0);
@@ -221,6 +245,8 @@ int main(int argc, char** argv) {
   vb_round_trip(make_data(515, 389, 0.12, 6), 40);
   tri_round_trip(make_data(100, 80, 0.1, 7), 5, 5, 4);
   tri_round_trip(make_data(400, 300, 0.1, 8), 32, 17, 3);
+  tri_vb_round_trip(make_data(90, 70, 0.1, 15), 4, 5, 3);
+  tri_vb_round_trip(make_data(1200, 1100, 0.1, 16), 12, 9, 2);         // the on-chip F / G sweeps' host side, the blocked chain's (K L >= 64)
   batches();
   column_blocks(make_data(150, 120, 0.15, 21));
   column_blocks(make_data(70, 60, 0.1, 22));             // (blocks that qualify for the one-launch arena)

@@ -92,3 +92,28 @@ def test_fp32_sweep_routine_matches_the_oracle_formula():
     # the oracle's own fp64 variance loses ~x^4 eps for mu << 0; compare where that is below the fp32 level
     okv = ok & (xr < 12)
     np.testing.assert_allclose(v[okv], vo[okv], rtol=5e-6, atol=1e-30)
+
+
+def test_segment_table_of_the_mean_matches_the_oracle_formula():
+    """tn_mean_table.h (the S chain of the variational tri-factorisation reads a step's mean out of it, kernel_trivb.hip): the
+    committed table evaluated as the device evaluates it -- fp32 segment coordinate, floor / fract, fp32 Horner -- against the
+    reference's formula (truncated_normal.py:42-52 through the oracle) on x in [-6, 26), and the file is what the generator writes."""
+    spec = importlib.util.spec_from_file_location("gen_tab", os.path.join(ROOT, "tools", "gen_tn_mean_table.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    txt = open(os.path.join(ROOT, "bnmtf_amd", "csrc", "tn_mean_table.h")).read()
+    rows = re.findall(r"^\s*\{(.*?)\},\s*$", txt, re.M)
+    tab = np.array([[float(v.strip().rstrip("f")) for v in r.split(",")] for r in rows], dtype=np.float32)
+    assert tab.shape == (g.NSEG, g.DEG + 1) == (64, 6)
+    assert "kTnMeanX0 = %.1ff, kTnMeanInvW = %.1ff" % (g.X0, 1.0 / g.W) in txt
+    rs = np.random.RandomState(4)
+    x = np.concatenate([rs.uniform(-6, 25.99, 20000), -6 + 0.5 * np.arange(64) + 1e-6]).astype(np.float32)
+    got = g.eval_f32(tab, x).astype(np.float64)
+    # E[TN(mu, 1)] with mu = -x: sigma = 1, so the mean IS r(x); the oracle's formula loses digits like x^2 eps for x >> 0
+    ref = O.tn_expectation(-x.astype(np.float64), np.ones(x.size))
+    lo = x < 12
+    np.testing.assert_allclose(got[lo], ref[lo], rtol=5e-7)
+    np.testing.assert_allclose(got[~lo], ref[~lo], rtol=2e-5)
+    # ... and against 40-digit values over the whole range, a coarser sample (the generator's own check)
+    assert g.max_rel_error(tab, n=1500, seed=1) < 3e-7
+    np.testing.assert_array_equal(tab, g.table().astype(np.float32))
