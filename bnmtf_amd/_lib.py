@@ -83,6 +83,8 @@ _SIGS = {
     "bnmf_set_column_block": ([_P, C.c_int], C.c_int),
     "bnmf_set_residual_data": ([_P, _P, C.c_int], C.c_int),
     "bnmf_half_sweep": ([_P, C.c_int, C.c_int], C.c_int),
+    "bnmtf_set_s_block": ([_P, C.c_int, C.c_int, C.c_int], C.c_int),
+    "bnmtf_s_rows": ([_P, C.c_int, C.c_int, C.c_int], C.c_int),
     "bnmtf_tn_sample": ([_P, _P, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, _P], C.c_int),
     "bnmtf_tn_moments": ([_P, _P, C.c_size_t, C.c_int, _P, _P], C.c_int),
     "bnmtf_gamma_sample": ([C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_double)], C.c_int),

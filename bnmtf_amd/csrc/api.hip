@@ -1564,7 +1564,7 @@ int bnmf_set_column_block(bnmtf_handle h, int col0) {
 
 int bnmf_set_residual_data(bnmtf_handle h, const bnmtf_handle* others, int n_others) {
   if (n_others < 0 || n_others > kMaxOtherBlocks) { set_error("at most %d other column blocks", kMaxOtherBlocks); return BNMTF_EINVAL; }
-  if (h->L != 0 || h->comm) { set_error("residual data: BNMF handles on one GPU"); return BNMTF_ESTATE; }
+  if (h->comm) { set_error("residual data: one GPU"); return BNMTF_ESTATE; }       // (the target may be a BNMTF handle -- an S block of a wider tri-factorisation; the others are two-factor products)
   HIPCHK(hipSetDevice(h->device));
   CHK(ensure_std(h));
   ResidualSpec rs;

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(1024) void srow_draw_kernel(SDrawArgs a) {
     if (a.update == 0 && a.cond_l < 0 && on) {
 #pragma unroll
       for (int c = 0; c < NH; ++c) {
-        const U4 r = philox4x32_10(0u, (uint32_t)(k * L + lane), a.it, kStreamS + 16u * (uint32_t)c, a.key0, a.key1);
+        const U4 r = philox4x32_10(0u, a.word0 + (uint32_t)(k * a.ldword + lane), a.it, kStreamS + 16u * (uint32_t)c, a.key0, a.key1);
         const TnCand cd = tn_cand_pre(r.x, r.y);
         cands[(lane * NH + c) * 3 + 0] = cd.nl; cands[(lane * NH + c) * 3 + 1] = cd.z; cands[(lane * NH + c) * 3 + 2] = cd.sw;
       }
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(1024) void srow_draw_kernel(SDrawArgs a) {
           bool acc = tn_cand_post(tp, cd0, &xc) && lane < NH;
           unsigned long long m = __ballot(acc);
           for (uint32_t round = 0; m == 0ull && round < 64u; ++round) {     // candidates NH + 64 round + lane
-            const U4 r = philox4x32_10(0u, (uint32_t)(k * L + l), a.it, kStreamS + 16u * ((uint32_t)NH + round * 64u + (uint32_t)lane), a.key0, a.key1);
+            const U4 r = philox4x32_10(0u, a.word0 + (uint32_t)(k * a.ldword + l), a.it, kStreamS + 16u * ((uint32_t)NH + round * 64u + (uint32_t)lane), a.key0, a.key1);
             acc = tn_eval_fast(tp, r.x, r.y, &xc);
             m = __ballot(acc);
           }

@@ -194,7 +194,7 @@ void launch_post_gram_rows(const PostArgs& a, int own0, int own1, hipStream_t st
 void launch_masked_operand(const float* R, const uint8_t* M, int I, int J, int by_rows, int unit0, int n, int m, float* out, int ld, hipStream_t st);
 // the same operand for the RESIDUAL data of a column block: M ? R - sum_b A_b[i] . B_b[j] : 0 (up to kMaxOtherBlocks products of
 // width W_b, row-major [.][KP_b] factors): what the other column blocks of a wider factorisation explain is taken off the data
-constexpr int kMaxOtherBlocks = 3;
+constexpr int kMaxOtherBlocks = 4;      // (a model of four column blocks has three others; the S blocks of a wide tri-factorisation take four carriers)
 struct ResidualSpec { int n; const float* A[kMaxOtherBlocks]; const float* B[kMaxOtherBlocks]; int KP[kMaxOtherBlocks]; int W[kMaxOtherBlocks]; };
 void launch_residual_operand(const float* R, const uint8_t* M, int I, int J, int by_rows, int unit0, int n, int m, float* out, int ld,
                              const ResidualSpec& rs, hipStream_t st);
@@ -299,6 +299,7 @@ struct SDrawArgs {
   const float* partial; const float* omp; float* S; const float* lambdaS; const float* tau;
   const double* Cf64; float* CfS; float* delta_out;
   uint32_t key0, key1, it;
+  uint32_t word0; int ldword;          // the Philox column word of entry (k, l) is word0 + k ldword + l: (0, L) for a whole S, (row0 Lw + col0, Lw) for a block of a wider one
   double* numer_out; double* tau_out;
 };
 void launch_srow_draw(const SDrawArgs& a, hipStream_t st);

@@ -22,6 +22,9 @@ class nmtf_icm(bnmtf_gibbs_optimised):
     def run(self, iterations, minimum_TN=0.):
         """:132-173; returns None like the reference."""
         it = int(iterations)
+        if self._blocks is not None:           # K or L above 64: blocks (_blocked.py), the same updates with the Gamma mode for tau
+            self._run_blocked(it, _lib.UPDATE_ICM, False, None, minimum_TN=float(minimum_TN), icm=True)
+            return
         self._push()
         taus = np.zeros(it); perf = np.zeros((it, 3)); times = np.zeros(it)
         L = _lib.lib()

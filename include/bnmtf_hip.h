@@ -158,8 +158,9 @@ BNMTF_API int bnmf_gibbs_run_many(const bnmtf_handle* hs, int n_models, int n_it
 /* this handle holds columns [col0, col0 + K) of the wider model: the Philox column word of its column k is col0 + k (the
  * draws are keyed by the wide model's column index: oracle/rng.py); no one-launch path, no q hand-over */
 BNMTF_API int bnmf_set_column_block(bnmtf_handle h, int col0);
-/* the contraction operands of h become M . (R - sum_b U_b V_b^T) over the n_others (<= 3) handles' current factors
- * (n_others = 0: M . R again); predict() / metric entry points keep the full R */
+/* the contraction operands of h become M . (R - sum_b U_b V_b^T) over the n_others (<= 4) BNMF handles' current factors
+ * (n_others = 0: M . R again); predict() / metric entry points keep the full R.  h itself may be a BNMTF handle (a block of
+ * the S of a wider tri-factorisation, below) */
 BNMTF_API int bnmf_set_residual_data(bnmtf_handle h, const bnmtf_handle* others, int n_others);
 /* one half of an iteration of run(): contraction, the K sequential column updates of U (which = 0, :134-137) or V
  * (which = 1, :139-142) with the handle's current tau and iteration counter, then the relayout + Gram the other half reads.
@@ -175,6 +176,15 @@ BNMTF_API int bnmtf_metric_sums_wide(bnmtf_handle h, const uint8_t* Mp, const do
  * over the handle's own columns (additive over blocks) */
 BNMTF_API int bnmf_vb_half_sweep(bnmtf_handle h, int which);
 BNMTF_API int bnmf_vb_esd_terms(bnmtf_handle h, double out[2]);
+
+/* the tri-factorisation with K or L above 64 (bnmtf_gibbs_optimised.py:56-84 takes any; bnmtf_amd/_blocked.py: TriBlocks).  F's
+ * column blocks and G's are BNMF handles against the effective factors (G S_b^T, F S_c), driven through the entry points above;
+ * block (b, c) of S is a BNMTF handle (F_b, S_bc, G_c) on the data minus what every other block of S explains:
+ * this handle is rows row0.., columns col0.. of a K x L_wide S -- its draws are keyed by their place there (oracle/rng.py: the
+ * Philox column word of S_kl is k L + l); its S step runs row by row, no one-launch path, no dense system */
+BNMTF_API int bnmtf_set_s_block(bnmtf_handle h, int row0, int col0, int L_wide);
+/* rows k0 .. k1-1 of the handle's S, every l in order (:157-160), for its current F, G, tau, iteration counter and data */
+BNMTF_API int bnmtf_s_rows(bnmtf_handle h, int k0, int k1, int update);
 
 /* ---- BNMTF Gibbs (bnmtf_gibbs_optimised.py) ---------------------------- */
 BNMTF_API int bnmtf_set_state(bnmtf_handle h, const double* F, const double* S, const double* G, double tau);

@@ -584,6 +584,52 @@ def make_wide_rank():
     np.savez_compressed(os.path.join(HERE, "wide_rank.npz"), **out)
 
 
+def make_wide_tri():
+    """The tri-factorisation with K or L above 64 (round 6: the device runs it as blocks of S): the reference's conditional
+    parameters from random states (every column of F and G, a sample of the entries of S) and whole nmtf_icm trajectories
+    (deterministic) -- one with a single column block of S, one with two row and two column blocks."""
+    from BNMTF.code.models.bnmtf_gibbs_optimised import bnmtf_gibbs_optimised
+    from BNMTF.code.models.nmtf_icm import nmtf_icm
+    rs = np.random.RandomState(4052)
+    out = {}
+    for tag, (I, J, K, L) in (("k70l5", (48, 37, 70, 5)), ("k6l66", (41, 52, 6, 66)), ("k70l66", (45, 39, 70, 66))):
+        R = rs.exponential(1.0, (I, 5)) @ rs.exponential(1.0, (5, 4)) @ rs.exponential(1.0, (J, 4)).T + rs.normal(0, 1, (I, J))
+        M = rand_mask(rs, I, J, 0.2)
+        pri = dict(alpha=2.0, beta=0.5, lambdaF=rs.uniform(0.05, 2.0, (I, K)), lambdaS=rs.uniform(0.05, 2.0, (K, L)), lambdaG=rs.uniform(0.05, 2.0, (J, L)))
+        b = bnmtf_gibbs_optimised(R, M, K, L, pri)
+        b.F = rs.exponential(0.3, (I, K)); b.S = rs.exponential(0.3, (K, L)); b.G = rs.exponential(0.3, (J, L)); b.tau = 0.7
+        for k_, v in dict(R=R, M=M, F=b.F, S=b.S, G=b.G, tau=b.tau, **pri).items():
+            out[tag + "/" + k_] = np.asarray(v)
+        tF = np.array([b.tauF(k) for k in range(K)]); mF = np.array([b.muF(tF[k], k) for k in range(K)])
+        tG = np.array([b.tauG(l) for l in range(L)]); mG = np.array([b.muG(tG[l], l) for l in range(L)])
+        kl = np.array([(k, l) for k in range(K) for l in range(L)])
+        kl = kl[rs.permutation(len(kl))[:60]]
+        tS = np.array([b.tauS(k, l) for k, l in kl]); mS = np.array([b.muS(tS[i], k, l) for i, (k, l) in enumerate(kl)])
+        out[tag + "/tauF"], out[tag + "/muF"], out[tag + "/tauG"], out[tag + "/muG"] = tF, mF, tG, mG
+        out[tag + "/kl"], out[tag + "/tauS"], out[tag + "/muS"] = kl, tS, mS
+        out[tag + "/beta_s"] = np.float64(b.beta_s())
+        p = b.predict_while_running()
+        out[tag + "/perf"] = np.array([p["MSE"], p["R^2"], p["Rp"]])
+    for tag, (I, J, K, L, its, mtn, seed) in (("icm_k70l4", (50, 40, 70, 4, 5, 0.001, 21)), ("icm_k70l66", (44, 38, 70, 66, 3, 0.001, 22))):
+        R = rs.exponential(1.0, (I, 5)) @ rs.exponential(1.0, (5, 4)) @ rs.exponential(1.0, (J, 4)).T + rs.normal(0, 1, (I, J))
+        M = rand_mask(rs, I, J, 0.15)
+        pri = dict(alpha=1.0, beta=1.0, lambdaF=0.1 * np.ones((I, K)), lambdaS=0.1 * np.ones((K, L)), lambdaG=0.1 * np.ones((J, L)))
+        np.random.seed(seed)
+        c = nmtf_icm(R, M, K, L, pri)
+        c.initialise("exp", "exp")
+        # (a start on the data's scale: from the priors' own draws every entry falls to minimum_TN in the first sweep)
+        a0 = (R[M > 0].mean() / (K * L)) ** (1.0 / 3.0)
+        c.F = rs.exponential(a0, (I, K)); c.S = rs.exponential(a0, (K, L)); c.G = rs.exponential(a0, (J, L))
+        c.tau = (c.alpha_s() - 1.0) / c.beta_s()
+        for k_, v in dict(R=R, M=M, F0=c.F.copy(), S0=c.S.copy(), G0=c.G.copy(), tau0=np.array(c.tau), minimum_TN=np.array(mtn), iterations=np.array(its)).items():
+            out[tag + "/" + k_] = np.asarray(v)
+        with quiet(), np.errstate(all="ignore"):
+            c.run(its, minimum_TN=mtn)
+        out[tag + "/F"], out[tag + "/S"], out[tag + "/G"], out[tag + "/all_tau"] = c.F.copy(), c.S.copy(), c.G.copy(), np.array(c.all_tau)
+        out[tag + "/mse"] = np.array(c.all_performances["MSE"])
+    np.savez_compressed(os.path.join(HERE, "wide_tri.npz"), **out)
+
+
 def make_toy_data():
     """The reference's toy inputs (data files its own tests/experiments hold) as one fixture."""
     out = {}
@@ -596,7 +642,7 @@ def make_toy_data():
 
 if __name__ == "__main__":
     import_reference()
-    which = sys.argv[1:] or ["toy", "bnmf", "bnmtf", "vb", "tn", "traj", "icm", "trivb", "masks", "kmeans", "gdsc", "wide"]
+    which = sys.argv[1:] or ["toy", "bnmf", "bnmtf", "vb", "tn", "traj", "icm", "trivb", "masks", "kmeans", "gdsc", "wide", "widetri"]
     if "toy" in which: make_toy_data()
     if "bnmf" in which: make_bnmf_cond()
     if "bnmtf" in which: make_bnmtf_cond()
@@ -609,6 +655,7 @@ if __name__ == "__main__":
     if "kmeans" in which: make_kmeans()
     if "gdsc" in which: make_gdsc()
     if "wide" in which: make_wide_rank()
+    if "widetri" in which: make_wide_tri()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

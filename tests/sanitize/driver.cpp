@@ -198,6 +198,30 @@ static void column_blocks(const Data& d) {
   OK(bnmtf_destroy(a)); OK(bnmtf_destroy(b));
 }
 
+// a block of the S of a wider tri-factorisation: a BNMTF handle on the data minus what two carriers (BNMF handles) explain
+static void tri_blocks(const Data& d) {
+  bnmtf_handle c0 = create(d, 40, 0, 0, 1, nullptr), c1 = create(d, 9, 0, 0, 1, nullptr), t = create(d, 33, 40, 0, 1, nullptr);
+  OK(bnmf_set_column_block(c0, 0)); OK(bnmf_set_column_block(c1, 64));
+  OK(bnmtf_set_s_block(t, 64, 0, 49));
+  EXPECT_ERR(bnmtf_set_s_block(t, 0, 20, 49));                 // (the block would stick out of the wide S)
+  EXPECT_ERR(bnmtf_set_s_block(c0, 0, 0, 40));                 // (a BNMF handle)
+  std::vector<double> U0((size_t)d.I * 40, 0.5), V0((size_t)d.J * 40, 0.5), U1((size_t)d.I * 9, 0.5), V1((size_t)d.J * 9, 0.5);
+  OK(bnmf_set_state(c0, U0.data(), V0.data(), 1.0)); OK(bnmf_set_state(c1, U1.data(), V1.data(), 1.0));
+  std::vector<double> F((size_t)d.I * 33, 0.3), S((size_t)33 * 40, 0.3), G((size_t)d.J * 40, 0.3);
+  OK(bnmtf_set_state(t, F.data(), S.data(), G.data(), 1.0));
+  bnmtf_handle cs[2] = {c0, c1};
+  OK(bnmf_set_residual_data(t, cs, 2));
+  OK(bnmtf_set_iteration(t, 2));
+  OK(bnmtf_s_rows(t, 0, 33, BNMTF_UPDATE_DRAW));
+  OK(bnmtf_s_rows(t, 5, 6, BNMTF_UPDATE_ICM));
+  EXPECT_ERR(bnmtf_s_rows(t, 3, 40, BNMTF_UPDATE_DRAW));
+  EXPECT_ERR(bnmtf_s_rows(c0, 0, 1, BNMTF_UPDATE_DRAW));
+  OK(bnmtf_get_state(t, nullptr, S.data(), nullptr, nullptr));
+  double num, tp;
+  OK(bnmtf_cond_params(t, 1, 32, 39, &num, &tp));
+  OK(bnmtf_destroy(c0)); OK(bnmtf_destroy(c1)); OK(bnmtf_destroy(t));
+}
+
 // `world` ranks of this process, one thread each, joined by the in-process transport (communicator id "BNMTFLOC...")
 static void sharded(const Data& d, int K, int L, int world, const char* token, int iters) {
   uint8_t cid[128];
@@ -250,6 +274,8 @@ int main(int argc, char** argv) {
   batches();
   column_blocks(make_data(150, 120, 0.15, 21));
   column_blocks(make_data(70, 60, 0.1, 22));             // (blocks that qualify for the one-launch arena)
+  tri_blocks(make_data(130, 110, 0.12, 23));
+  tri_blocks(make_data(60, 50, 0.1, 24));
   sharded(make_data(640, 512, 0.12, 9), 24, 0, 2, "a2", 5);
   sharded(make_data(515, 389, 0.12, 10), 40, 0, 3, "a3", 5);
   sharded(make_data(300, 260, 0.1, 11), 8, 6, 2, "t2", 3);

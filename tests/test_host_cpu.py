@@ -337,7 +337,8 @@ def test_joint_map_survives_a_walk_that_fails():
 
 def test_rank_limits_are_said_at_construction_and_wide_bnmf_models_are_column_blocks():
     """The reference takes any rank (bnmf_gibbs_optimised.py:54-78).  Here: bnmf_gibbs / nmf_icm up to 256 (column blocks of 64,
-    _blocked.py: built without touching a device), the tri-factorisations up to 64 / 32 -- and what lies beyond is refused when
+    _blocked.py: built without touching a device), the Gibbs / ICM tri-factorisations up to 256 as blocks of S, the variational
+    one up to 32 -- and what lies beyond is refused when
     the class is constructed, with the limit in the message, not at the first device call of a search."""
     import bnmtf_amd
     from bnmtf_amd._lib import BnmtfError
@@ -351,8 +352,16 @@ def test_rank_limits_are_said_at_construction_and_wide_bnmf_models_are_column_bl
     assert bnmtf_amd.bnmf_gibbs_optimised(R, M, 64, pri, verbose=False)._blocks is None
     with pytest.raises(BnmtfError, match="K = 257 is outside what this build runs"):
         bnmtf_amd.bnmf_gibbs_optimised(R, M, 257, pri, verbose=False)
+    pri3 = dict(alpha=1., beta=1., lambdaF=1., lambdaS=1., lambdaG=1.)
+    t = bnmtf_amd.bnmtf_gibbs_optimised(R, M, 65, 130, pri3, verbose=False)              # blocks of S: 2 x 3 (TriBlocks)
+    assert (t._blocks.kr, t._blocks.lr) == ([(0, 64), (64, 65)], [(0, 64), (64, 128), (128, 130)])
+    assert [c.K for c in t._blocks.Fch] == [64, 1] and [c.K for c in t._blocks.Gch] == [64, 64, 2]
+    assert [[(c.K, c.L) for c in row] for row in t._blocks.Sch] == [[(64, 64), (64, 64), (64, 2)], [(1, 64), (1, 64), (1, 2)]]
+    assert bnmtf_amd.nmtf_icm(R, M, 3, 65, pri3, verbose=False)._blocks is not None and bnmtf_amd.bnmtf_gibbs_optimised(R, M, 64, 64, pri3, verbose=False)._blocks is None
     with pytest.raises(BnmtfError, match="outside what this build runs"):
-        bnmtf_amd.bnmtf_gibbs_optimised(R, M, 65, 3, dict(alpha=1., beta=1., lambdaF=1., lambdaS=1., lambdaG=1.), verbose=False)
+        bnmtf_amd.bnmtf_gibbs_optimised(R, M, 257, 3, pri3, verbose=False)
+    with pytest.raises(BnmtfError, match="outside what this build runs"):
+        bnmtf_amd.bnmtf_vb_optimised(R, M, 33, 3, pri3, verbose=False)
     assert bnmtf_amd.bnmf_vb_optimised(R, M, 65, pri, verbose=False)._blocks.ranges == [(0, 64), (64, 65)]
     with pytest.raises(BnmtfError, match="outside what this build runs"):
         bnmtf_amd.bnmf_vb_optimised(R, M, 257, pri, verbose=False)

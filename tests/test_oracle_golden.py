@@ -318,6 +318,38 @@ def test_oracle_matches_the_reference_at_ranks_above_64(golden):
     np.testing.assert_allclose(m.U, g["U"], rtol=1e-8, atol=1e-10)
 
 
+def test_tri_oracle_matches_the_reference_at_ranks_above_64(golden):
+    """tests/golden/wide_tri.npz (round 6): the reference's conditional parameters of a tri-factorisation with K = 70 and / or
+    L = 66, and its nmtf_icm trajectories there -- what pins the oracle where the device runs blocks of S (tests/test_wide_tri_gpu.py)."""
+    for tag in ("k70l5", "k6l66", "k70l66"):
+        c = golden("wide_tri.npz").case(tag)
+        K, L = c["S"].shape
+        pri = dict(alpha=float(c["alpha"]), beta=float(c["beta"]), lambdaF=c["lambdaF"], lambdaS=c["lambdaS"], lambdaG=c["lambdaG"])
+        o = O.BNMTFGibbsOracle(c["R"], c["M"], K, L, pri)
+        o.F, o.S, o.G, o.tau = c["F"].copy(), c["S"].copy(), c["G"].copy(), float(c["tau"])
+        for k in (0, K - 1, K // 2):
+            t = o.tauF(k)
+            np.testing.assert_allclose(t, c["tauF"][k], rtol=1e-12)
+            np.testing.assert_allclose(o.muF(t, k), c["muF"][k], rtol=1e-9, atol=1e-12)
+        for l in (0, L - 1):
+            t = o.tauG(l)
+            np.testing.assert_allclose(t, c["tauG"][l], rtol=1e-12)
+            np.testing.assert_allclose(o.muG(t, l), c["muG"][l], rtol=1e-9, atol=1e-12)
+        for i, (k, l) in enumerate(c["kl"][:12]):
+            t = o.tauS(int(k), int(l))
+            assert abs(t / c["tauS"][i] - 1) < 1e-12 and abs(o.muS(t, int(k), int(l)) - c["muS"][i]) < 1e-9 * (1 + abs(c["muS"][i]))
+        assert abs(o.beta_s() / float(c["beta_s"]) - 1) < 1e-12
+    g = golden("wide_tri.npz").case("icm_k70l4")
+    I, J = g["R"].shape; K, L = g["S0"].shape
+    pri = dict(alpha=1.0, beta=1.0, lambdaF=0.1 * np.ones((I, K)), lambdaS=0.1 * np.ones((K, L)), lambdaG=0.1 * np.ones((J, L)))
+    m = O.NMTFICMOracle(g["R"], g["M"], K, L, pri)
+    m.F, m.S, m.G, m.tau = g["F0"].copy(), g["S0"].copy(), g["G0"].copy(), float(g["tau0"])
+    m.run(int(g["iterations"]), minimum_TN=float(g["minimum_TN"]))
+    np.testing.assert_allclose(m.all_tau, g["all_tau"], rtol=1e-9)
+    np.testing.assert_allclose(m.F, g["F"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(m.S, g["S"], rtol=1e-8, atol=1e-10)
+
+
 def test_vb_oracle_matches_the_reference_at_k70(golden):
     c = golden("wide_rank.npz").case("vb70")
     pri = dict(alpha=1.0, beta=1.0, lambdaU=c["lambdaU"], lambdaV=c["lambdaV"])
