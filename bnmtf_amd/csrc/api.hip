@@ -810,7 +810,10 @@ struct SampleSink {
   // Slots are handed over in GROUPS of kGroup iterations: one event recorded on the compute stream and one stream wait per
   // group, not per iteration -- an event record drains the compute queue for a few microseconds each time (round 1: eight
   // records cost 30 us per iteration).  Two groups of slots: one being filled while the other goes to the host.
-  static constexpr int kGroup = 4, kGroups = 2, kDepth = kGroup * kGroups;
+#ifndef BNMTF_SAMPLE_GROUP
+#define BNMTF_SAMPLE_GROUP 8
+#endif
+  static constexpr int kGroup = BNMTF_SAMPLE_GROUP, kGroups = 2, kDepth = kGroup * kGroups;
   struct Mat { const float* src; int rows, W, KP; float* dst; size_t off; };
   bnmtf_model* h = nullptr;
   Mat m[3]; int nmat = 0;

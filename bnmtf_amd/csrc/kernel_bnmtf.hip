@@ -53,23 +53,27 @@ void launch_small_product(const SmallProductArgs& a, hipStream_t st) {
 // already (the S step's own contraction, F has not changed since), so the second pass over R~ shrinks to a K x L product per
 // column.  Half wave per unit: lane c holds the summed slab entry t = c and column c of the product.
 __global__ __launch_bounds__(256) void slab_product_kernel(SlabProductArgs a) {
-  __shared__ float Ss[64 * 64];
-  for (int t = threadIdx.x; t < a.K * a.L; t += 256) Ss[t] = a.S[t];
+  __shared__ float Ss[64 * 64];                 // [inner index][output column], row stride 64, either way round
+  for (int t = threadIdx.x; t < a.K * a.L; t += 256) {
+    const int k = t / a.L, l = t % a.L;
+    Ss[a.transposeS ? l * 64 + k : k * 64 + l] = a.S[t];
+  }
   __syncthreads();
   const int l5 = threadIdx.x & 31;
   const int u = blockIdx.x * 8 + (threadIdx.x >> 5);
   if (u >= a.n) return;
   const size_t stride = (size_t)a.n_pad * a.KPin;
+  const int inner = a.transposeS ? a.L : a.K, outw = a.transposeS ? a.K : a.L;      // (transposeS: out = slabs . S^T)
   for (int c0 = 0; c0 < a.KPout; c0 += 32) {
     float acc = 0.f;
-    for (int t0 = 0; t0 < a.K; t0 += 32) {
-      const float tv = t0 + l5 < a.K ? slab_sum_ordered(a.slabs, a.split, stride, (size_t)u * a.KPin + t0 + l5) : 0.f;
-      for (int t = 0; t < 32 && t0 + t < a.K; ++t) {
+    for (int t0 = 0; t0 < inner; t0 += 32) {
+      const float tv = t0 + l5 < inner ? slab_sum_ordered(a.slabs, a.split, stride, (size_t)u * a.KPin + t0 + l5) : 0.f;
+      for (int t = 0; t < 32 && t0 + t < inner; ++t) {
         const float x = __shfl(tv, t, 32);
-        if (c0 + l5 < a.L) acc = fmaf(x, Ss[(t0 + t) * a.L + c0 + l5], acc);
+        if (c0 + l5 < outw) acc = fmaf(x, Ss[(t0 + t) * 64 + c0 + l5], acc);
       }
     }
-    a.out[(size_t)u * a.KPout + c0 + l5] = c0 + l5 < a.L ? acc : 0.f;
+    a.out[(size_t)u * a.KPout + c0 + l5] = c0 + l5 < outw ? acc : 0.f;
   }
 }
 void launch_slab_product(const SlabProductArgs& a, hipStream_t st) {

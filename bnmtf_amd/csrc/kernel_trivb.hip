@@ -23,8 +23,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // mean and second moment of the effective factor:  Xe[r][c] = sum_t X[r][t] S(t,c),
 // S2e[r][c] = sum_t (varX + X^2)[r][t] (varS + S^2)(t,c) - sum_t X^2[r][t] S^2(t,c) + Xe^2     (S(t,c) = S[t][c] or S[c][t])
 __global__ __launch_bounds__(256) void small_product_vb_kernel(SmallProductVbArgs a) {
+  // S(t, c) at [t][c] in LDS whichever way it is read: consecutive lanes (c) on consecutive banks (round 6: the transposed read
+  // c L + t was a 32-way bank conflict -- 16.8 us for the F side against 5 us for the G side)
   __shared__ float Ss[32 * 32], Vs[32 * 32];
-  for (int t = threadIdx.x; t < a.K * a.L; t += 256) { Ss[t] = a.S[t]; Vs[t] = a.varS[t]; }
+  for (int t = threadIdx.x; t < a.K * a.L; t += 256) {
+    const int k = t / a.L, l = t % a.L;
+    const int at = a.transposeS ? l * 32 + k : k * 32 + l;
+    Ss[at] = a.S[t]; Vs[at] = a.varS[t];
+  }
   __syncthreads();
   const int inner = a.transposeS ? a.L : a.K, outw = a.transposeS ? a.K : a.L;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < (size_t)a.rows * outw; e += (size_t)gridDim.x * 256) {
@@ -33,7 +39,7 @@ __global__ __launch_bounds__(256) void small_product_vb_kernel(SmallProductVbArg
     const float* vx = a.varX + (size_t)r * 32;
     float m = 0.f, s2 = 0.f, sq = 0.f;
     for (int t = 0; t < inner; ++t) {
-      const int si = a.transposeS ? c * a.L + t : t * a.L + c;
+      const int si = t * 32 + c;
       const float xs = x[t], ss = Ss[si];
       m = fmaf(xs, ss, m);
       s2 = fmaf(vx[t] + xs * xs, Vs[si] + ss * ss, s2);

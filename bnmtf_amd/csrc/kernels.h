@@ -267,6 +267,7 @@ struct SmallProductArgs {   // out = X . S (transposeS = 0, out width L) or X . 
 void launch_small_product(const SmallProductArgs& a, hipStream_t st);
 struct SlabProductArgs {    // out[n][KPout] = (sum of the `split` slabs [n_pad][KPin]) . S: contraction slabs times S (kernel_bnmtf.hip)
   const float* slabs; int split, n_pad, KPin; const float* S; int K, L; int n; float* out; int KPout;
+  int transposeS = 0;          // 1: out[n][K] = slabs[n][L] . S^T (the F side: R~ (G S^T) = (R~ G) S^T); out may be slab 0 of `slabs` when KPout == 32
 };
 void launch_slab_product(const SlabProductArgs& a, hipStream_t st);
 void launch_cfs(const double* Cf64, int KPk, const float* S, int K, int L, float* CfS, hipStream_t st);
