@@ -37,11 +37,39 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // their 64, the texture path takes ~9 cycles per wave-level load): per step one shift-add (row offset), one row load.
 // Everything else sits in buffer descriptors, scalar offsets and immediates.  Rows are loaded a batch (8 steps) ahead,
 // indices two.
+// (the three-term bf16 split of the round-6 matrix-core kernels below: ssys_gemm_bf16_kernel's comment)
+namespace {
+typedef __bf16 g_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 g_bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t g_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t g_pack_rne(float a0, float a1) {
+  f32x2 v; v.x = a0; v.y = a1;
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, g_bf16x2));
+}
+__device__ __forceinline__ void g_split3(const float (&v)[8], g_u32x4& hi, g_u32x4& mid, g_u32x4& lo) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float a0 = v[2 * p], a1 = v[2 * p + 1];
+    const uint32_t h = g_pack_rne(a0, a1);
+    hi[p] = h;
+    const float b0 = a0 - __builtin_bit_cast(float, h << 16);                 // exact
+    const float b1 = a1 - __builtin_bit_cast(float, h & 0xffff0000u);
+    const uint32_t m = g_pack_rne(b0, b1);
+    mid[p] = m;
+    const float c0 = b0 - __builtin_bit_cast(float, m << 16);                 // exact
+    const float c1 = b1 - __builtin_bit_cast(float, m & 0xffff0000u);
+    lo[p] = g_pack_rne(c0, c1);
+  }
+}
+}  // namespace
 __device__ __forceinline__ void gamma_pack_body(const GammaPackArgs& a, int block);
 // (blocks behind the column Grams' pack the second moments of G's rows -- gamma_pack_body, below: the two do not depend on each
 // other, and one launch less is ~5 us of the S step)
 __device__ __forceinline__ void ssys_b_body(const SSysBArgs& a, int block);
-template <int VB>
+// BF = 1 (round 6): the outer products on the bf16 matrix cores, fp32-exact -- a half's eight rows of a 16-slot step ARE the A (and
+// B) operand of v_mfma_f32_32x32x16_bf16 (lane (c, g) holds k = 8 g .. 8 g + 7), so the loads stay as they are and a step is one
+// three-term split of eight registers (g_split3) and six products (6 x 32 cycles) instead of eight f32 products (8 x 64).
+template <int VB, int BF = 0>
 __global__ __launch_bounds__(256) void scol_gram_kernel(SColGramArgs a, GammaPackArgs gp, SSysBArgs sb) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   const int gram_blocks = (a.n + 3) / 4, pack_blocks = (gp.n + 7) / 8;
@@ -75,11 +103,27 @@ __global__ __launch_bounds__(256) void scol_gram_kernel(SColGramArgs a, GammaPac
     }
   };
   auto mfmas = [&](const Rows& r) {
+    if constexpr (BF != 0) {
+      g_u32x4 hi, mid, lo;
+      g_split3(r.f, hi, mid, lo);
+      const g_bf16x8 h8 = __builtin_bit_cast(g_bf16x8, hi), m8 = __builtin_bit_cast(g_bf16x8, mid), l8 = __builtin_bit_cast(g_bf16x8, lo);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l8, h8, acc, 0, 0, 0);          // small terms first, the two accumulators in turn
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h8, l8, acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m8, m8, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m8, h8, acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h8, m8, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h8, h8, acc2, 0, 0, 0);
+      if (VB) {
 #pragma unroll
-    for (int t = 0; t < 8; t += 2) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(r.f[t], r.f[t], acc, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(r.f[t + 1], r.f[t + 1], acc2, 0, 0, 0);
-      if (VB) dv += r.v[t] + r.v[t + 1];
+        for (int t = 0; t < 8; ++t) dv += r.v[t];
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 8; t += 2) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(r.f[t], r.f[t], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(r.f[t + 1], r.f[t + 1], acc2, 0, 0, 0);
+        if (VB) dv += r.v[t] + r.v[t + 1];
+      }
     }
   };
   // a column with nothing missing has no slots at all (s0 == s1, possibly the very end of idx): nothing may be
@@ -113,8 +157,15 @@ void launch_scol_gram(const SColGramArgs& a, const GammaPackArgs& gp, hipStream_
   if (a.n <= 0) return;
   SSysBArgs b0 = {};
   const int blocks = (a.n + 3) / 4 + (gp.n + 7) / 8 + (sb ? ssys_b_blocks(sb->n) : 0);
-  if (a.varF) hipLaunchKernelGGL(scol_gram_kernel<1>, dim3(blocks), dim3(256), 0, st, a, gp, sb ? *sb : b0);
-  else        hipLaunchKernelGGL(scol_gram_kernel<0>, dim3(blocks), dim3(256), 0, st, a, gp, sb ? *sb : b0);
+  // BNMTF_SCOL_GRAM=f32: the f32 matrix-core form (A/B switch)
+  static const bool f32 = [] { const char* e = getenv("BNMTF_SCOL_GRAM"); return e && !strcmp(e, "f32"); }();
+  if (f32) {
+    if (a.varF) hipLaunchKernelGGL((scol_gram_kernel<1, 0>), dim3(blocks), dim3(256), 0, st, a, gp, sb ? *sb : b0);
+    else        hipLaunchKernelGGL((scol_gram_kernel<0, 0>), dim3(blocks), dim3(256), 0, st, a, gp, sb ? *sb : b0);
+  } else {
+    if (a.varF) hipLaunchKernelGGL((scol_gram_kernel<1, 1>), dim3(blocks), dim3(256), 0, st, a, gp, sb ? *sb : b0);
+    else        hipLaunchKernelGGL((scol_gram_kernel<0, 1>), dim3(blocks), dim3(256), 0, st, a, gp, sb ? *sb : b0);
+  }
 }
 
 // Gc[j][r(l, l')] = G_jl G_jl' (l <= l'), the packed second-moment matrix of column j's row of G.  Block = 8 columns (512 blocks at 4096 columns: two per CU hide each other's load -> store latency).
@@ -217,30 +268,6 @@ __global__ __launch_bounds__(256) void ssys_gemm_kernel(SSysGemmArgs a) {
 // of BOTH interleaved tiles) -- splits its four fragments (a0, a1, b0, b1) and issues the 24 products; the next step's rows are
 // on their way in a second register set meanwhile.  Ranges are cut at multiples of 16 columns; past a range's end the zero rows
 // behind the arrays are read.  Same tiles, same slab layout, same epilogue as ssys_gemm_kernel.
-namespace {
-typedef __bf16 g_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 g_bf16x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t g_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint32_t g_pack_rne(float a0, float a1) {
-  f32x2 v; v.x = a0; v.y = a1;
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, g_bf16x2));
-}
-__device__ __forceinline__ void g_split3(const float (&v)[8], g_u32x4& hi, g_u32x4& mid, g_u32x4& lo) {
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const float a0 = v[2 * p], a1 = v[2 * p + 1];
-    const uint32_t h = g_pack_rne(a0, a1);
-    hi[p] = h;
-    const float b0 = a0 - __builtin_bit_cast(float, h << 16);                 // exact
-    const float b1 = a1 - __builtin_bit_cast(float, h & 0xffff0000u);
-    const uint32_t m = g_pack_rne(b0, b1);
-    mid[p] = m;
-    const float c0 = b0 - __builtin_bit_cast(float, m << 16);                 // exact
-    const float c1 = b1 - __builtin_bit_cast(float, m & 0xffff0000u);
-    lo[p] = g_pack_rne(c0, c1);
-  }
-}
-}  // namespace
 __host__ __device__ inline int ssys_gemm_range(int n, int nsplit) { return ((n + nsplit - 1) / nsplit + 15) & ~15; }     // columns per range: a multiple of a step
 __global__ __launch_bounds__(256) void ssys_gemm_bf16_kernel(SSysGemmArgs a) {
   const int lane = threadIdx.x & 63, half = lane >> 5, c = lane & 31;
