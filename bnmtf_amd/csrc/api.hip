@@ -1470,6 +1470,7 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
     CHK(await_gram(h, c)); CHK(await_gram(h, r));
     // ---- tau and the metrics of this sample
     FinishArgs f;
+    f.copy_src = nullptr; f.copy_dst = nullptr; f.copy_n = 0;
     f.Cr64 = r.C64; f.Cc64 = c.C64; f.sr = r.colsum; f.sc = c.colsum; f.KP = r.KP;
     f.acc = h->acc; f.stats = (fast_stats && !h->comm) ? c.stats : nullptr; f.nstats = (fast_stats && !h->comm) ? c.stats_blocks : 0;
     f.n_obs = h->n_obs; f.sumR = h->sumR; f.sumR2 = h->sumR2;

@@ -59,6 +59,8 @@ void launch_gram(const GramArgs& a, hipStream_t st) {
 __global__ __launch_bounds__(1024) void finish_kernel(FinishArgs a) {
   __shared__ double red[16];
   const int KP = a.KP, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (a.copy_dst)      // (round 6: S's sample was a device-to-device copy of 4 KB on the compute stream, 4.8 us of every iteration)
+    for (int t = threadIdx.x; t < a.copy_n; t += 1024) a.copy_dst[t] = a.copy_src[t];
   // five sums, one per WAVE (round 5: every wave used to reduce four values over its lanes): waves 0-3 a quarter of <Cr, Cc> each,
   // waves 4-6 one column of the per-block sweep statistics, wave 7 the column-sum product; the other waves have nothing to do
   double s = 0.0;

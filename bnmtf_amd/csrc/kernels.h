@@ -233,6 +233,7 @@ struct FinishArgs {
   const double* gunit;        // Gamma(alpha_s, 1) variate of this iteration computed ahead on the host, or null (draw here)
   double* tau_d; float* tau_f;
   double* rec;                // [5]: tau, MSE, R2, Rp, SSE  (slot of this iteration)
+  const float* copy_src; float* copy_dst; int copy_n;     // a small array that rides along (the tri-factorisation's sample of S into its slot), or null
 };
 void launch_finish(const FinishArgs& a, hipStream_t st);
 struct VbFinishArgs {
