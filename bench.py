@@ -573,7 +573,8 @@ def main():
     # record drains the queue for ~4 us: two per iteration were 2 % of the headline iteration)
     # (BNMTF: the cols direction's contraction is no pass over R~ any more -- (R~^T F) S from the S step's slabs -- so the
     # roofline kernel there is the rows direction's, R~ . (G S^T))
-    ROOF = _lib.KERNEL_GEMM_ROWS if kind in ("bnmtf", "trivb") else _lib.KERNEL_GEMM_COLS
+    # (bnmtf_vb: its rows-side pass over R~ runs on a second stream beside the S pass since round 6 -- the timed one is R~^T E[F])
+    ROOF = _lib.KERNEL_GEMM_ROWS if kind == "bnmtf" else _lib.KERNEL_GEMM_COLS
     model.set_profiling(True, kernel=ROOF, every=4)
     perf_first = None
     dts = []
@@ -664,7 +665,7 @@ def main():
                     "unit": "TFLOP/s", "frac": ach / PEAK_F32_VECTOR_TFLOPS, "traffic": None}
         else:
             ach = bytes_alg / (g["avg_us"] * 1e-6) / 1e9 if g["avg_us"] > 0 else 0.0
-            roof = {"bound": "hbm", "kernel": ("gemm_rows: P = R~.(G S^T)" if kind in ("bnmtf", "trivb") else "gemm_cols: Pv = R~^T.U") + " (bf16x3 MFMA 32x32x16, fp32-exact products)", "achieved": ach,
+            roof = {"bound": "hbm", "kernel": ("gemm_rows: P = R~.(G S^T)" if kind == "bnmtf" else ("gemm_cols: Pv = R~^T.E[F]" if kind == "trivb" else "gemm_cols: Pv = R~^T.U")) + " (bf16x3 MFMA 32x32x16, fp32-exact products)", "achieved": ach,
                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": traffic}
         roof.update({"algorithmic_per_launch": {"flop": flops, "bytes": bytes_alg,
                                                 "bytes_note": "4 B per element: the operand is the PRE-MASKED R~ = M.R (fp32, built once at create), so a launch reads no mask; "

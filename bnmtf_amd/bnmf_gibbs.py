@@ -117,8 +117,8 @@ class bnmf_gibbs_optimised(DeviceModel):
 
     def _run_blocked(self, iterations, update, store_samples, expectation, minimum_TN=0.0, icm=False):
         """run() of a model wider than 64 columns: the blocks' half sweeps in turn (_blocked.py); tau by the update rule's own
-        law -- a Gamma(alpha_s, beta_s) draw keyed like the single-handle loop's (seed, iteration), its ratio mean is not used
-        here; mode updates keep the Gibbs harness's tau draw, ICM takes the Gamma mode (nmf_icm.py:137)."""
+        law -- a Gamma(alpha_s, beta_s) draw keyed like the single-handle loop's (seed, iteration); mode updates (the deterministic
+        harness) take its mean, ICM the Gamma mode (nmf_icm.py:137)."""
         from .distributions import gamma_draw
         it = int(iterations)
         self._push()
@@ -137,6 +137,8 @@ class bnmf_gibbs_optimised(DeviceModel):
             beta_s = self.beta + 0.5 * sse
             if icm:
                 return (alpha_s - 1.0) / beta_s
+            if update == _lib.UPDATE_MODE:          # the deterministic harness: the mean, as the single-handle loop takes it (csrc finish_kernel)
+                return alpha_s / beta_s
             return gamma_draw(alpha_s, beta_s, seed=self._seed, it=iteration, device=self._device)
 
         def store(i, U, V):

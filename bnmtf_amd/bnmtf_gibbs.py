@@ -123,7 +123,7 @@ class bnmtf_gibbs_optimised(DeviceModel):
 
     def _run_blocked(self, iterations, update, store_samples, expectation, minimum_TN=0.0, icm=False):
         """run() of a model with K or L above 64 (_blocked.py: TriBlocks): tau by the update rule's own law -- a Gamma(alpha_s,
-        beta_s) draw keyed like the single-handle loop's (seed, iteration); ICM takes the Gamma mode (nmtf_icm.py:160)."""
+        beta_s) draw keyed like the single-handle loop's (seed, iteration); mode updates take its mean, ICM the Gamma mode (nmtf_icm.py:160)."""
         from .distributions import gamma_draw
         it = int(iterations)
         blocks = self._blocks
@@ -142,6 +142,8 @@ class bnmtf_gibbs_optimised(DeviceModel):
             beta_s = self.beta + 0.5 * sse
             if icm:
                 return (alpha_s - 1.0) / beta_s
+            if update == _lib.UPDATE_MODE:          # the deterministic harness: the mean, as the single-handle loop takes it (csrc finish_kernel)
+                return alpha_s / beta_s
             return gamma_draw(alpha_s, beta_s, seed=self._seed, it=iteration, device=self._device)
 
         def store(i, F, S, G):

@@ -71,6 +71,7 @@ def test_mode_trajectory_and_draws_follow_the_oracle(I, J, K):
     sU = max(1.0, np.abs(o.all_U[0]).max()); sV = max(1.0, np.abs(o.all_V[0]).max())
     assert np.abs(b.all_U[0] - o.all_U[0]).max() < 5e-4 * sU and np.abs(b.all_V[0] - o.all_V[0]).max() < 5e-4 * sV
     np.testing.assert_allclose(b.all_performances["MSE"], o.all_performances["MSE"], rtol=5e-4)
+    np.testing.assert_allclose(b.all_tau, o.all_tau, rtol=5e-4)           # (the mean of the Gamma in mode updates, not a draw)
     # draws
     b2 = bnmf_gibbs_optimised(R, M, K, pri, verbose=False, seed=21)
     b2.U, b2.V, b2.tau = U0.copy(), V0.copy(), 1.3
