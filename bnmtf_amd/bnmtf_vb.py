@@ -24,7 +24,7 @@ from .kmeans import KMeans
 
 
 class bnmtf_vb_optimised(DeviceModel):
-    def __init__(self, R, M, K, L, priors, *, device=0, verbose=True):
+    def __init__(self, R, M, K, L, priors, *, device=0, verbose=True, rank=0, world=1, comm_id=None):
         self.R = np.array(R, dtype=float)
         self.M = np.array(M, dtype=float)
         self.K, self.L = K, L
@@ -37,7 +37,8 @@ class bnmtf_vb_optimised(DeviceModel):
         self.lambdaS = broadcast_lambda(priors['lambdaS'], (self.K, self.L), "lambdaS")
         self.lambdaG = broadcast_lambda(priors['lambdaG'], (self.J, self.L), "lambdaG")
         self.verbose = verbose
-        self._init_device(0, device, 0, 1, None)           # VB draws nothing on the device
+        # (VB draws nothing on the device; rank / world / comm_id: rows of F and columns of G over several GPUs, round 6)
+        self._init_device(0, device, rank, world, comm_id)
 
     def _lambda_arrays(self):
         return self.lambdaF, self.lambdaG, self.lambdaS

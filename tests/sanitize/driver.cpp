@@ -243,6 +243,18 @@ static void sharded(const Data& d, int K, int L, int world, const char* token, i
         std::vector<double> F((size_t)d.I * K, 1.0), S((size_t)K * L, 1.0), G((size_t)d.J * L, 1.0);
         OK(bnmtf_set_state(h, F.data(), S.data(), G.data(), 1.0));
         OK(bnmtf_gibbs_run(h, iters, BNMTF_UPDATE_MODE, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+        // ... and the variational tri-factorisation over the same ranks (round 6)
+        OK(bnmtf_vb_set_state(h, F.data(), F.data(), F.data(), F.data(), S.data(), S.data(), S.data(), S.data(), G.data(), G.data(), G.data(), G.data(), 1.0));
+        const int per = K * L + K + L;
+        std::vector<int32_t> orders((size_t)2 * per);
+        for (int it = 0; it < 2; ++it) {
+          int32_t* o = &orders[(size_t)it * per];
+          for (int a = 0; a < K * L; ++a) o[a] = (a + it) % (K * L);
+          for (int k = 0; k < K; ++k) o[K * L + k] = K - 1 - k;
+          for (int l = 0; l < L; ++l) o[K * L + K + l] = l;
+        }
+        OK(bnmtf_vb_run(h, 2, orders.data(), nullptr, nullptr, nullptr, nullptr));
+        EXPECT_ERR(bnmtf_vb_update(h, 0, 0, 0, 1));          // (single updates are single-GPU hooks)
       }
       OK(bnmtf_destroy(h));
       rc[r] = 1;

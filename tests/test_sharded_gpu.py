@@ -140,6 +140,53 @@ def test_sharded_vb_run_equals_single_rank_run(monkeypatch, I, J, K, world, path
         assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("I,J,K,L,world", [(640, 512, 8, 6, 2), (515, 389, 12, 9, 3), (1300, 1100, 32, 32, 2)])
+def test_sharded_bnmtf_vb_run_equals_single_rank_run(I, J, K, L, world):
+    """bnmtf_vb over several ranks (round 6): rows of F and columns of G updated by their owners, the blocks of (E, var, S2)
+    gathered behind each half sweep, the S system summed over the ranks' column ranges and walked by every rank, the iteration's
+    sums exchanged as 21 doubles.  Deterministic: every rank holds the same trajectory, the single-rank one up to the order of sums."""
+    from bnmtf_amd import bnmtf_vb_optimised
+    from bnmtf_amd.synthetic import generate_bnmtf
+    R, M, _, _, _ = generate_bnmtf(I, J, K, L, 0.12, seed_data=5, seed_mask=6)
+    pri = dict(alpha=1., beta=1., lambdaF=0.1, lambdaS=0.1, lambdaG=0.1)
+    rs = np.random.RandomState(4)
+    n_it = 4
+    orders = np.array([np.concatenate([rs.permutation(K * L), rs.permutation(K), rs.permutation(L)]) for _ in range(n_it)], dtype=np.int32)
+
+    names = ["muF", "tauF", "expF", "varF", "muS", "tauS", "expS", "varS", "muG", "tauG", "expG", "varG"]
+    b0 = bnmtf_vb_optimised(R, M, K, L, pri, verbose=False)
+    np.random.seed(3)
+    b0.initialise("random", "random")
+    init = {n: getattr(b0, n).copy() for n in names}
+    init_exptau = float(b0.exptau)
+    b0.close()
+
+    def fit(**kw):
+        b = bnmtf_vb_optimised(R, M, K, L, pri, verbose=False, **kw)
+        for n in names:                      # (NumPy's global stream is not a thing to draw from in several threads)
+            setattr(b, n, init[n].copy())
+        b.exptau = init_exptau
+        b.run(n_it, orders=orders)
+        res = (np.array(b.all_exp_tau), np.array(b.all_performances["MSE"]), b.expF.copy(), b.expS.copy(), b.expG.copy(), b.muF.copy(), b.tauG.copy(), b.varG.copy(),
+               np.array(b.beta_s), np.array(b.exp_square_diff()))
+        b.close()
+        return res
+
+    single = fit()
+    cid = (b"BNMTFLOC" + ("tvb%d_%d" % (world, K)).encode()).ljust(128, b"\0")
+    ranks = _threads(world, lambda rank: fit(rank=rank, world=world, comm_id=cid))
+    for r in range(1, world):
+        for a, b in zip(ranks[0][:9], ranks[r][:9]):
+            assert np.array_equal(a, b)
+        assert abs(float(ranks[0][9]) / float(ranks[r][9]) - 1) < 1e-10       # (the direct pass adds its blocks' sums with atomics)
+    np.testing.assert_allclose(ranks[0][0], single[0], rtol=2e-4)
+    np.testing.assert_allclose(ranks[0][1], single[1], rtol=2e-4)
+    for got, ref in zip(ranks[0][2:8], single[2:8]):
+        assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max()
+    # update_tau of the last iteration (the exchanged sums) against the direct exp_square_diff of the gathered state
+    assert abs(float(ranks[0][8]) - (1.0 + 0.5 * float(ranks[0][9]))) < 5e-5 * float(ranks[0][8])
+
+
 @pytest.mark.parametrize("I,J,K,L,world", [(512, 640, 12, 9, 2), (389, 515, 20, 32, 3)])
 def test_sharded_bnmtf_run_equals_single_rank_run(I, J, K, L, world):
     """BNMTF Gibbs sharded: F rows / G columns drawn by their owners and gathered; the S step's (A, b) summed over the
