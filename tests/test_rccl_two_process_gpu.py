@@ -48,3 +48,39 @@ def test_two_ranks_over_rccl_draw_the_single_gpu_chain(tmp_path):
     v.initialise("exp"); v.run(6)
     np.testing.assert_allclose(r0["vb_mse"], v.all_performances["MSE"], rtol=1e-6)
     np.testing.assert_allclose(r0["vb_exptau"], v.all_exp_tau, rtol=1e-6)
+
+
+def test_every_sharded_model_family_runs_its_exchanges_through_a_one_rank_rccl_communicator(monkeypatch):
+    """One GPU: BNMTF_FORCE_COMM gives a model a 1-rank RCCL communicator, so its run() takes the multi-GPU code path -- the dlopen'd
+    RCCL calls (in-place all-gathers of factor blocks and moments, the S system's all-reduce, the exchanged sums) on the library's
+    streams -- with collectives that move nothing.  bnmf_gibbs has had this since round 2 (tests/test_bnmf_gibbs_gpu.py); here
+    the other families: bnmf_vb, bnmtf_gibbs, bnmtf_vb (sharded since round 6).  The trajectories must be the unsharded ones up
+    to the order of the exchanged sums."""
+    from bnmtf_amd import bnmf_vb_optimised, bnmtf_gibbs_optimised, bnmtf_vb_optimised
+    from bnmtf_amd.synthetic import generate_bnmf, generate_bnmtf
+    I, J, K, L = 300, 260, 12, 9
+    R2, M2, _, _ = generate_bnmf(I, J, K, 0.12, seed_data=1, seed_mask=2)
+    R3, M3, _, _, _ = generate_bnmtf(I, J, K, L, 0.12, seed_data=3, seed_mask=4)
+    pri2 = dict(alpha=1., beta=1., lambdaU=0.1, lambdaV=0.1)
+    pri3 = dict(alpha=1., beta=1., lambdaF=0.1, lambdaS=0.1, lambdaG=0.1)
+    rs = np.random.RandomState(0)
+    F0 = rs.exponential(1.0, (I, K)); S0 = rs.exponential(1.0, (K, L)); G0 = rs.exponential(1.0, (J, L))
+    orders = np.array([np.concatenate([rs.permutation(K * L), rs.permutation(K), rs.permutation(L)]) for _ in range(4)], dtype=np.int32)
+    out = {}
+    for force in (False, True):
+        if force:
+            monkeypatch.setenv("BNMTF_FORCE_COMM", "1")
+        v = bnmf_vb_optimised(R2, M2, K, pri2, verbose=False)
+        v.initialise("exp"); v.run(5)
+        g = bnmtf_gibbs_optimised(R3, M3, K, L, pri3, verbose=False, seed=3)
+        g.set_small_path(False)
+        g.F, g.S, g.G, g.tau = F0.copy(), S0.copy(), G0.copy(), 0.8
+        g.run(4, update="mode")
+        t = bnmtf_vb_optimised(R3, M3, K, L, pri3, verbose=False)
+        np.random.seed(2); t.initialise("random", "random")
+        t.run(4, orders=orders)
+        out[force] = (np.array(v.all_exp_tau), v.expU.copy(), np.array(g.all_tau), g.all_S[-1].copy(), np.array(t.all_exp_tau), t.expS.copy(), t.expF.copy())
+        for m in (v, g, t):
+            m.close()
+    for a, b in zip(out[False], out[True]):
+        assert np.abs(a - b).max() <= 2e-4 * np.abs(a).max()
