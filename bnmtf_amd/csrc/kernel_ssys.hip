@@ -148,7 +148,12 @@ __global__ __launch_bounds__(256) void scol_gram_kernel(SColGramArgs a, GammaPac
     const int row = (t & 3) + 8 * (t >> 2) + 4 * half;             // C/D layout of the 32 x 32 tile: column on the lane
     float cf = (float)a.Cf64[(size_t)row * 32 + c];
     float m = acc[t];
-    if (row == c) { if (a.cf_diag_extra) cf = (float)a.cf_diag_extra[c]; m += dv; }      // VB: C~f_kk = sum_i (E[F_ik]^2 + varF_ik) = the column sum of the second moments
+    if (row == c) {
+      // VB: C~f_kk = sum_i (E[F_ik]^2 + varF_ik) = the column sum of the second moments; the missing rows' variances gathered here
+      // (dv), or -- round 6 -- taken from the masked variance sums the G step has formed for this very q(F): total - observed
+      if (a.cf_diag_extra) cf = (float)a.cf_diag_extra[c];
+      m += a.var_obs ? (float)(a.cf_diag_extra[c] - a.Cf64[(size_t)c * 32 + c]) - a.var_obs[(size_t)u * 32 + c] : dv;
+    }
     if (row <= c && c < a.K) w[tri_pos(tri_index(row, c, a.K))] = cf - m;    // the upper triangle, packed: what the S-system GEMM reads
   }
 }
