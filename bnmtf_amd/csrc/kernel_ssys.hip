@@ -142,6 +142,8 @@ __global__ __launch_bounds__(256) void scol_gram_kernel(SColGramArgs a, GammaPac
 #pragma unroll
   for (int t = 0; t < 16; ++t) acc[t] += acc2[t];
   dv += __shfl_xor(dv, 32, 64);
+  if (VB && a.var_obs_out && half == 0)      // sum_{i in Omega_j} varF_ik = total - missing: what the G sweep's covariance term reads (masked_colsum_kernel's output)
+    a.var_obs_out[(size_t)u * 32 + c] = c < a.K ? (float)(a.cf_diag_extra[c] - a.Cf64[(size_t)c * 32 + c]) - dv : 0.f;
   float* w = a.Wc + (size_t)u * tri_padded(a.K);
 #pragma unroll
   for (int t = 0; t < 16; ++t) {

@@ -331,6 +331,7 @@ struct SColGramArgs {       // W~_j = C~f - sum_{i in miss(j)} (F_i F_i^T + diag
   const double* cf_diag_extra;         // VB: sum_i (E[F_ik]^2 + varF_ik) [32] (replaces the diagonal of Cf64), or null
   const uint32_t* slot_ptr; const uint32_t* idx;   // 64-wide slots of the cols direction
   float* Wc;                           // [n + 2][tri_padded(K)]: the packed upper triangle of W~_j (pads and the two extra rows stay zero)
+  float* var_obs_out = nullptr;        // VB with varF: [n][32] the observed rows' variance sums (total minus the gathered missing ones) go here -- the G step's mv
   const float* var_obs = nullptr;      // VB, instead of varF: [n][32] sum_{i in Omega_j} varF_ik (the G step's masked variance sums) -- the diagonal's sum over the MISSING rows is the total minus this
 };
 struct GammaPackArgs;

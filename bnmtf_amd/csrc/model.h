@@ -173,6 +173,7 @@ struct bnmtf_model {
   int* tri_order = nullptr; size_t tri_order_cap = 0;        // per iteration: K L entries of S, K columns of F, L columns of G
   double* tri_sums = nullptr;                                // 3 x 8 masked sums (metric_kernel passes)
   uint32_t s_word0 = 0; int s_ldword = 0;                    // a block of a wider S (bnmtf_set_s_block): the Philox column word of its entry (k, l) is s_word0 + k s_ldword + l (0: k L + l)
+  bool tri_w_current = false;                                // ss_Wc holds the masked column Grams of the current q(F) (formed behind its sweep)
   bool tri_mv_cols_current = false;                          // mv_cols holds the masked variance sums of the current q(F) (formed in the G step)
   bool tri_pv_current = false;                               // bnmtf_vb_run: slabsS holds R~^T E[F] of the current E[F] (formed behind the F sweep: the G step's and the next S system's)
   float* ss_Aperm = nullptr;                                 // the S system in the order of the current pass (bnmtf_vb's chain)
