@@ -135,6 +135,10 @@ __global__ __launch_bounds__(1024) void vb_finish_kernel(VbFinishArgs a) {
     const double* src = c < 6 ? a.stats_r : a.stats_c;
     const int n = c < 6 ? a.nr : a.nc;
     for (int b = lane; b < n; b += 64) s0 += src[(size_t)b * 8 + col];
+    // (round 6: the on-chip cols sweep's per-block sums -- sum P.X', sum_miss q, sum_miss q^2 -- are folded here by waves 4-6;
+    // they used to be a launch of their own behind a memset of acc: ~10 us of an iteration that is 125 us for a GDSC-shaped model)
+    if (a.sweep_stats && c < 3)
+      for (int b = lane; b < a.n_sweep_stats; b += 64) s1 += a.sweep_stats[(size_t)b * 4 + c];
   }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) { s0 += __shfl_xor(s0, m, 64); s1 += __shfl_xor(s1, m, 64); }
@@ -149,7 +153,8 @@ __global__ __launch_bounds__(1024) void vb_finish_kernel(VbFinishArgs a) {
     const double* su = &tot[1];
     const double* sv = &tot[7];
     const double sp1 = tot[13], s22 = tot[14], sdd = tot[15];
-    const double srp = a.acc[0], sp = sp1 - a.acc[1], spp = dot - a.acc[2];
+    const double acc0 = a.acc[0] + (a.sweep_stats ? red[4][1] : 0.0), acc1 = a.acc[1] + (a.sweep_stats ? red[5][1] : 0.0), acc2 = a.acc[2] + (a.sweep_stats ? red[6][1] : 0.0);
+    const double srp = acc0, sp = sp1 - acc1, spp = dot - acc2;
     const double n = a.n_obs;
     const double sse = a.sumR2 - 2.0 * srp + spp;
     const double esd = sse + (s22 - sv[4]) - (sdd - sv[5]) + red[0][1];

@@ -245,6 +245,7 @@ struct VbFinishArgs {
   double* tau_d; float* tau_f;         // exptau
   double* rec;                         // [16]: exptau, MSE, R2, Rp, ESD, beta_s, then 4 ELBO sums for U and 4 for V
   const double* extra; int n_extra;    // (tri-factorisation: partial sums of exp_square_diff's third term, added to ESD; null: none)
+  const double* sweep_stats; int n_sweep_stats;    // [n][4] per-block sums of the on-chip cols sweep, added to acc here (null: acc holds everything)
 };
 void launch_vb_finish(const VbFinishArgs& a, hipStream_t st);
 
