@@ -7,6 +7,10 @@ iteration in a deterministic update, against the reference's column loops restat
   cfg5  BNMF VB    8192 x 8192, K = 64        bnmf_vb_optimised.py:121-153, :181-215      update_U/V + moments of all 2 x 64 columns, exptau, ELBO pieces
   cfg4  BNMTF Gibbs 4096 x 4096, K = L = 32   bnmtf_gibbs_optimised.py:152-167, :195-211  F sweep, the first 64 steps of the S chain, G sweep
 
+The residual form lives in tests/_residual_form.py and is itself pinned: tests/test_residual_form_cpu.py holds it to the as-written
+oracle (oracle/bnmtf_oracle.py, which the reference's vectors pin) at 1e-9 on small shapes; oracle.BNMFGibbsFairCPU is the same
+form with draws.
+
 Tolerances: factors 5e-4 of their scale (fp32 contractions against fp64), masked MSE / exptau 3e-4 relative -- the MSE-identity
 tolerance stated in DESIGN.md section 5."""
 import numpy as np
@@ -15,6 +19,7 @@ import pytest
 from bnmtf_amd import bnmf_gibbs_optimised, bnmf_vb_optimised, bnmtf_gibbs_optimised
 from bnmtf_amd.synthetic import generate_bnmf, generate_bnmtf
 from oracle import bnmtf_oracle as O
+from _residual_form import mode_sweep, s_step_mode
 
 pytestmark = pytest.mark.gpu
 
@@ -22,15 +27,7 @@ LAM = 0.1
 
 
 def _mode_sweep(E, X, Y, Mm, tau, lam=LAM):
-    """columns of X given Y, mode update; E = M (R - X Y^T) is (rows of X) x (rows of Y) and kept current"""
-    for k in range(X.shape[1]):
-        a = Mm @ (Y[:, k] ** 2)
-        num = E @ Y[:, k] + X[:, k] * a
-        with np.errstate(divide="ignore", invalid="ignore"):
-            mu = (-lam + tau * num) / (tau * a)
-        new = np.where(a > 0, np.maximum(mu, 0.0), 0.0)
-        E -= Mm * np.outer(new - X[:, k], Y[:, k])
-        X[:, k] = new
+    mode_sweep(E, X, Y, Mm, tau, lam)
 
 
 def test_cfg2_whole_iteration_against_fp64_closed_forms():
@@ -121,8 +118,9 @@ def test_cfg5_whole_vb_iteration_against_fp64_closed_forms():
 
 def test_cfg4_f_sweep_first_s_steps_and_g_sweep_against_fp64_closed_forms():
     """One BNMTF iteration in the mode update (bnmtf_gibbs_optimised.py:152-167): the 32 F columns, the first 64 of the 1 024
-    sequential S entries (an entry's value after the iteration is its value right after its own step), and the 32 G columns
-    -- the latter from the device's own (F, S) so that the whole S chain need not be walked in NumPy."""
+    sequential S entries walked in NumPy (an entry's value after the iteration is its value right after its own step), eight
+    later entries up to the last one each checked as one step from the device's own earlier entries, and the 32 G columns
+    -- the latter from the device's own (F, S)."""
     I = J = 4096; K = L = 32
     R, M, _, _, _ = generate_bnmtf(I, J, K, L, 0.1, tau=1.0, seed_data=0, seed_mask=1)
     pri = dict(alpha=1., beta=1., lambdaF=LAM, lambdaS=LAM, lambdaG=LAM)
@@ -130,6 +128,7 @@ def test_cfg4_f_sweep_first_s_steps_and_g_sweep_against_fp64_closed_forms():
     rs = np.random.RandomState(2)                  # (factors of the data's scale: F S G^T ~ R, no column collapses to zero)
     b.F, b.S, b.G, b.tau = rs.exponential(1.0, (I, K)), rs.exponential(1.0, (K, L)), rs.exponential(1.0, (J, L)), 0.7
     F, S, G, tau = b.F.copy(), b.S.copy(), b.G.copy(), float(b.tau)
+    S_start = S.copy()
     b.run(1, update="mode")
     R64 = R.astype(np.float64); M64 = M.astype(np.float64)
     # ---- F columns: the U sweep with V := G S^T (:195-199)
@@ -142,12 +141,18 @@ def test_cfg4_f_sweep_first_s_steps_and_g_sweep_against_fp64_closed_forms():
     Sd = b.all_S[0]
     for step in range(64):
         k, l = divmod(step, L)
-        a = (F[:, k] ** 2) @ (M64 @ (G[:, l] ** 2))
-        num = F[:, k] @ (E @ G[:, l]) + S[k, l] * a
-        new = max((-LAM + tau * num) / (tau * a), 0.0) if a > 0 else 0.0
-        E -= M64 * ((new - S[k, l]) * np.outer(F[:, k], G[:, l]))
-        S[k, l] = new
+        new = s_step_mode(E, F, S, G, M64, tau, LAM, k, l)
         assert abs(Sd[k, l] - new) <= 1e-3 * max(abs(new), np.abs(S[:2]).max() * 1e-1), (k, l, Sd[k, l], new)
+    # ---- later S entries, up to the last one, each from the device's own earlier entries (an entry sees the new values of the
+    # entries before it and the old values of those behind it): the closed form of that one step, the whole chain length covered
+    Sold = S_start
+    for step in (64, 65, 257, 511, 512, 800, 1022, 1023):
+        k, l = divmod(step, L)
+        Smix = np.where((np.arange(K * L) < step).reshape(K, L), Sd.astype(np.float64), Sold)
+        Emix = M64 * (R64 - (F @ Smix) @ G.T)
+        new = s_step_mode(Emix, F, Smix, G, M64, tau, LAM, k, l)
+        assert abs(Sd[k, l] - new) <= 1e-3 * max(abs(new), np.abs(Sold).max() * 1e-1), (k, l, Sd[k, l], new)
+    del Emix
     # ---- G columns from the device's (F, S): the V sweep with U := F S (:207-211)
     Fd, Sd64 = b.all_F[0].astype(np.float64), Sd.astype(np.float64)
     Ueff = Fd @ Sd64
