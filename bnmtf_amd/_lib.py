@@ -65,6 +65,7 @@ _SIGS = {
     "bnmf_vb_exp_square_diff": ([_P, C.POINTER(C.c_double)], C.c_int),
     "bnmf_vb_masked_sums": ([_P, C.c_int, _P, _P], C.c_int),
     "bnmf_vb_run": ([_P, C.c_int, _P, _P, _P, _P], C.c_int),
+    "bnmf_vb_run_many": ([_P, C.c_int, C.c_int, _P, _P, _P, _P, _P], C.c_int),
     "bnmtf_vb_set_state": ([_P] + [_P] * 12 + [C.c_double], C.c_int),
     "bnmtf_vb_get_state": ([_P] + [_P] * 12, C.c_int),
     "bnmtf_vb_update": ([_P, C.c_int, C.c_int, C.c_int, C.c_int], C.c_int),

@@ -8,6 +8,7 @@ The reference fits the candidates of a model search -- folds x ranks x restarts 
 (csrc/kernel_small.hip), so a list of them is one launch per kind; models that do not qualify are run in turn.  ICM models (nmf_icm:
 their own run(), update rule and minimum_TN) are not taken: ReplicaPool runs them one by one."""
 import ctypes as C
+import time
 
 import numpy as np
 
@@ -26,13 +27,17 @@ def _kind(model):
         return "bnmf"
     if isinstance(model, bnmtf_gibbs_optimised) and type(model).run is bnmtf_gibbs_optimised.run:
         return "bnmtf"
+    from .bnmf_vb import bnmf_vb_optimised
+    if isinstance(model, bnmf_vb_optimised) and type(model).run is bnmf_vb_optimised.run:
+        return "vb"
     return None
 
 
 def run_many(models, iterations, update='draw', store_samples=True, expectation=None):
     """run(iterations, update, store_samples, expectation) of every model in `models` (bnmf_gibbs_optimised and / or
     bnmtf_gibbs_optimised instances), with the models of the one-launch path that share a device and a kind sharing a single
-    launch.  Returns the list of the runs' results, in the order of `models`."""
+    launch; bnmf_vb_optimised instances (their run(iterations)): the models of a device walk their iterations in lock-step, one
+    launch per kernel for all of them (csrc/api_many.inc).  Returns the list of the runs' results, in the order of `models`."""
     models = list(models)
     if not models:
         return []
@@ -45,6 +50,7 @@ def run_many(models, iterations, update='draw', store_samples=True, expectation=
         return [None for _ in models]
     out = [None] * len(models)
     upd = _lib.UPDATE_MODE if update == 'mode' else _lib.UPDATE_DRAW
+    _run_many_vb([m for m in models if _kind(m) == "vb"], int(iterations))
     for kind in ("bnmf", "bnmtf"):
         idx = [i for i, m in enumerate(models) if _kind(m) == kind]
         if not idx:
@@ -69,3 +75,27 @@ def run_many(models, iterations, update='draw', store_samples=True, expectation=
         for i, m, b, st in zip(idx, ms, bufs, states):
             out[i] = m._run_finish(b, store_samples, state=st)
     return out
+
+
+def _run_many_vb(ms, it):
+    """bnmf_vb_optimised.run(it) of every model of `ms` (bnmf_vb_optimised.py:121-153): per device one bnmf_vb_run_many call;
+    models wider than 64 columns (column blocks) run on their own."""
+    by_device = {}
+    for m in ms:
+        if m._blocks is not None:
+            m.run(it)
+        else:
+            by_device.setdefault(m._device, []).append(m)
+    for group in by_device.values():
+        n = len(group)
+        for m in group:
+            m._push()
+        hs = (C.c_void_p * n)(*[m._handle().value for m in group])
+        exptau = np.zeros((n, it)); perf = np.zeros((n, it, 3)); terms = np.zeros((n, it, 10)); times = np.zeros((n, it))
+        info = np.zeros(2, dtype=np.int32)
+        t0 = time.perf_counter()
+        _lib.check(_lib.lib().bnmf_vb_run_many(hs, n, it, _lib.ptr(exptau), _lib.ptr(perf), _lib.ptr(terms), _lib.ptr(times), _lib.ptr(info)))
+        dt = time.perf_counter() - t0
+        for i, m in enumerate(group):
+            m._run_finish(it, exptau[i], perf[i], terms[i], times[i])
+            m._many_info = (int(info[0]), int(info[1]), dt)     # models that shared launches, argument-list uploads, seconds of the device call

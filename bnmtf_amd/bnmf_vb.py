@@ -81,9 +81,15 @@ class bnmf_vb_optimised(DeviceModel):
         held = getattr(self, "_device_state", None)
         if held is not None and held[0] is self._h and held[1] == exptau and all(np.array_equal(getattr(self, n), a) for n, a in zip(self._NAMES, held[2])):
             return
+        if held is not None and held[0] is self._h and all(np.array_equal(getattr(self, n), a) for n, a in zip(self._NAMES, held[2])):
+            # only exptau moved (update_tau / update_exp_tau between two device calls): the q parameters on the device stay
+            _lib.check(_lib.lib().bnmtf_set_tau(self._handle(), exptau))
+            self._device_state = (held[0], exptau, held[2])
+            return
         self._device_state = None
         arrs = [_lib.f64(getattr(self, n)) for n in self._NAMES]
         _lib.check(_lib.lib().bnmf_vb_set_state(self._handle(), *[_lib.ptr(a) for a in arrs], exptau))
+        self._device_state = (self._h, exptau, [np.array(a, dtype=float) for a in arrs])      # (what the device holds now -- in fp32; a push of the same arrays would give it the same)
 
     def _pull(self):
         if self._blocks is not None:
@@ -108,12 +114,14 @@ class bnmf_vb_optimised(DeviceModel):
         if init == 'random':
             self.muU = self._rng().exponential(scale=1.0 / self.lambdaU)
             self.muV = self._rng().exponential(scale=1.0 / self.lambdaV)
-        self.expU, self.varU = np.zeros((self.I, self.K)), np.zeros((self.I, self.K))
-        self.expV, self.varV = np.zeros((self.J, self.K)), np.zeros((self.J, self.K))
-        for k in range(self.K):
-            self.update_exp_U(k)
-        for k in range(self.K):
-            self.update_exp_V(k)
+        # (update_exp_U(k) / update_exp_V(k) of every column, :111-115: the moments are element-wise -- one device call per factor
+        # instead of two per column; a model search builds dozens of models and their set-up was most of its wall time)
+        from .distributions import _moments
+        muU, muV = np.broadcast_to(self.muU, (self.I, self.K)), np.broadcast_to(self.muV, (self.J, self.K))
+        e, v = _moments(np.ravel(muU), np.ravel(self.tauU))
+        self.expU, self.varU = e.reshape(self.I, self.K), v.reshape(self.I, self.K)
+        e, v = _moments(np.ravel(muV), np.ravel(self.tauV))
+        self.expV, self.varV = e.reshape(self.J, self.K), v.reshape(self.J, self.K)
         self.update_tau()
         self.update_exp_tau()
 
@@ -125,12 +133,16 @@ class bnmf_vb_optimised(DeviceModel):
         self._push()
         exptau = np.zeros(it); perf = np.zeros((it, 3)); terms = np.zeros((it, 10)); times = np.zeros(it)
         _lib.check(_lib.lib().bnmf_vb_run(self._handle(), it, _lib.ptr(exptau), _lib.ptr(perf), _lib.ptr(terms), _lib.ptr(times)))
+        self._run_finish(it, exptau, perf, terms, times)
+
+    def _run_finish(self, it, exptau, perf, terms, times):
+        """What run() does behind the device call (batch.run_many: behind the call that ran this model among others)."""
         self._pull()
         self.all_exp_tau = list(exptau)
         self.all_times = list(times)
         self.all_performances = {'MSE': list(perf[:, 0]), 'R^2': list(perf[:, 1]), 'Rp': list(perf[:, 2])}
-        self.all_elbo = [self._elbo_from_terms(terms[i]) for i in range(it)]
         self.all_elbo_terms = terms        # per iteration: exp_square_diff, beta_s, then (quad, log erfc, log tau, lambda E) sums of U and of V
+        self._all_elbo = None              # (all_elbo: finished from the terms when somebody reads it -- a model search reads the last state only)
         if it > 0:
             self.alpha_s = self.alpha + self.size_Omega / 2.0
             self.beta_s = terms[-1, 1]
@@ -186,6 +198,18 @@ class bnmf_vb_optimised(DeviceModel):
             - (alpha_s - 1.) * explogtau + beta_s * exptau \
             - .5 * ltau_u + self.I * self.K / 2. * math.log(2 * math.pi) + lerfc_u + quad_u \
             - .5 * ltau_v + self.J * self.K / 2. * math.log(2 * math.pi) + lerfc_v + quad_v
+
+    @property
+    def all_elbo(self):
+        """The ELBO of every iteration of the last run() (the value the reference prints, :148-150)."""
+        if getattr(self, "_all_elbo", None) is None:
+            terms = getattr(self, "all_elbo_terms", None)
+            self._all_elbo = [] if terms is None else [self._elbo_from_terms(t) for t in terms]
+        return self._all_elbo
+
+    @all_elbo.setter
+    def all_elbo(self, value):
+        self._all_elbo = value
 
     def _elbo_from_terms(self, t):
         esd, beta_s = t[0], t[1]

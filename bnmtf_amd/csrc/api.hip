@@ -15,6 +15,7 @@
 
 #include "model.h"
 #include "comm.h"
+#include "many.h"
 #include "device_rng.h"
 
 namespace bnmtf {
@@ -1743,3 +1744,4 @@ int bnmtf_gamma_sample(double alpha, double beta, uint64_t seed, uint64_t it, in
 
 #include "api_models.inc"
 #include "api_trivb.inc"
+#include "api_many.inc"

@@ -20,6 +20,7 @@
 #include <cstring>
 
 #include "kernels.h"
+#include "many.h"
 
 namespace bnmtf {
 
@@ -183,7 +184,7 @@ __device__ __forceinline__ void split3(const float (&v)[8], u32x4& hi, u32x4& mi
 }
 
 template <int MT, int NSET, int TW, int RB = 1>      // RB = 0 (BNMTF_GEMM_RING=old, A/B only): the ring with its loads behind conditions
-__global__ __launch_bounds__(256, (TW == 4 ? 1 : 2)) void gemm_bf16x3_kernel(GemmArgs a) {
+__device__ __forceinline__ void gemm_bf16x3_body(const GemmArgs& a) {
   typedef float f32xT __attribute__((ext_vector_type(TW)));   // TW column tiles per wave: one TW-dword load per lane per row
   constexpr int KP = MT * 32;
   constexpr int NACC = MT * TW * 16;            // accumulator floats per lane
@@ -328,6 +329,12 @@ __global__ __launch_bounds__(256, (TW == 4 ? 1 : 2)) void gemm_bf16x3_kernel(Gem
   }
 }
 
+template <int MT, int NSET, int TW, int RB = 1>
+__global__ __launch_bounds__(256, (TW == 4 ? 1 : 2)) void gemm_bf16x3_kernel(GemmArgs a) { gemm_bf16x3_body<MT, NSET, TW, RB>(a); }
+// list form (many.h): blockIdx.z = model
+template <int MT, int NSET, int TW>
+__global__ __launch_bounds__(256, (TW == 4 ? 1 : 2)) void gemm_bf16x3_many(const GemmArgs* list, int) { gemm_bf16x3_body<MT, NSET, TW, 1>(load_pack(list, blockIdx.z)); }
+
 #ifndef BNMTF_GEMM_NSET
 #define BNMTF_GEMM_NSET 3        // raw-operand register sets of the ring (tools/variant.sh builds try 4)
 #endif
@@ -356,6 +363,12 @@ void launch_gemm(const GemmArgs& a, int KP, hipStream_t st) {
       return;
     }
 #endif
+    if (g_recorder) {
+      if (KP == 32) record_launch((const void*)gemm_bf16x3_many<1, BNMTF_GEMM_NSET, 4>, grid, block, 0, a);
+      else if (a.tw == 2) record_launch((const void*)gemm_bf16x3_many<2, BNMTF_GEMM_NSET, 2>, dim3(a.n_pad / 64, ns), block, 0, a);
+      else record_launch((const void*)gemm_bf16x3_many<2, BNMTF_GEMM_NSET, 4>, grid, block, 0, a);
+      return;
+    }
     if (KP == 32) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, BNMTF_GEMM_NSET, 4>), grid, block, 0, st, a);
     else if (a.tw == 2) hipLaunchKernelGGL((gemm_bf16x3_kernel<2, BNMTF_GEMM_NSET, 2>), dim3(a.n_pad / 64, ns), block, 0, st, a);
     else          hipLaunchKernelGGL((gemm_bf16x3_kernel<2, BNMTF_GEMM_NSET, 4>), grid, block, 0, st, a);

@@ -4,6 +4,7 @@
 #include <algorithm>
 
 #include "kernels.h"
+#include "many.h"
 #include "device_rng.h"
 
 namespace bnmtf {
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(1024) void finish_kernel(FinishArgs a) {
 }
 // VB end of iteration (bnmf_vb_optimised.py:181-187, 213-215): exp_square_diff from Gram identities,
 // exptau = alpha_s / beta_s, training-mask metrics, and the O((I+J)K) sums elbo() needs.
-__global__ __launch_bounds__(1024) void vb_finish_kernel(VbFinishArgs a) {
+__device__ __forceinline__ void vb_finish_body(const VbFinishArgs& a) {
   __shared__ double red[16][16];
   const int KP = a.KP, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // 16 sums: <Cr, Cc>, six columns of the rows-sweep pieces, six of the cols-sweep pieces, and the three K-term sums (colsum .
@@ -170,7 +171,15 @@ __global__ __launch_bounds__(1024) void vb_finish_kernel(VbFinishArgs a) {
     for (int c = 0; c < 4; ++c) { a.rec[6 + c] = su[c]; a.rec[10 + c] = sv[c]; }
   }
 }
+__global__ __launch_bounds__(1024) void vb_finish_kernel(VbFinishArgs a) { vb_finish_body(a); }
+// list form (many.h): blockIdx.z = model; rec = the run's first record, the iteration's one is `it` records behind it
+__global__ __launch_bounds__(1024) void vb_finish_many(const VbFinishArgs* list, int it) {
+  VbFinishArgs a = load_pack(list, blockIdx.z);
+  a.rec += (size_t)it * 16;
+  vb_finish_body(a);
+}
 void launch_vb_finish(const VbFinishArgs& a, hipStream_t st) {
+  if (record_launch((const void*)vb_finish_many, dim3(1), dim3(1024), 0, a)) return;     // (recording: the caller passes the run's FIRST record)
   hipLaunchKernelGGL(vb_finish_kernel, dim3(1), dim3(1024), 0, st, a);
 }
 

@@ -6,6 +6,7 @@
 // One pass over X: kPostRows (32) rows per block staged in LDS; per-block Gram partials go to a
 // slab and are summed by gram_reduce_kernel (deterministic, no atomics).
 #include "kernels.h"
+#include "many.h"
 
 namespace bnmtf {
 
@@ -17,7 +18,7 @@ __device__ __forceinline__ void tri_tile(int p, int NT, int* ty, int* tx) {
 }
 
 template <bool VB>
-__global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
+__device__ __forceinline__ void post_body(const PostArgs& a) {
   constexpr int RB = kPostRows;
   constexpr int LD = 68, LDD = 66;           // floats per row of a layout tile ; doubles per row of the Gram tile
   // a layout block holds X rows (VB: and S2 rows) as floats; a Gram block holds its X rows as DOUBLES (converted once, when the
@@ -132,11 +133,15 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
       }
   }
 }
+template <bool VB>
+__global__ __launch_bounds__(256) void post_kernel(PostArgs a) { post_body<VB>(a); }
+template <bool VB>       // list form (many.h): blockIdx.z = model
+__global__ __launch_bounds__(256) void post_many(const PostArgs* list, int) { post_body<VB>(load_pack(list, blockIdx.z)); }
 
 // 32 packed entries per block, 32 partial-slab strides per entry (thread = entry e + 32*g), summed through LDS in a fixed
 // order: ceil(PS/32) blocks of 1024 threads (+ one for the column sums), every slab read is a coalesced 256 B segment; a
 // tile above the diagonal is written twice (itself and its mirror).
-__global__ __launch_bounds__(1024) void gram_reduce_kernel(PostArgs a, int nblk) {
+__device__ __forceinline__ void gram_reduce_body(const PostArgs& a, int nblk) {
   __shared__ double red[1024];
   const int KP = a.KP;
   if (a.S2 && a.mpart && a.umax && (int)blockIdx.x == (int)gridDim.x - 2) {
@@ -220,14 +225,26 @@ __global__ __launch_bounds__(1024) void gram_reduce_kernel(PostArgs a, int nblk)
     if (ty != tx) { a.C64[col * KP + row] = tot; a.C32[col * KP + row] = (float)tot; }    // the mirror tile
   }
 }
+__global__ __launch_bounds__(1024) void gram_reduce_kernel(PostArgs a, int nblk) { gram_reduce_body(a, nblk); }
+struct GramReducePack { PostArgs a; int nblk; int pad_; };
+__global__ __launch_bounds__(1024) void gram_reduce_many(const GramReducePack* list, int) {
+  const GramReducePack p = load_pack(list, blockIdx.z);
+  gram_reduce_body(p.a, p.nblk);
+}
 
 void launch_post(const PostArgs& a0, hipStream_t st) {
   PostArgs a = a0;
   a.do_layout = 1; a.do_gram = 1; a.blk0 = 0; a.own0 = 0; a.own1 = a.rows;
   const int nblk = post_blocks(a.rows);
-  if (a.S2) hipLaunchKernelGGL(post_kernel<true>, dim3(nblk, 2), dim3(256), 0, st, a); else hipLaunchKernelGGL(post_kernel<false>, dim3(nblk, 2), dim3(256), 0, st, a);
   const int nt = a.KP / 4, ps = nt * (nt + 1) / 2 * 16;
   const int extra = (a.S2 && a.mpart && a.umax) ? 2 : 1;      // the column-sum block, and (VB with the masked sums) the column-maximum block
+  if (g_recorder) {
+    record_launch(a.S2 ? (const void*)post_many<true> : (const void*)post_many<false>, dim3(nblk, 2), dim3(256), 0, a);
+    GramReducePack p; memset(&p, 0, sizeof(p)); p.a = a; p.nblk = nblk;
+    record_launch((const void*)gram_reduce_many, dim3((ps + 31) / 32 + extra), dim3(1024), 0, p);
+    return;
+  }
+  if (a.S2) hipLaunchKernelGGL(post_kernel<true>, dim3(nblk, 2), dim3(256), 0, st, a); else hipLaunchKernelGGL(post_kernel<false>, dim3(nblk, 2), dim3(256), 0, st, a);
   hipLaunchKernelGGL(gram_reduce_kernel, dim3((ps + 31) / 32 + extra), dim3(1024), 0, st, a, nblk);
 }
 

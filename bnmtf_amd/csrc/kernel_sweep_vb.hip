@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include "sweep_common.h"
+#include "many.h"
 
 namespace bnmtf {
 
@@ -378,6 +379,22 @@ __global__ __launch_bounds__((NW + NS) * 64, 1) void sweep_vb_kernel(SweepArgs a
   else sweep_vb_body<kWideMaxSlots, NX, NW, NS, COV>(a, f, lds);      // host guarantees e0 <= kWideMaxSlots
 }
 
+struct SweepVbPack { SweepArgs a; FastArgs f; };
+template <int NX, int NW, int NS, int COV = 0>       // list form (many.h): blockIdx.z = model; a model with fewer blocks than the launch leaves
+__global__ __launch_bounds__((NW + NS) * 64, 1) void sweep_vb_many(const SweepVbPack* list, int) {
+  extern __shared__ float lds[];
+  const SweepVbPack p = load_pack(list, blockIdx.z);
+  if ((int)blockIdx.x >= (p.f.npairs + NW - 1) / NW) return;
+  const int wv = (int)(threadIdx.x >> 6);
+  const int pr = blockIdx.x * NW + wv;
+  const int e0 = __builtin_amdgcn_readfirstlane((wv < NW && pr < p.f.npairs) ? (int)p.f.pair_E[pr] : 0);
+  if (e0 <= 8) sweep_vb_body<8, NX, NW, NS, COV>(p.a, p.f, lds);
+  else if (e0 <= 16) sweep_vb_body<16, NX, NW, NS, COV>(p.a, p.f, lds);
+  else if (e0 <= 24) sweep_vb_body<24, NX, NW, NS, COV>(p.a, p.f, lds);
+  else if (e0 <= 28) sweep_vb_body<28, NX, NW, NS, COV>(p.a, p.f, lds);
+  else sweep_vb_body<kWideMaxSlots, NX, NW, NS, COV>(p.a, p.f, lds);
+}
+
 int sweep_vb_blocks(int npairs, int nw) { return (npairs + nw - 1) / nw; }
 static size_t sweep_vb_lds_bytes(int KP, int pw, bool cov = false) { return sizeof(float) * ((size_t)KP * KP + KP + 2 * 16 * 5 + (cov ? 1024 : 0) + 4 * (size_t)pw); }
 
@@ -388,6 +405,16 @@ template <int NX, int NW, int NS, int COV = 0>
 static void launch_vb_inst(const SweepArgs& a, const FastArgs& f, hipStream_t st) {
   static std::atomic<uint64_t> lds_ok{0};
   const int nblocks = sweep_vb_blocks(f.npairs, NW);
+  if (g_recorder) {
+    if constexpr (COV == 0) {            // (the tri-factorisation's sweeps have no list form)
+    static std::atomic<uint64_t> lds_ok_many{0};
+    if (nblocks <= 0 || !allow_full_lds((const void*)sweep_vb_many<NX, NW, NS, COV>, lds_ok_many)) return;
+    SweepVbPack p; memset(&p, 0, sizeof(p)); p.a = a; p.f = f;
+    record_launch((const void*)sweep_vb_many<NX, NW, NS, COV>, dim3(nblocks), dim3((NW + NS) * 64),
+                  std::max(sweep_vb_lds_bytes(a.KP, f.pw, COV != 0), sizeof(float) * ((size_t)a.KP * a.KP + a.KP + 2 * 16 * 5 + (size_t)f.ho_lds_floats)), p, true);
+    }
+    return;
+  }
   if (nblocks > 0 && allow_full_lds((const void*)sweep_vb_kernel<NX, NW, NS, COV>, lds_ok)) hipLaunchKernelGGL((sweep_vb_kernel<NX, NW, NS, COV>), dim3(nblocks), dim3((NW + NS) * 64), std::max(sweep_vb_lds_bytes(a.KP, f.pw, COV != 0), sizeof(float) * ((size_t)a.KP * a.KP + a.KP + 2 * 16 * 5 + (size_t)f.ho_lds_floats)), st, a, f);
 }
 
@@ -406,8 +433,8 @@ void launch_sweep_vb(const SweepArgs& a, const FastArgs& f, hipStream_t st) {
 //   [0] sum_k tau/2 (Var + (E - mu)^2)   [1] sum_k log(1/2 erfc(-mu sqrt(tau/2)))   [2] sum_k log tau   [3] sum_k lambda E
 //   [4] sum_k S2self sum_miss S2other    [5] sum_k E^2 sum_miss Eother^2
 // out: one row of 8 per BLOCK of four units (vb_finish_kernel only needs the totals).
-__global__ __launch_bounds__(256) void vb_pieces_kernel(int n, int n0, int KP, int K, const float* mu, const float* tauq, const float* ex,
-                                                         const float* var, const float* lambda, const float* asq, const float* vsq, double* out) {
+__device__ __forceinline__ void vb_pieces_body(int n, int n0, int KP, int K, const float* mu, const float* tauq, const float* ex,
+                                               const float* var, const float* lambda, const float* asq, const float* vsq, double* out) {
   const int lane = threadIdx.x & 63, u = blockIdx.x * 4 + (threadIdx.x >> 6);
   double p[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   if (u < n && lane < K) {
@@ -431,6 +458,16 @@ __global__ __launch_bounds__(256) void vb_pieces_kernel(int n, int n0, int KP, i
   if (lane == 0) for (int c = 0; c < 6; ++c) red[threadIdx.x >> 6][c] = p[c];
   sync_with_dma();
   if (threadIdx.x < 6) out[(size_t)blockIdx.x * 8 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void vb_pieces_kernel(int n, int n0, int KP, int K, const float* mu, const float* tauq, const float* ex,
+                                                         const float* var, const float* lambda, const float* asq, const float* vsq, double* out) {
+  vb_pieces_body(n, n0, KP, K, mu, tauq, ex, var, lambda, asq, vsq, out);
+}
+struct VbPiecesPack { int n, n0, KP, K; const float *mu, *tauq, *ex, *var, *lambda, *asq, *vsq; double* out; };
+__global__ __launch_bounds__(256) void vb_pieces_many(const VbPiecesPack* list, int) {      // list form (many.h): blockIdx.z = model
+  const VbPiecesPack p = load_pack(list, blockIdx.z);
+  if ((int)blockIdx.x >= (p.n + 3) / 4) return;
+  vb_pieces_body(p.n, p.n0, p.KP, p.K, p.mu, p.tauq, p.ex, p.var, p.lambda, p.asq, p.vsq, p.out);
 }
 
 // the same with sum_miss S2other / sum_miss Eother^2 taken from the slabs of kernel_maskgemm.hip ([msplit][n_pad][2 KP], local
@@ -472,6 +509,12 @@ void launch_vb_pieces_slabs(int n, int n0, int KP, int K, const float* mu, const
 void launch_vb_pieces(int n, int n0, int KP, int K, const float* mu, const float* tauq, const float* ex, const float* var,
                       const float* lambda, const float* asq, const float* vsq, double* out, hipStream_t st) {
   if (n <= 0) return;
+  if (g_recorder) {
+    VbPiecesPack p; memset(&p, 0, sizeof(p));
+    p.n = n; p.n0 = n0; p.KP = KP; p.K = K; p.mu = mu; p.tauq = tauq; p.ex = ex; p.var = var; p.lambda = lambda; p.asq = asq; p.vsq = vsq; p.out = out;
+    record_launch((const void*)vb_pieces_many, dim3((n + 3) / 4), dim3(256), 0, p, true);
+    return;
+  }
   hipLaunchKernelGGL(vb_pieces_kernel, dim3((n + 3) / 4), dim3(256), 0, st, n, n0, KP, K, mu, tauq, ex, var, lambda, asq, vsq, out);
 }
 

@@ -233,6 +233,14 @@ BNMTF_API int bnmf_vb_masked_sums(bnmtf_handle h, int which, double* asq, double
  *    the same four for V};  the host finishes the scalar algebra (digamma, gammaln). */
 BNMTF_API int bnmf_vb_run(bnmtf_handle h, int n_iter, double* exptau_out, double* perf_out,
                 double* elbo_terms_out, double* times_out);
+/* run(iterations) of n_models variational models on one device, walked in lock-step: every kernel of an iteration is ONE launch
+ * for all of them (csrc/many.h, api_many.inc) -- the reference's model searches (experiments_gdsc/cross_validation/vb_nmf/
+ * linesearch_xval_vb.py:17-52) are dozens of independent models of 622 x 138.  Every model ends with the bits of its own
+ * bnmf_vb_run.  Outputs model-major ([n_models][n_iter]..., as bnmf_vb_run's; times = the batch's clock); any may be null.  Models
+ * that cannot share launches (several GPUs, the 16-wave shapes of large problems, kernel timers on) run one after the other.
+ * launch_info (optional, 2 ints): the models that shared launches, the argument-list uploads. */
+BNMTF_API int bnmf_vb_run_many(bnmtf_handle* hs, int n_models, int n_iter, double* exptau_out, double* perf_out,
+                     double* elbo_terms_out, double* times_out, int* launch_info);
 
 /* ---- BNMTF VB (bnmtf_vb_optimised.py); K, L <= 32, one GPU ---------------- */
 /* the twelve q-parameter matrices (F: I x K, S: K x L, G: J x L) + exptau; any pointer may be NULL (left as is) */

@@ -105,6 +105,30 @@ static void vb_round_trip(const Data& d, int K) {
   OK(bnmtf_destroy(h));
 }
 
+// several variational models in lock-step (api_many.inc): the recorder, the argument lists, the per-model outputs; two shapes and a
+// model given once only
+static void vb_many(const Data& d1, const Data& d2, int K) {
+  std::vector<bnmtf_handle> hs;
+  const long live0 = hipstub_live_allocs();
+  for (int m = 0; m < 5; ++m) {
+    const Data& d = m == 3 ? d2 : d1;
+    bnmtf_handle h = create(d, m == 1 ? K + 3 : K, 0, 0, 1, nullptr);
+    const int Km = m == 1 ? K + 3 : K;
+    std::vector<double> a((size_t)d.I * Km, 1.0), b((size_t)d.J * Km, 1.0);
+    OK(bnmf_vb_set_state(h, a.data(), a.data(), a.data(), a.data(), b.data(), b.data(), b.data(), b.data(), 1.0));
+    hs.push_back(h);
+  }
+  const int n = (int)hs.size(), it = 3;
+  std::vector<double> et((size_t)n * it), perf((size_t)n * it * 3), elbo((size_t)n * it * 10), times((size_t)n * it);
+  int info[2];
+  OK(bnmf_vb_run_many(hs.data(), n, it, et.data(), perf.data(), elbo.data(), times.data(), info));
+  OK(bnmf_vb_run_many(hs.data(), n, 2, nullptr, nullptr, nullptr, nullptr, nullptr));
+  OK(bnmf_vb_run_many(hs.data(), 1, 2, et.data(), nullptr, nullptr, nullptr, info));
+  const long live1 = hipstub_live_allocs();
+  for (bnmtf_handle h : hs) OK(bnmtf_destroy(h));
+  if (getenv("SAN_VERBOSE")) printf("vb_many: live allocations %ld before, %ld with five models, %ld after\n", live0, live1, hipstub_live_allocs());
+}
+
 // the variational tri-factorisation: set_state / run with shuffled orders / the direct exp_square_diff / single updates / get_state
 static void tri_vb_round_trip(const Data& d, int K, int L, int iters) {
   bnmtf_handle h = create(d, K, L, 0, 1, nullptr);
@@ -258,6 +282,7 @@ static void sharded(const Data& d, int K, int L, int world, const char* token, i
       }
       OK(bnmtf_destroy(h));
       rc[r] = 1;
+  vb_many(make_data(300, 120, 0.15, 21), make_data(210, 150, 0.1, 22), 12);
     });
   for (auto& t : ts) t.join();
   for (int r = 0; r < world; ++r) if (!rc[r]) { fprintf(stderr, "rank %d did not finish\n", r); exit(2); }
