@@ -404,7 +404,7 @@ def main_cv(a, w):
     its = a.steps if a.steps_given else w["iterations"]
     burn, thin = (w["burn_in"], w["thinning"]) if its == w["iterations"] else (its // 2, 2)
     res = {}
-    vb = w.get("classifier") == "vb"             # (the variational line search, linesearch_xval_vb.py: no one-launch kernel -- every model on the multi-launch path)
+    vb = w.get("classifier") == "vb"             # (the variational line search, linesearch_xval_vb.py: no one-launch kernel; --cv-batched: the models of a slot share every launch, csrc/api_many.inc)
     for s in a.slots:
         random.seed(0); np.random.seed(0)
         pool = ReplicaPool(devices=[0] * s, shared={"R": np.asarray(R, dtype=float)}, **({"batched": True} if a.cv_batched else {}))

@@ -19,6 +19,7 @@ python bench.py --workload cv_gdsc_bnmtf --slots 1 4 8 > gpurun_out/bench_$tag/$
 python bench.py --workload cv_gdsc > gpurun_out/bench_$tag/${tag}_cv_gdsc_slots.json 2>> gpurun_out/bench_$tag/err.txt
 python bench.py --workload cv_gdsc --cv-batched --slots 1 > gpurun_out/bench_$tag/${tag}_cv_gdsc_batched.json 2>> gpurun_out/bench_$tag/err.txt
 python bench.py --workload cv_gdsc_vb --slots 1 4 8 > gpurun_out/bench_$tag/${tag}_cv_gdsc_vb.json 2>> gpurun_out/bench_$tag/err.txt
+python bench.py --workload cv_gdsc_vb --cv-batched --slots 1 2 4 > gpurun_out/bench_$tag/${tag}_cv_gdsc_vb_batched.json 2>> gpurun_out/bench_$tag/err.txt
 rocm-smi --showpower --showclocks 2>/dev/null | grep -E "sclk|Power" | head -4 > gpurun_out/bench_$tag/smi.txt
 cat gpurun_out/bench_$tag/gpu_suite.txt
 for f in gpurun_out/bench_$tag/*.json; do python - "$f" <<'PY'
