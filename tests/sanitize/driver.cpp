@@ -283,6 +283,12 @@ static void sharded(const Data& d, int K, int L, int world, const char* token, i
       OK(bnmtf_destroy(h));
       rc[r] = 1;
   vb_many(make_data(300, 120, 0.15, 21), make_data(210, 150, 0.1, 22), 12);
+  {   // two host threads, a list of models each (the recorder is thread-local)
+    const Data da = make_data(280, 110, 0.15, 23), db = make_data(190, 160, 0.1, 24), dc = make_data(260, 100, 0.2, 25), dd = make_data(150, 170, 0.1, 26);
+    std::thread t1([&] { vb_many(da, db, 10); });
+    std::thread t2([&] { vb_many(dc, dd, 14); });
+    t1.join(); t2.join();
+  }
     });
   for (auto& t : ts) t.join();
   for (int r = 0; r < world; ++r) if (!rc[r]) { fprintf(stderr, "rank %d did not finish\n", r); exit(2); }
