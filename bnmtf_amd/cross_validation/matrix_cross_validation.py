@@ -26,6 +26,11 @@ def fold_job(job, shared):
     """One fold on the worker's GPU: `method(X, train, **parameters).train(**train_config).predict(test)` (:85-88)."""
     method = job["method"]
     kw = dict(job["parameters"])
+    if job.get("seed") is not None:              # (an extension: the reference's folds draw from the process's global streams, :85-88)
+        import random
+        numpy.random.seed(job["seed"] % (2 ** 32)); random.seed(job["seed"])
+        if _accepts(method.__init__, "seed"):
+            kw.setdefault("seed", job["seed"])
     if _accepts(method.__init__, "device"):
         kw["device"] = job.get("device", 0)
     if _accepts(method.__init__, "verbose"):
@@ -47,8 +52,11 @@ class _Setting(object):
 
 
 class MatrixCrossValidation(object):
-    def __init__(self, method, X, M, K, parameter_search, train_config, file_performance, *, devices=None):
+    def __init__(self, method, X, M, K, parameter_search, train_config, file_performance, *, devices=None, seed=None):
+        """seed (not in the reference): every fold job seeds NumPy's and Python's global streams -- and the model's sampler -- with
+        seed + its index before it builds its model; the folds run in worker processes, whose streams are otherwise their own."""
         self.method = method
+        self.seed = seed
         self.X = numpy.array(X, dtype=float)
         self.M = numpy.array(M)
         self.K = K
@@ -85,7 +93,8 @@ class MatrixCrossValidation(object):
         jobs, owner = [], []
         for si, setting in enumerate(plan):
             for train, test in setting.folds:
-                jobs.append(dict(method=self.method, parameters=setting.parameters, train=train, test=test, train_config=self.train_config))
+                jobs.append(dict(method=self.method, parameters=setting.parameters, train=train, test=test, train_config=self.train_config,
+                                 seed=None if self.seed is None else self.seed + 7919 * len(jobs)))
                 owner.append(si)
         if not jobs:
             return

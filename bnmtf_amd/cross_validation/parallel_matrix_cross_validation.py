@@ -5,10 +5,10 @@ from .matrix_cross_validation import MatrixCrossValidation
 
 
 class ParallelMatrixCrossValidation(MatrixCrossValidation):
-    def __init__(self, method, X, M, K, parameter_search, train_config, file_performance, P, *, devices=None):
+    def __init__(self, method, X, M, K, parameter_search, train_config, file_performance, P, *, devices=None, seed=None):
         if devices is None:
             from .replicas import visible_devices
             n = max(visible_devices(), 1)
             devices = [p % n for p in range(P)]
-        MatrixCrossValidation.__init__(self, method, X, M, K, parameter_search, train_config, file_performance, devices=devices)
+        MatrixCrossValidation.__init__(self, method, X, M, K, parameter_search, train_config, file_performance, devices=devices, seed=seed)
         self.P = P

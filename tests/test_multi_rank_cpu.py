@@ -9,9 +9,27 @@ import socket
 
 import numpy as np
 import pytest
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
+
+
+class _Lazy(object):
+    """torch, imported when a test of THIS module first touches it.  A `pytest tests -m gpu` session imports every test module at
+    collection; torch brings the HIP runtime bundled with its wheel into the process, and libbnmtf_hip.so -- loaded later -- would
+    then run on that runtime instead of /opt/rocm's (the one bench.py, smoke() and every user of the library run on)."""
+    def __init__(self, name):
+        self._name, self._mod = name, None
+
+    def __getattr__(self, attr):
+        if attr.startswith("_"):                  # (pytest's collection probes every module-level object for __test__, pytestmark, ...)
+            raise AttributeError(attr)
+        if self._mod is None:
+            import importlib
+            self._mod = importlib.import_module(self._name)
+        return getattr(self._mod, attr)
+
+
+torch = _Lazy("torch")
+dist = _Lazy("torch.distributed")
+mp = _Lazy("torch.multiprocessing")
 
 from bnmtf_amd.comm import shard_range
 from oracle import bnmtf_oracle as O

@@ -2,7 +2,8 @@
 # The round's closing run on the GPU box: the gpu suite, the profiles of the four large workloads, the bench lines kept under profiles/bench/.
 tag=$1
 mkdir -p gpurun_out/bench_$tag
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > gpurun_out/bench_$tag/gpu_suite.txt
+timeout 1500 python -X faulthandler -m pytest tests -m gpu -q > gpurun_out/bench_$tag/gpu_suite_full.txt 2>&1      # (whole output kept: an abort's message and stacks are in it)
+grep -E "passed|failed|error|Abort|Fatal|fault" gpurun_out/bench_$tag/gpu_suite_full.txt | tail -5 > gpurun_out/bench_$tag/gpu_suite.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" >> gpurun_out/bench_$tag/gpu_suite.txt 2>&1
 bash tools/profile_round.sh $tag bnmf_8192_k64 bnmf_4096_k32 bnmtf_4096_k32 vb_8192_k64 bnmtf_vb_4096_k32 > gpurun_out/bench_$tag/profile.log 2>&1
 python bench.py > gpurun_out/bench_$tag/${tag}_bnmf_8192_k64.json 2> gpurun_out/bench_$tag/err.txt
