@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <system_error>
 #include <thread>
 #include <tuple>
 #include <vector>
@@ -113,8 +114,15 @@ static void parallel_chunks(int n, int chunk, Fn fn) {
     for (int c = next.fetch_add(1); c < nchunks; c = next.fetch_add(1)) fn(c * chunk, std::min(n, (c + 1) * chunk));
   };
   if (nt == 1) { work(); return; }
+  // nt - 1 helpers and the calling thread.  A thread that cannot be had (EAGAIN: the user's process / thread limit -- a long test
+  // session with worker pools, three ranks building their layouts at once) must not leave this function as an exception: it
+  // would cross the C ABI and end the process (std::terminate).  The chunks are claimed one by one, so whoever is there does them.
   std::vector<std::thread> ts;
-  for (int t = 0; t < nt; ++t) ts.emplace_back(work);
+  ts.reserve(nt);
+  for (int t = 0; t + 1 < nt; ++t) {
+    try { ts.emplace_back(work); } catch (const std::system_error&) { break; }
+  }
+  work();
   for (auto& t : ts) t.join();
 }
 
