@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <exception>
+#include <new>
 #include <system_error>
 #include <thread>
 #include <tuple>
@@ -31,6 +33,13 @@ void set_error(const char* fmt, ...) {
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 }  // namespace bnmtf
+// No C++ exception leaves the library: every entry point that returns a status is a function-try-block ending in this handler
+// (round 6: a std::system_error from a thread that could not be had crossed the ABI once -- std::terminate, the caller's process
+// gone; HISTORY 8.4).  Out of host memory -> BNMTF_ENOMEM, anything else -> BNMTF_EINVAL, the message in bnmtf_last_error().
+#define BNMTF_ABI_GUARD                                                                                                              \
+  catch (const std::bad_alloc&) { bnmtf::set_error("out of host memory"); return BNMTF_ENOMEM; }                                     \
+  catch (const std::exception& e) { bnmtf::set_error("host exception: %s", e.what()); return BNMTF_EINVAL; }                         \
+  catch (...) { bnmtf::set_error("host exception"); return BNMTF_EINVAL; }
 extern "C" int bnmtf_shard_range(int64_t n, int rank, int world, int64_t* first, int64_t* count);
 namespace bnmtf {
 
@@ -1004,24 +1013,24 @@ extern "C" {
 int bnmtf_version(void) { return 100; }
 const char* bnmtf_last_error(void) { return g_err; }
 
-int bnmtf_device_count(int* count) {
+int bnmtf_device_count(int* count) try {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess) { n = 0; (void)hipGetLastError(); }
   *count = n;
   return BNMTF_OK;
-}
+} BNMTF_ABI_GUARD
 
 int bnmtf_comm_unique_id(uint8_t out[128]) { return comm_unique_id(out); }
 
-int bnmtf_shard_range(int64_t n, int rank, int world, int64_t* first, int64_t* count) {
+int bnmtf_shard_range(int64_t n, int rank, int world, int64_t* first, int64_t* count) try {
   if (world < 1 || rank < 0 || rank >= world || n < 0) { set_error("bad shard request"); return BNMTF_EINVAL; }
   *first = n * rank / world;
   *count = n * (rank + 1) / world - *first;
   return BNMTF_OK;
-}
+} BNMTF_ABI_GUARD
 
-int bnmtf_create(const bnmtf_problem* p, bnmtf_handle* out) {
+int bnmtf_create(const bnmtf_problem* p, bnmtf_handle* out) try {
   *out = nullptr;
   if (!p || !p->R || !p->M || !p->lambda_rows || !p->lambda_cols) { set_error("bnmtf_create: null argument"); return BNMTF_EINVAL; }
   if (p->I < 1 || p->J < 1 || p->K < 1 || p->K > BNMTF_MAX_RANK || p->L < 0 || p->L > BNMTF_MAX_RANK) {
@@ -1119,7 +1128,7 @@ int bnmtf_create(const bnmtf_problem* p, bnmtf_handle* out) {
   describe_model(h);
   *out = h;
   return BNMTF_OK;
-}
+} BNMTF_ABI_GUARD
 }  // extern "C"
 
 namespace bnmtf {
@@ -1213,7 +1222,7 @@ static void describe_model(bnmtf_model* h) {
 }  // namespace bnmtf
 extern "C" {
 
-int bnmtf_destroy(bnmtf_handle h) {
+int bnmtf_destroy(bnmtf_handle h) try {
   if (!h) return BNMTF_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -1244,22 +1253,22 @@ int bnmtf_destroy(bnmtf_handle h) {
   if (h->stream && !(h->pool_stream && device_pool().give_stream(h->device, h->stream))) (void)hipStreamDestroy(h->stream);
   delete h;
   return BNMTF_OK;
-}
+} BNMTF_ABI_GUARD
 
-int bnmtf_sync(bnmtf_handle h) {
+int bnmtf_sync(bnmtf_handle h) try {
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
   return BNMTF_OK;
-}
+} BNMTF_ABI_GUARD
 
-int bnmtf_omega_counts(bnmtf_handle h, uint64_t* total, uint32_t* row, uint32_t* col) {
+int bnmtf_omega_counts(bnmtf_handle h, uint64_t* total, uint32_t* row, uint32_t* col) try {
   if (total) *total = (uint64_t)h->n_obs;
   if (row) memcpy(row, h->rows.obs_count.data(), sizeof(uint32_t) * h->I);
   if (col) memcpy(col, h->cols.obs_count.data(), sizeof(uint32_t) * h->J);
   return BNMTF_OK;
-}
+} BNMTF_ABI_GUARD
 
-int bnmtf_host_alloc(size_t bytes, void** out) {
+int bnmtf_host_alloc(size_t bytes, void** out) try {
   *out = nullptr;
   const hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
   if (e != hipSuccess) {
@@ -1269,18 +1278,18 @@ int bnmtf_host_alloc(size_t bytes, void** out) {
     return BNMTF_EHIP;
   }
   return BNMTF_OK;
-}
-int bnmtf_host_free(void* p) {
+} BNMTF_ABI_GUARD
+int bnmtf_host_free(void* p) try {
   if (p) HIPCHK(hipHostFree(p));
   return BNMTF_OK;
-}
+} BNMTF_ABI_GUARD
 
-int bnmtf_set_expectation(bnmtf_handle h, int burn_in, int thinning) {
+int bnmtf_set_expectation(bnmtf_handle h, int burn_in, int thinning) try {
   if (burn_in >= 0 && thinning < 1) { set_error("thinning must be >= 1"); return BNMTF_EINVAL; }
   h->exp_burn = burn_in; h->exp_thin = thinning < 1 ? 1 : thinning;
   return BNMTF_OK;
-}
-int bnmtf_get_expectation(bnmtf_handle h, double* A, double* S, double* B, double* tau, uint64_t* count) {
+} BNMTF_ABI_GUARD
+int bnmtf_get_expectation(bnmtf_handle h, double* A, double* S, double* B, double* tau, uint64_t* count) try {
   if (!h->exp_rows || h->exp_count == 0) { set_error("no samples accumulated (bnmtf_set_expectation before run, burn_in < iterations)"); return BNMTF_ESTATE; }
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -1297,60 +1306,60 @@ int bnmtf_get_expectation(bnmtf_handle h, double* A, double* S, double* B, doubl
   if (tau) { double t; HIPCHK(hipMemcpy(&t, h->exp_tau, sizeof(double), hipMemcpyDeviceToHost)); *tau = t * inv; }
   if (count) *count = h->exp_count;
   return BNMTF_OK;
-}
+} BNMTF_ABI_GUARD
 
 int bnmtf_set_iteration(bnmtf_handle h, uint64_t it) { h->iteration = it; return BNMTF_OK; }
-int bnmtf_set_tau(bnmtf_handle h, double tau) {        // the noise precision alone (the factors on the device stay as they are)
+int bnmtf_set_tau(bnmtf_handle h, double tau) try {        // the noise precision alone (the factors on the device stay as they are)
   if (!h->have_state) { set_error("bnmtf_set_tau before the state is set"); return BNMTF_ESTATE; }
   HIPCHK(hipSetDevice(h->device));
   return set_tau(h, tau);
-}
+} BNMTF_ABI_GUARD
 int bnmtf_get_iteration(bnmtf_handle h, uint64_t* it) { *it = h->iteration; return BNMTF_OK; }
 
-int bnmtf_set_minimum_tn(bnmtf_handle h, double minimum_TN) {
+int bnmtf_set_minimum_tn(bnmtf_handle h, double minimum_TN) try {
   if (!(minimum_TN >= 0.0)) { set_error("minimum_TN must be >= 0"); return BNMTF_EINVAL; }
   h->min_tn = minimum_TN;
   return BNMTF_OK;
-}
-int bnmtf_set_profiling(bnmtf_handle h, int enable) {
+} BNMTF_ABI_GUARD
+int bnmtf_set_profiling(bnmtf_handle h, int enable) try {
   // 0: off; 1: every kernel; 2 + k: kernel k only (so that a timed region carries two event records, not eight)
   h->profiling = enable == 0 ? 0u : (enable == 1 ? 0xFFFFFFFFu : 1u << (unsigned)((enable - 2) & 31));
   h->profile_stride = enable >= 2 ? (uint64_t)((enable - 2) >> 5) + 1 : 1;     // every n-th iteration only: an event record costs the queue a few microseconds
   for (int i = 0; i < BNMTF_KERNEL_COUNT; ++i) { h->kernel_ms[i] = 0; h->kernel_launches[i] = 0; }
   return BNMTF_OK;
-}
+} BNMTF_ABI_GUARD
 int bnmtf_set_sweep_path(bnmtf_handle h, int fast) { h->use_fast = fast != 0; h->ho_regions_current = false; return BNMTF_OK; }
 int bnmtf_comm_info(bnmtf_handle h, int* kind, int* ranks) { return comm_info(h->comm, kind, ranks); }
-int bnmtf_has_experiments(void) {
+int bnmtf_has_experiments(void) try {
 #ifdef BNMTF_EXPERIMENTS
   return 1;
 #else
   return 0;
 #endif
-}
-int bnmtf_set_small_path(bnmtf_handle h, int mode) {
+} BNMTF_ABI_GUARD
+int bnmtf_set_small_path(bnmtf_handle h, int mode) try {
   if (mode < 0 || mode > 2) { set_error("bnmtf_set_small_path: mode 0 (never), 1 (auto) or 2 (always)"); return BNMTF_EINVAL; }
   h->small_mode = mode;
   return BNMTF_OK;
-}
+} BNMTF_ABI_GUARD
 int bnmtf_is_small(bnmtf_handle h, int* out) { *out = small_wanted(h) ? 1 : 0; return BNMTF_OK; }
-int bnmtf_kernel_stats(bnmtf_handle h, int kernel, double* total_ms, uint64_t* launches) {
+int bnmtf_kernel_stats(bnmtf_handle h, int kernel, double* total_ms, uint64_t* launches) try {
   if (kernel < 0 || kernel >= BNMTF_KERNEL_COUNT) { set_error("bad kernel id"); return BNMTF_EINVAL; }
   HIPCHK(hipStreamSynchronize(h->stream));
   drain_events(h);
   *total_ms = h->kernel_ms[kernel]; *launches = h->kernel_launches[kernel];
   return BNMTF_OK;
-}
-int bnmtf_describe(bnmtf_handle h, char* buf, size_t buflen) {
+} BNMTF_ABI_GUARD
+int bnmtf_describe(bnmtf_handle h, char* buf, size_t buflen) try {
   // (+ which kernels the last variational half sweep ran on: vb_chip_ok)
   static const char* const kVbPath[] = {"", " vb_sweep=generic", " vb_sweep=pairs", " vb_sweep=masked"};
   static const char* const kTriPath[] = {"", " tri_vb_sweeps=generic", " tri_vb_sweeps=pairs+cov", ""};      // (bnmtf_vb_run: api_trivb.inc enqueue_tri_sweep)
   snprintf(buf, buflen, "%s%s%s", h->description.c_str(), kVbPath[h->last_vb_path & 3], kTriPath[h->last_tri_path & 3]);
   return BNMTF_OK;
-}
+} BNMTF_ABI_GUARD
 
 // ------------------------------------------------------------------ BNMF Gibbs
-int bnmf_set_state(bnmtf_handle h, const double* U, const double* V, double tau) {
+int bnmf_set_state(bnmtf_handle h, const double* U, const double* V, double tau) try {
   if (h->L != 0) { set_error("bnmf_set_state on a BNMTF handle"); return BNMTF_ESTATE; }
   HIPCHK(hipSetDevice(h->device));
   h->std_cur = false; h->small_cur = false;
@@ -1364,9 +1373,9 @@ int bnmf_set_state(bnmtf_handle h, const double* U, const double* V, double tau)
   h->have_state = true;
   h->ho_regions_current = false;          // (q hand-over: whatever the regions hold belongs to the state that was just replaced)
   return BNMTF_OK;
-}
+} BNMTF_ABI_GUARD
 
-int bnmf_get_state(bnmtf_handle h, double* U, double* V, double* tau) {
+int bnmf_get_state(bnmtf_handle h, double* U, double* V, double* tau) try {
   if (!h->have_state) { set_error("no state set"); return BNMTF_ESTATE; }
   HIPCHK(hipSetDevice(h->device));
   if (h->small && h->small_cur) CHK(small_download_state(h, U, V));
@@ -1379,9 +1388,9 @@ int bnmf_get_state(bnmtf_handle h, double* U, double* V, double* tau) {
     HIPCHK(hipStreamSynchronize(h->stream));
   }
   return BNMTF_OK;
-}
+} BNMTF_ABI_GUARD
 
-int bnmf_cond_params(bnmtf_handle h, int which, int k, double* numer_out, double* tau_out) {
+int bnmf_cond_params(bnmtf_handle h, int which, int k, double* numer_out, double* tau_out) try {
   if (!h->have_state) { set_error("no state set"); return BNMTF_ESTATE; }
   if (h->world != 1) { set_error("cond_params is a single-GPU test hook"); return BNMTF_EINVAL; }
   Dir& d = which == 0 ? h->rows : h->cols;
@@ -1398,10 +1407,10 @@ int bnmf_cond_params(bnmtf_handle h, int which, int k, double* numer_out, double
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipGetLastError());
   return BNMTF_OK;
-}
+} BNMTF_ABI_GUARD
 
 int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* V_out,
-                   double* tau_out, double* perf_out, double* times_out) {
+                   double* tau_out, double* perf_out, double* times_out) try {
   if (h->L != 0) { set_error("bnmf_gibbs_run on a BNMTF handle"); return BNMTF_ESTATE; }
   if (!h->have_state) { set_error("bnmf_gibbs_run before bnmf_set_state"); return BNMTF_ESTATE; }
   if (n_iter < 0) { set_error("negative iteration count"); return BNMTF_EINVAL; }
@@ -1509,11 +1518,11 @@ int bnmf_gibbs_run(bnmtf_handle h, int n_iter, int update, float* U_out, float* 
     }
   }
   return BNMTF_OK;
-}
+} BNMTF_ABI_GUARD
 
 int bnmf_gibbs_run_many(const bnmtf_handle* hs, int n_models, int n_iter, int update, float* const* U_outs, float* const* V_outs,
                         double* const* tau_outs, double* const* perf_outs, double* const* times_outs,
-                        double* const* U_final, double* const* V_final, double* const* tau_final) {
+                        double* const* U_final, double* const* V_final, double* const* tau_final) try {
   if (n_models < 0 || n_iter < 0) { set_error("negative count"); return BNMTF_EINVAL; }
   if (n_models == 0 || n_iter == 0) return BNMTF_OK;
   if (update < 0 || update > BNMTF_UPDATE_ICM) { set_error("unknown update rule"); return BNMTF_EINVAL; }
@@ -1559,23 +1568,23 @@ int bnmf_gibbs_run_many(const bnmtf_handle* hs, int n_models, int n_iter, int up
     CHK(small_run_many(batch.data(), (int)batch.size(), n_iter, update, outs.data()));
   }
   return BNMTF_OK;
-}
+} BNMTF_ABI_GUARD
 
 // ---------------------------------------------------------------------- ranks above 64: a factorisation as column blocks
 // The reference takes any K (bnmf_gibbs_optimised.py:54-78).  The kernels hold a latent factor per wave lane (K <= 64), so a wider
 // model runs as ceil(K / 64) COLUMN BLOCKS, one handle each (bnmtf_amd/_blocked.py): the conditionals of block b's columns given the
 // other blocks are those of a rank-K_b model on the residual data R - sum_{b' != b} U_b' V_b'^T -- exactly the reference's
 // sequential column order when the blocks' half sweeps run in turn, rows first (:134-137), then columns (:139-142).
-int bnmf_set_column_block(bnmtf_handle h, int col0) {
+int bnmf_set_column_block(bnmtf_handle h, int col0) try {
   if (col0 < 0) { set_error("negative column offset"); return BNMTF_EINVAL; }
   if (h->L != 0 || h->comm) { set_error("column blocks: BNMF handles on one GPU"); return BNMTF_ESTATE; }
   h->col0 = (uint32_t)col0;
   h->block_mode = true;
   h->small_mode = 0;                          // (the one-launch kernel runs whole iterations: not a block's half sweeps)
   return BNMTF_OK;
-}
+} BNMTF_ABI_GUARD
 
-int bnmf_set_residual_data(bnmtf_handle h, const bnmtf_handle* others, int n_others) {
+int bnmf_set_residual_data(bnmtf_handle h, const bnmtf_handle* others, int n_others) try {
   if (n_others < 0 || n_others > kMaxOtherBlocks) { set_error("at most %d other column blocks", kMaxOtherBlocks); return BNMTF_EINVAL; }
   if (h->comm) { set_error("residual data: one GPU"); return BNMTF_ESTATE; }       // (the target may be a BNMTF handle -- an S block of a wider tri-factorisation; the others are two-factor products)
   HIPCHK(hipSetDevice(h->device));
@@ -1597,12 +1606,12 @@ int bnmf_set_residual_data(bnmtf_handle h, const bnmtf_handle* others, int n_oth
   }
   HIPCHK(hipGetLastError());
   return BNMTF_OK;
-}
+} BNMTF_ABI_GUARD
 
 // one half of an iteration of run(): the contraction, the K sequential column updates of one factor (which = 0: U, :134-137; 1: V,
 // :139-142) with the handle's current tau and iteration counter, the relayout + Gram the other direction reads.  tau, the
 // metrics, the samples and the iteration counter are the caller's (a column-blocked model: bnmtf_amd/_blocked.py).
-int bnmf_half_sweep(bnmtf_handle h, int which, int update) {
+int bnmf_half_sweep(bnmtf_handle h, int which, int update) try {
   if (which < 0 || which > 1 || update < 0 || update > BNMTF_UPDATE_ICM) { set_error("bnmf_half_sweep: which in {0, 1}, a known update rule"); return BNMTF_EINVAL; }
   if (h->L != 0 || h->comm) { set_error("bnmf_half_sweep: BNMF handles on one GPU"); return BNMTF_ESTATE; }
   if (!h->have_state) { set_error("no state set"); return BNMTF_ESTATE; }
@@ -1623,17 +1632,17 @@ int bnmf_half_sweep(bnmtf_handle h, int which, int update) {
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipGetLastError());
   return BNMTF_OK;
-}
+} BNMTF_ABI_GUARD
 
 // ---------------------------------------------------------------------- metrics
 static int metric_sums_impl(bnmtf_handle h, const uint8_t* Mp, const double* A, const double* S, const double* B, double sums_out[6], int Kc_given);
 int bnmtf_metric_sums(bnmtf_handle h, const uint8_t* Mp, const double* A, const double* S, const double* B,
                       double sums_out[6]) { return metric_sums_impl(h, Mp, A, S, B, sums_out, 0); }
-int bnmtf_metric_sums_wide(bnmtf_handle h, const uint8_t* Mp, const double* A, const double* B, int Kc, double sums_out[6]) {
+int bnmtf_metric_sums_wide(bnmtf_handle h, const uint8_t* Mp, const double* A, const double* B, int Kc, double sums_out[6]) try {
   if (!A || !B || Kc <= 0) { set_error("bnmtf_metric_sums_wide: A [I][Kc], B [J][Kc] and Kc > 0 required"); return BNMTF_EINVAL; }
   if (h->L != 0) { set_error("bnmtf_metric_sums_wide on a BNMTF handle"); return BNMTF_ESTATE; }
   return metric_sums_impl(h, Mp, A, nullptr, B, sums_out, Kc);
-}
+} BNMTF_ABI_GUARD
 static int metric_sums_impl(bnmtf_handle h, const uint8_t* Mp, const double* A, const double* S, const double* B, double sums_out[6], int Kc_given) {
   HIPCHK(hipSetDevice(h->device));
   const int I = h->I, J = h->J;
@@ -1702,16 +1711,16 @@ static int metric_sums_impl(bnmtf_handle h, const uint8_t* Mp, const double* A, 
   return BNMTF_OK;
 }
 
-int bnmtf_beta_s(bnmtf_handle h, double* out) {
+int bnmtf_beta_s(bnmtf_handle h, double* out) try {
   double s[6];
   CHK(bnmtf_metric_sums(h, nullptr, nullptr, nullptr, nullptr, s));
   *out = h->beta + 0.5 * (s[2] - 2.0 * s[5] + s[4]);
   return BNMTF_OK;
-}
+} BNMTF_ABI_GUARD
 
 // ---------------------------------------------------------------- distributions
 int bnmtf_tn_sample(const double* mu, const double* tau, size_t n, uint64_t seed, uint64_t it, uint32_t col,
-                    uint32_t elem0, int device, double* out) {
+                    uint32_t elem0, int device, double* out) try {
   if (n == 0) return BNMTF_OK;
   HIPCHK(hipSetDevice(device));
   DevBuf<double> dm, dt, dout;
@@ -1722,9 +1731,9 @@ int bnmtf_tn_sample(const double* mu, const double* tau, size_t n, uint64_t seed
   HIPCHK(hipMemcpy(out, dout.p, n * sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipGetLastError());
   return BNMTF_OK;
-}
+} BNMTF_ABI_GUARD
 
-int bnmtf_tn_moments(const double* mu, const double* tau, size_t n, int device, double* exp_out, double* var_out) {
+int bnmtf_tn_moments(const double* mu, const double* tau, size_t n, int device, double* exp_out, double* var_out) try {
   if (n == 0) return BNMTF_OK;
   HIPCHK(hipSetDevice(device));
   DevBuf<double> dm, dt, de, dv;
@@ -1736,9 +1745,9 @@ int bnmtf_tn_moments(const double* mu, const double* tau, size_t n, int device, 
   HIPCHK(hipMemcpy(var_out, dv.p, n * sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipGetLastError());
   return BNMTF_OK;
-}
+} BNMTF_ABI_GUARD
 
-int bnmtf_gamma_sample(double alpha, double beta, uint64_t seed, uint64_t it, int device, double* out) {
+int bnmtf_gamma_sample(double alpha, double beta, uint64_t seed, uint64_t it, int device, double* out) try {
   HIPCHK(hipSetDevice(device));
   DevBuf<double> d;
   CHK(d.alloc(1, true));
@@ -1746,7 +1755,7 @@ int bnmtf_gamma_sample(double alpha, double beta, uint64_t seed, uint64_t it, in
   HIPCHK(hipMemcpy(out, d.p, sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipGetLastError());
   return BNMTF_OK;
-}
+} BNMTF_ABI_GUARD
 
 }  // extern "C"
 

@@ -15,6 +15,7 @@
 
 extern "C" long hipstub_launches();
 extern "C" long hipstub_live_allocs();
+extern "C" void hipstub_throw_at_sync(long n);
 
 #define OK(expr)                                                                                     \
   do {                                                                                               \
@@ -91,6 +92,19 @@ static void bnmf_round_trip(const Data& d, int K, int iters, bool samples) {
   }
   char buf[2048];
   OK(bnmtf_describe(h, buf, sizeof buf));
+  OK(bnmtf_destroy(h));
+}
+
+// a C++ exception inside an entry point comes back as a status with its message; the handle is still good afterwards
+static void exception_stays_inside(const Data& d, int K) {
+  bnmtf_handle h = create(d, K, 0, 0, 1, nullptr);
+  std::vector<double> U((size_t)d.I * K, 1.0), V((size_t)d.J * K, 1.0);
+  OK(bnmf_set_state(h, U.data(), V.data(), 1.0));
+  hipstub_throw_at_sync(1);
+  const int rc = bnmf_gibbs_run(h, 2, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+  if (rc != BNMTF_EINVAL || !strstr(bnmtf_last_error(), "injected by the stub")) { fprintf(stderr, "exception guard: rc %d, message '%s'\n", rc, bnmtf_last_error()); exit(1); }
+  hipstub_throw_at_sync(0);
+  OK(bnmf_gibbs_run(h, 2, 0, nullptr, nullptr, nullptr, nullptr, nullptr));
   OK(bnmtf_destroy(h));
 }
 
@@ -282,6 +296,7 @@ static void sharded(const Data& d, int K, int L, int world, const char* token, i
       }
       OK(bnmtf_destroy(h));
       rc[r] = 1;
+  exception_stays_inside(make_data(515, 389, 0.12, 27), 24);
   vb_many(make_data(300, 120, 0.15, 21), make_data(210, 150, 0.1, 22), 12);
   {   // two host threads, a list of models each (the recorder is thread-local)
     const Data da = make_data(280, 110, 0.15, 23), db = make_data(190, 160, 0.1, 24), dc = make_data(260, 100, 0.2, 25), dd = make_data(150, 170, 0.1, 26);

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <stdexcept>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -50,7 +51,14 @@ hipError_t hipPointerGetAttributes(hipPointerAttribute_t*, const void*) { return
 
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = reinterpret_cast<hipStream_t>(malloc(8)); ++g_allocs; return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { free(s); --g_allocs; return hipSuccess; }
-hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+// hipstub_throw_at_sync(n): the n-th stream synchronisation from now throws -- a C++ exception inside an entry point of the library,
+// which must come back as a status, not cross the C ABI (api.hip: BNMTF_ABI_GUARD)
+static thread_local long t_throw_at = 0;          // (per host thread: the driver walks the ABI from several at a time)
+extern "C" void hipstub_throw_at_sync(long n) { t_throw_at = n; }
+hipError_t hipStreamSynchronize(hipStream_t) {
+  if (t_throw_at > 0 && --t_throw_at == 0) throw std::runtime_error("injected by the stub");
+  return hipSuccess;
+}
 hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* e) { *e = reinterpret_cast<hipEvent_t>(new StubEvent{std::chrono::steady_clock::now()}); ++g_allocs; return hipSuccess; }
