@@ -23,13 +23,21 @@ while time.time() - t0 < budget:
     b = bnmf_gibbs_optimised(R, M, K, pri, verbose=False, seed=3)
     b.U, b.V, b.tau = U0.copy(), V0.copy(), 0.9
     b.run(2, update="mode")
-    o = O.BNMFGibbsOracle(R, M, K, pri, seed=3)
-    o.U, o.V, o.tau = U0.copy(), V0.copy(), 0.9
-    with np.errstate(all="ignore"):
-        o.run(2, draw=False)
-    errs["gibbs_U"] = float(np.abs(b.all_U[-1] - o.all_U[-1]).max() / max(1.0, np.abs(o.all_U[-1]).max()))
-    errs["gibbs_V"] = float(np.abs(b.all_V[-1] - o.all_V[-1]).max() / max(1.0, np.abs(o.all_V[-1]).max()))
-    errs["gibbs_tau"] = float(np.abs(b.all_tau / o.all_tau - 1).max())
+    # every iteration against the oracle STARTED FROM THE DEVICE'S previous state: a rank far above the matrix's extent is an
+    # ill-conditioned fit, and a free-running oracle amplifies the first iteration's fp32 rounding (seed 11: K = 168 on 113 x 113,
+    # 2e-5 after one iteration, 5e-3 after two -- and 2e-6 against the restarted oracle; tools/r06/wide_bnmf_case.py)
+    errs["gibbs_U"] = errs["gibbs_V"] = errs["gibbs_tau"] = 0.0
+    for it in range(2):
+        o = O.BNMFGibbsOracle(R, M, K, pri, seed=3)
+        if it == 0:
+            o.U, o.V, o.tau = U0.copy(), V0.copy(), 0.9
+        else:
+            o.U, o.V, o.tau = b.all_U[it - 1].astype(float), b.all_V[it - 1].astype(float), float(b.all_tau[it - 1])
+        with np.errstate(all="ignore"):
+            o.run(1, draw=False)
+        errs["gibbs_U"] = max(errs["gibbs_U"], float(np.abs(b.all_U[it] - o.all_U[0]).max() / max(1.0, np.abs(o.all_U[0]).max())))
+        errs["gibbs_V"] = max(errs["gibbs_V"], float(np.abs(b.all_V[it] - o.all_V[0]).max() / max(1.0, np.abs(o.all_V[0]).max())))
+        errs["gibbs_tau"] = max(errs["gibbs_tau"], float(abs(b.all_tau[it] / o.all_tau[0] - 1)))
     b.close()
     v = bnmf_vb_optimised(R, M, K, pri, verbose=False)
     v.initialise("exp")
@@ -43,7 +51,7 @@ while time.time() - t0 < budget:
     errs["vb_exptau"] = float(np.abs(np.array(v.all_exp_tau) / np.array(ov.all_exp_tau) - 1).max())
     v.close()
     n += 1; worst = max(worst, max(errs.values()))
-    bad = {k: x for k, x in errs.items() if not (x < 3e-3)}
+    bad = {k: x for k, x in errs.items() if not (x < (3e-4 if k.startswith("gibbs") else 3e-3))}
     if bad:
         print("MISMATCH", dict(I=I, J=J, K=K, lam=lam), errs); sys.exit(1)
 print("fuzz_wide_bnmf: %d cases, worst relative difference %.2e" % (n, worst))

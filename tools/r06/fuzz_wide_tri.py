@@ -23,28 +23,62 @@ while time.time() - t0 < budget:
     F0 = rs.exponential(a0, (I, K)); S0 = rs.exponential(a0, (K, L)); G0 = rs.exponential(a0, (J, L))
     seed = int(rs.randint(1 << 30))
     errs = {}
-    for draw in (False, True):
-        b = bnmtf_gibbs_optimised(R, M, K, L, pri, verbose=False, seed=seed)
-        b.F, b.S, b.G, b.tau = F0.copy(), S0.copy(), G0.copy(), 0.8
-        its = 1 if draw else 2
-        b.run(its, update="draw" if draw else "mode")
+    from oracle import rng as orng
+    rows, cols = np.arange(I), np.arange(J)
+    # ---- two iterations of mode updates, each against the oracle started from the device's previous state (a free-running oracle
+    # amplifies the first iteration's fp32 rounding on these over-parameterised fits)
+    b = bnmtf_gibbs_optimised(R, M, K, L, pri, verbose=False, seed=seed)
+    b.F, b.S, b.G, b.tau = F0.copy(), S0.copy(), G0.copy(), 0.8
+    b.run(2, update="mode")
+    for name in ("F", "S", "G", "mse"):
+        errs["mode_" + name] = 0.0
+    floor = 1e-2 * float(R[M > 0].var())      # (ranks far above the matrix's extent fit it exactly: the MSE is then rounding of a difference -- scale by the data's spread)
+    for it in range(2):
         o = O.BNMTFGibbsOracle(R, M, K, L, pri, seed=seed)
-        o.F, o.S, o.G, o.tau = F0.copy(), S0.copy(), G0.copy(), 0.8
+        if it == 0:
+            o.F, o.S, o.G, o.tau = F0.copy(), S0.copy(), G0.copy(), 0.8
+        else:
+            o.F, o.S, o.G, o.tau = b.all_F[0].astype(float), b.all_S[0].astype(float), b.all_G[0].astype(float), float(b.all_tau[0])
         with np.errstate(all="ignore"):
-            o.run(its, draw=draw)
-        for name, dev, ora in (("F", b.all_F[0], o.all_F[0]), ("S", b.all_S[0], o.all_S[0]), ("G", b.all_G[0], o.all_G[0])):
-            d = np.abs(dev - ora) / (1e-3 + np.abs(ora))
-            if draw:
-                errs["draw_" + name] = 1.0 - float(np.mean(d < 3e-3))          # share of entries off (decisions on a rounding boundary)
-            else:
-                errs["mode_" + name] = float(np.abs(dev - ora).max() / (np.abs(ora).max() + 1e-30))
-        if not draw:
-            # (ranks far above the matrix's extent fit it exactly: the MSE is then rounding of a difference -- scale by the data's spread)
-            floor = 1e-2 * float(R[M > 0].var())
-            errs["mode_mse"] = float((np.abs(np.array(b.all_performances["MSE"]) - np.array(o.all_performances["MSE"])) / np.maximum(np.array(o.all_performances["MSE"]), floor)).max())
-        b.close()
+            o.run(1, draw=False)
+        for name, dev, ora in (("F", b.all_F[it], o.all_F[0]), ("S", b.all_S[it], o.all_S[0]), ("G", b.all_G[it], o.all_G[0])):
+            errs["mode_" + name] = max(errs["mode_" + name], float(np.abs(dev - ora).max() / (np.abs(ora).max() + 1e-30)))
+        errs["mode_mse"] = max(errs["mode_mse"], float(abs(b.all_performances["MSE"][it] - o.all_performances["MSE"][0]) / max(o.all_performances["MSE"][0], floor)))
+    b.close()
+    # ---- one iteration of draws on the same Philox keys, the oracle walked BY HAND with the device's earlier values in it: a
+    # candidate within rounding of zero is accepted by one side and rejected by the other (seed 11: step 1 060 of 1 700, mu 0.525537
+    # against 0.525508, x = 2.4e-6 against the next candidate 0.4455), and everything behind such a step differs in a free-running
+    # comparison (481 entries there; tools/r06/wide_tri_case.py).  Walked like this only the entries ON a boundary are off.
+    b = bnmtf_gibbs_optimised(R, M, K, L, pri, verbose=False, seed=seed)
+    b.F, b.S, b.G, b.tau = F0.copy(), S0.copy(), G0.copy(), 0.8
+    b.run(1, update="draw")
+    Fd, Sd, Gd = b.all_F[0].astype(float), b.all_S[0].astype(float), b.all_G[0].astype(float)
+    o = O.BNMTFGibbsOracle(R, M, K, L, pri, seed=seed)
+    o.F, o.S, o.G, o.tau = F0.copy(), S0.copy(), G0.copy(), 0.8
+    off = lambda dev, ora: np.abs(dev - ora) / (1e-3 + np.abs(ora)) >= 3e-3
+    with np.errstate(all="ignore"):
+        n_off = 0
+        for k in range(K):
+            t = o.tauF(k); m = o.muF(t, k)
+            n_off += int(off(Fd[:, k], orng.tn_draw(m, t, rows, k, 0, orng.STREAM_ROWS, o.seed)).sum())
+            o.F[:, k] = Fd[:, k]
+        errs["draw_F"] = n_off / float(I * K)
+        n_off = 0
+        for k in range(K):
+            for l in range(L):
+                t = o.tauS(k, l); m = o.muS(t, k, l)
+                n_off += int(off(Sd[k, l], float(orng.tn_draw(m, t, 0, k * L + l, 0, orng.STREAM_S, o.seed))))
+                o.S[k, l] = Sd[k, l]
+        errs["draw_S"] = n_off / float(K * L)
+        n_off = 0
+        for l in range(L):
+            t = o.tauG(l); m = o.muG(t, l)
+            n_off += int(off(Gd[:, l], orng.tn_draw(m, t, cols, l, 0, orng.STREAM_COLS, o.seed)).sum())
+            o.G[:, l] = Gd[:, l]
+        errs["draw_G"] = n_off / float(J * L)
+    b.close()
     # (the MSE of a fit this tight is a small difference of large products: the fp32 factors' 1e-4 shows there as 1e-2)
-    bad = {k: v for k, v in errs.items() if not (v < (0.03 if k.startswith("draw") else (2e-2 if k == "mode_mse" else 3e-3)))}
+    bad = {k: v for k, v in errs.items() if not (v < (0.005 if k.startswith("draw") else (2e-2 if k == "mode_mse" else 3e-3)))}
     n += 1; worst = max(worst, max(v for k, v in errs.items() if k.startswith("mode")))
     if bad:
         print("MISMATCH", dict(I=I, J=J, K=K, L=L, seed=seed), errs); sys.exit(1)
