@@ -5,8 +5,10 @@
 The reference fits the candidates of a model search -- folds x ranks x restarts -- one after the other
 (code/cross_validation/line_search_cross_validation.py:54-131, line_search_bnmf.py:53-76) or in a process pool
 (parallel_matrix_cross_validation.py:40-74).  Small BNMF and BNMTF Gibbs models run on the device as ONE block each
-(csrc/kernel_small.hip), so a list of them is one launch per kind; models that do not qualify are run in turn.  ICM models (nmf_icm:
-their own run(), update rule and minimum_TN) are not taken: ReplicaPool runs them one by one."""
+(csrc/kernel_small.hip), so a list of them is one launch per kind; models that do not qualify are run in turn.  Variational models
+(bnmf_vb_optimised, any size its 8-wave kernels serve) walk their iterations in lock-step: every kernel of an iteration is ONE
+launch for all of them (csrc/many.h, api_many.inc: bnmf_vb_run_many), each model ending with the bits of its own run().  ICM models
+(nmf_icm: their own run(), update rule and minimum_TN) are not taken: ReplicaPool runs them one by one."""
 import ctypes as C
 import time
 
